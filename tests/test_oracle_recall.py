@@ -1,0 +1,83 @@
+"""CPU: constructed rank cases for the RecallAtK restatement (model/metric.py:137-161)."""
+import numpy as np
+import torch
+
+from oracle import eval_ref as E
+
+
+def unit(x):
+    return x / np.linalg.norm(x, axis=-1, keepdims=True)
+
+
+def planted(n=64, d=32, ranks=(1, 2, 5, 6, 10, 11), seed=0):
+    """Gallery a = orthonormal-ish random unit rows; query i is built so that its own row i sits
+    at a chosen rank: r-1 other gallery rows are strictly closer."""
+    rng = np.random.default_rng(seed)
+    a = unit(rng.standard_normal((n, d))).astype(np.float32)
+    b = np.empty_like(a)
+    want = np.array([ranks[i % len(ranks)] for i in range(n)])
+    for i in range(n):
+        others = [j for j in range(n) if j != i][: want[i] - 1]
+        q = a[i].copy()
+        # move the query toward `others` so they become closer than the target
+        for j in others:
+            q = q + 1.5 * a[j]
+        b[i] = q
+    return a, b, want
+
+
+def test_permuted_identity_is_recall_one():
+    rng = np.random.default_rng(1)
+    a = unit(rng.standard_normal((50, 16))).astype(np.float32)
+    res = E.recall_at_k(a, a.copy(), [1, 5, 10])
+    assert res == [(1, 1.0), (5, 1.0), (10, 1.0)]
+
+
+def test_planted_ranks_match_fp64_truth():
+    a, b, want = planted()
+    ids64, _ = E.l2_topk(a, b, 11, np.float64)
+    rank = np.array([int(np.nonzero(ids64[i] == i)[0][0]) + 1 if (ids64[i] == i).any() else 99 for i in range(len(a))])
+    got = dict(E.recall_at_k(a, b, [1, 5, 10]))
+    for k in (1, 5, 10):
+        assert abs(got[k] - (rank <= k).mean()) < 1e-12
+    assert E.near_ties(a, b) == 0
+    # depth is max(k)+1 and the hit test is `target in rp[:k]` (metric.py:145,153)
+    assert 0 < got[1] < got[5] < got[10] < 1.0
+
+
+def test_non_unit_gallery_l2_differs_from_cosine():
+    """retrieval_evaluation.py:254-259 averages chunk embeddings WITHOUT renormalising, so the
+    gallery is not unit-norm and squared-L2 order != cosine order (SURVEY 7 hard parts)."""
+    a = np.array([[1.0, 0.0], [3.0, 0.6]], dtype=np.float32)   # row 1 has the larger cosine to q, but is far
+    q = np.array([[0.9, 0.3], [3.0, 0.6]], dtype=np.float32)
+    ids, _ = E.l2_topk(a, q, 2)
+    cos = (q[0] @ a.T) / np.linalg.norm(a, axis=1)
+    assert np.argmax(cos) == 1 and ids[0, 0] == 0
+
+
+def test_exact_ties_lowest_index_first():
+    a = np.zeros((4, 3), dtype=np.float32)
+    a[:, 0] = 1.0                                              # four identical gallery rows
+    ids, ds = E.l2_topk(a, a[:2], 4)
+    assert ids.tolist() == [[0, 1, 2, 3], [0, 1, 2, 3]]
+    # query 1's own row is at rank 2 under the lowest-index rule
+    assert dict(E.recall_at_k(a, a.copy(), [1, 2]))[1] == 0.25
+
+
+def test_denominator_is_gallery_size():
+    rng = np.random.default_rng(3)
+    a = unit(rng.standard_normal((10, 8))).astype(np.float32)
+    b = a[:4].copy()                                           # fewer queries than gallery rows
+    assert E.recall_at_k(a, b, [1])[0][1] == 4 / 10            # metric.py:138,158
+
+
+def test_chunking_and_mean():
+    fr = torch.arange(1 * 200 * 3 * 2 * 2, dtype=torch.float32).reshape(1, 200, 3, 2, 2)
+    ch = E.chunk_frames(fr, frame_stride=16, nframes=8)        # 13 strided frames -> 8 + 5(resampled to 8)
+    assert ch.shape == (2, 8, 3, 2, 2)
+    strided = fr[:, ::16]
+    assert torch.equal(ch[0], strided[0, :8])
+    idx = torch.floor(torch.linspace(0, 4, 8)).long()
+    assert torch.equal(ch[1], strided[0, 8:][idx])
+    m = E.mean_chunks([torch.tensor([[1.0, 0.0], [0.0, 1.0]]), torch.tensor([[2.0, 2.0]])])
+    assert torch.allclose(m, torch.tensor([[0.5, 0.5], [2.0, 2.0]]))   # not renormalised

@@ -1,0 +1,168 @@
+/*
+ * vtc_hip.h -- C ABI of libvtc_hip.so: the MI355X (gfx950) implementation of the VTC
+ * retrieval forward/eval hot path.
+ *
+ * The reference (unitaryai/VTC) is pure Python: its native boundary for this path is
+ * torch / openai-CLIP / faiss internals, it has no FFI of its own.  These entry points are
+ * therefore what a binding for this path would call; each one names the reference
+ * interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - `stream` is a hipStream_t passed as void* (so this header needs no HIP headers);
+ *   - functions only enqueue work on `stream`; they never allocate, free or synchronise;
+ *   - scratch memory is caller-provided: ask vtc_*_workspace_bytes(), pass `ws`/`ws_bytes`;
+ *   - return 0 on success, non-zero on error (see vtc_last_error); nothing throws;
+ *   - `dtype` selects the arithmetic of the GEMM/attention operands: VTC_F32 (exact fp32
+ *     MFMA) or VTC_BF16 (bf16 operands, fp32 accumulate).  LayerNorm, softmax, residual
+ *     stream, biases and all outputs are fp32 in both modes;
+ *   - weight matrices are row-major [out_features, in_features] (PyTorch Linear layout) in
+ *     the compute dtype; biases and LayerNorm parameters are fp32.
+ */
+#ifndef VTC_HIP_H
+#define VTC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VTC_F32 = 0, VTC_BF16 = 1 };
+
+/* residual activations of the CAM, model/model.py:65-77 (stateless ones) */
+enum { VTC_ACT_NONE = 0, VTC_ACT_NORMALIZE = 1, VTC_ACT_SQUASH = 2, VTC_ACT_TANH = 3 };
+
+/* sweep precision: how q.g is formed from fp32 embeddings */
+enum { VTC_SWEEP_F32 = 0,      /* fp32 MFMA, bitwise a k-ordered fmaf chain            */
+       VTC_SWEEP_BF16X3 = 1,   /* hi/lo bf16 split, 3 products: |err| ~ 5e-7           */
+       VTC_SWEEP_BF16 = 2 };   /* plain bf16 operands: |err| ~ 1e-3, ranks may differ  */
+
+/* One residual attention block.
+ * upstream clip/model.py ResidualAttentionBlock; TimeSformer extras
+ * model/timesformer_clip_alt.py:112-129 (NULL for ViT / text / CAM blocks). */
+typedef struct {
+  const float *ln1_g, *ln1_b;
+  const void  *qkv_w;  const float *qkv_b;   /* attn.in_proj_{weight,bias}   [3W,W],[3W] */
+  const void  *out_w;  const float *out_b;   /* attn.out_proj                [W,W],[W]   */
+  const float *ln2_g, *ln2_b;
+  const void  *fc_w;   const float *fc_b;    /* mlp.c_fc                     [4W,W],[4W] */
+  const void  *proj_w; const float *proj_b;  /* mlp.c_proj                   [W,4W],[W]  */
+  const float *lnt_g, *lnt_b;                /* ln_time                                  */
+  const void  *tqkv_w; const float *tqkv_b;  /* timeattn.in_proj                         */
+  const void  *tout_w; const float *tout_b;  /* timeattn.out_proj; NULL => tfc_* holds the
+                                                pre-multiplied map temporal_fc o out_proj */
+  const void  *tfc_w;  const float *tfc_b;   /* temporal_fc                  [W,W],[W]   */
+} vtc_block_w;
+
+/* Vision tower: upstream VisionTransformer (nframes == 0) or
+ * model/timesformer_clip_alt.py:203-286 VisualTransformer (nframes > 0). */
+typedef struct {
+  int width, heads, layers, patch, grid, embed_dim, nframes;
+  const void  *conv_w;            /* conv1.weight flattened [W, 3*patch*patch]            */
+  const float *class_embedding;   /* [W]                                                  */
+  const float *pos;               /* positional_embedding [1+grid*grid, W]                */
+  const float *temporal;          /* temporal_embed [nframes, W] or NULL                  */
+  const float *ln_pre_g, *ln_pre_b, *ln_post_g, *ln_post_b;
+  const void  *proj_t;            /* proj^T [embed_dim, W]                                */
+  const vtc_block_w *blocks;      /* HOST array of `layers` entries                       */
+} vtc_vision_w;
+
+/* Text tower: upstream CLIP.encode_text. */
+typedef struct {
+  int width, heads, layers, ctx, vocab, embed_dim;
+  const float *tok_emb;           /* token_embedding.weight [vocab, W] fp32               */
+  const float *pos;               /* positional_embedding [ctx, W]                        */
+  const float *ln_final_g, *ln_final_b;
+  const void  *proj_t;            /* text_projection^T [embed_dim, W]                     */
+  const vtc_block_w *blocks;      /* HOST array                                           */
+} vtc_text_w;
+
+/* Context Adapter Module: model/model.py:141-205 + :396-400. */
+typedef struct {
+  int width, heads, layers;
+  int init_from_avg;              /* model/model.py:156-161                               */
+  int residual_activation;        /* VTC_ACT_*                                            */
+  float squash_scale;             /* 1, 10, 1.2, 1.5, 1.8 for the squash* family          */
+  const void  *final_linear;      /* [D,D] compute dtype (used when !init_from_avg)       */
+  const float *mask_embedding;    /* [D]                                                  */
+  const vtc_block_w *blocks;      /* HOST array                                           */
+} vtc_cam_w;
+
+const char *vtc_last_error(void);          /* thread-local message of the last failure   */
+int vtc_abi_version(void);
+
+/* ---- towers ------------------------------------------------------------------------ */
+
+/* Replaces clip_model.encode_image (model/model.py:332,464) when w->nframes == 0 and
+ * VisualTransformer.forward (model/timesformer_clip_alt.py:252-286, called at
+ * model/model.py:497,613) when w->nframes > 0.
+ * pixels: [n_items, F, 3, H, W] (F = 1 for images), fp32 (pixel_dtype VTC_F32) or bf16.
+ * out:    [n_items, embed_dim] fp32 (not normalised). */
+size_t vtc_vision_workspace_bytes(const vtc_vision_w *w, int n_items, int frames, int dtype);
+int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int pixel_dtype, int n_items, int frames,
+                       float *out, void *ws, size_t ws_bytes, int dtype, void *stream);
+
+/* Replaces clip_model.encode_text (model/model.py:210,340,351,472,499,615).
+ * ids: [n_seq, ctx] int64.  out: [n_seq, embed_dim] fp32. */
+size_t vtc_text_workspace_bytes(const vtc_text_w *w, int n_seq, int dtype);
+int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_seq, float *out, void *ws, size_t ws_bytes,
+                     int dtype, void *stream);
+
+/* Replaces PretrainedCLIPBase._load_comment_features' masking + _adapt_feature
+ * (model/model.py:207-214, 141-205), eval semantics.
+ * main: [B,D] fp32; comm_feats: [B*nc, D] fp32 = encode_text(comments.reshape(B*nc, ctx));
+ * comments: [B,nc,ctx] int64 (only token 1 is read: the empty-string test :208).
+ * adapted: [B,D] fp32 = normalize(normalize(main) + r). */
+size_t vtc_cam_workspace_bytes(const vtc_cam_w *w, int B, int nc, int dtype);
+int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, const float *comm_feats, const int64_t *comments,
+                    int ctx, int B, int nc, float *adapted, void *ws, size_t ws_bytes, int dtype, void *stream);
+
+/* ---- small fp32 ops of the wrappers (model/model.py:26-27, 338, 357-362, 369) -------- */
+int vtc_normalize_rows(const float *x, float *out, int n, int d, void *stream);
+/* out[g] = mean over `group` consecutive rows (frames -> video, title+comments -> text) */
+int vtc_mean_groups(const float *x, float *out, int n_groups, int group, int d, void *stream);
+/* sim[nv,nt] = exp(*logit_scale) * v @ t^T, fp32 exact */
+int vtc_similarity(const float *v, const float *t, int nv, int nt, int d, const float *logit_scale, float *sim,
+                   void *stream);
+
+/* Replaces model/loss.py:18-22 clip_loss.  sim: [n,n] fp32; loss: 1 float (device). */
+size_t vtc_clip_loss_workspace_bytes(int n);
+int vtc_clip_loss(const float *sim, int n, float *loss, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- N x N sweep: replaces faiss.GpuIndexFlatL2.add/search in RecallAtK.compute
+ * (model/metric.py:137-146) and the hit counting (:148-160) --------------------------- */
+
+/* ids[nq,depth] (int64) / dists[nq,depth] (fp32, may be NULL) = the `depth` rows of `gallery`
+ * nearest to each row of `queries` by squared L2 = |q|^2 + |g|^2 - 2 q.g (fp32), ascending,
+ * ties by lowest gallery index.  The fp32 distance matrix is materialised in `ws` in
+ * row blocks of `rows_per_block` queries (0 = as many as fit). */
+size_t vtc_l2_topk_workspace_bytes(int n_gallery, int n_queries, int d, int precision, int rows_per_block);
+int vtc_l2_topk(const float *gallery, const float *queries, int n_gallery, int n_queries, int d, int depth,
+                int precision, int rows_per_block, int64_t *ids, float *dists, void *ws, size_t ws_bytes,
+                void *stream);
+/* hits[j] += #{ i : (target_offset + i) in ids[i, :k_vals[j]] }   (hits: int64 device) */
+int vtc_recall_hits(const int64_t *ids, int n_queries, int depth, int64_t target_offset, const int *k_vals_host,
+                    int nk, long long *hits, void *stream);
+
+/* ---- primitives (exported for parity tests and reuse) -------------------------------- */
+enum { VTC_EPI_STORE = 0,   /* out = acc + bias                      (out dtype = out_dtype) */
+       VTC_EPI_GELU = 1,    /* out = QuickGELU(acc + bias)                                     */
+       VTC_EPI_RESID = 2 }; /* out(fp32) += acc + bias; rows with m % skip_mod == 0 untouched  */
+/* out[M,N] = epi(A[M,K] @ W[N,K]^T + bias).  A, W in `dtype`; K % 64 == 0 (bf16) / % 32 (fp32). */
+int vtc_gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype,
+             int epilogue, int out_dtype, int skip_mod, void *stream);
+/* y[r,:] = LN(x[row(r),:]) * g + b, row(r) = row_index ? row_index[r] : r * row_mul; out dtype selectable */
+int vtc_layernorm(const float *x, const float *g, const float *b, void *y, int rows, int width, int out_dtype,
+                  const int *row_index, int row_mul, void *stream);
+/* softmax(q k^T / sqrt(64) [+causal]) v per (sequence, head) on a packed qkv buffer [rows, 3W];
+ * token p of sequence s lives at row  (s / s2) * a1 + (s % s2) * a2 + a0 + (p ? 1 + (s % s2) * a3 + (p - 1) * pstride : 0).
+ * out: [rows, W] (same row map).  If cls_out != NULL the p == 0 output goes to cls_out[s, W] (fp32) instead. */
+int vtc_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2, int a0,
+                  int a1, int a2, int a3, int pstride, int dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTC_HIP_H */

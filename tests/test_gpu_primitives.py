@@ -1,0 +1,136 @@
+"""GPU parity of the exported primitives (through the C ABI) against plain PyTorch fp32."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _ops():
+    from vtc_amd import _lib as L
+    from vtc_amd import ops
+    return L, ops
+
+
+def quick_gelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 384, 192), (77, 512, 3072), (1000, 2304, 768), (5, 50, 64)])
+def test_gemm_store_bias(dtype, M, N, K):
+    L, ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    # integer-valued data first: exact in both dtypes, catches any fragment/lane-map mistake (asymmetric W)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float() + torch.arange(N).float()[:, None] % 3
+    bias = torch.randint(-5, 6, (N,), generator=g).float()
+    ref = a.double() @ w.double().t() + bias.double()
+    out = ops.gemm(a.cuda().to(dtype), w.cuda().to(dtype), bias.cuda(), out_dtype=torch.float32)
+    assert torch.equal(out.cpu().double(), ref), (out.cpu().double() - ref).abs().max()
+    # random data
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    ad, wd = a.cuda().to(dtype), w.cuda().to(dtype)
+    ref = ad.float().cpu().double() @ wd.float().cpu().double().t() + bias.double()
+    out = ops.gemm(ad, wd, bias.cuda(), out_dtype=torch.float32).cpu().double()
+    tol = 2e-5 if dtype == torch.float32 else 1e-4   # operands already rounded; fp32 accumulate
+    assert (out - ref).abs().max() < tol * max(1.0, ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(dtype):
+    L, ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 393 * 2, 256, 128
+    a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
+    ad, wd = a.cuda().to(dtype), w.cuda().to(dtype)
+    lin = ad.float().cpu().double() @ wd.float().cpu().double().t() + b.double()
+    # QuickGELU, output in compute dtype
+    out = ops.gemm(ad, wd, b.cuda(), epilogue=L.EPI_GELU).float().cpu().double()
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert (out - quick_gelu(lin)).abs().max() < tol
+    # residual with cls-row skip (timesformer_clip_alt.py:149: temporal residual on patch tokens only)
+    x0 = torch.randn(M, N, generator=g)
+    x = x0.clone().cuda()
+    ops.gemm(ad, wd, b.cuda(), epilogue=L.EPI_RESID, out=x, skip_mod=393)
+    ref = x0.double() + lin
+    ref[0::393] = x0[0::393].double()
+    assert (x.cpu().double() - ref).abs().max() < 1e-4
+    assert torch.equal(x.cpu()[0::393], x0[0::393])
+
+
+@pytest.mark.parametrize("width", [128, 512, 768])
+def test_layernorm(width):
+    L, ops = _ops()
+    g = torch.Generator().manual_seed(width)
+    x = torch.randn(37, width, generator=g) * 3 + 1
+    gm, bt = torch.randn(width, generator=g), torch.randn(width, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (width,), gm, bt, 1e-5)
+    out = ops.layernorm(x.cuda(), gm.cuda(), bt.cuda())
+    assert (out.cpu() - ref).abs().max() < 5e-6
+    outb = ops.layernorm(x.cuda(), gm.cuda(), bt.cuda(), out_dtype=torch.bfloat16)
+    assert (outb.float().cpu() - ref).abs().max() < 3e-2
+    # row gather (EOT pooling / ln_post on cls rows)
+    idx = torch.tensor([5, 0, 36, 5], dtype=torch.int32)
+    outg = ops.layernorm(x.cuda(), gm.cuda(), bt.cuda(), row_index=idx.cuda())
+    assert (outg.cpu() - ref[idx.long()]).abs().max() < 5e-6
+    outm = ops.layernorm(x.cuda(), gm.cuda(), bt.cuda(), rows=4, row_mul=9)
+    assert (outm.cpu() - ref[[0, 9, 18, 27]]).abs().max() < 5e-6
+
+
+def ref_attention(q, k, v, causal):
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if causal:
+        Lq = q.shape[-2]
+        s = s + torch.full((Lq, Lq), float("-inf")).triu_(1)
+    return s.softmax(-1) @ v
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("L_,causal", [(6, False), (8, False), (16, False), (24, True), (50, False), (77, True)])
+def test_attention_contiguous(dtype, L_, causal):
+    L, ops = _ops()
+    heads, n_seq = 3, 5
+    W = heads * 64
+    g = torch.Generator().manual_seed(L_)
+    qkv = torch.randn(n_seq * L_, 3 * W, generator=g)
+    qd = qkv.cuda().to(dtype)
+    q, k, v = qd.float().cpu().reshape(n_seq, L_, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = ref_attention(q, k, v, causal).permute(0, 2, 1, 3).reshape(n_seq * L_, W)
+    out = ops.attention(qd, n_seq, L_, heads, causal=causal).float().cpu()
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert (out - ref).abs().max() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("F", [1, 2, 8, 16])
+def test_attention_time_and_space_row_maps(dtype, F):
+    """Token order of model/timesformer_clip_alt.py:271-275: row b*T = cls, row b*T + 1 + n*F + t."""
+    L, ops = _ops()
+    heads, B, P = 2, 3, 4
+    W, T = heads * 64, 1 + P * F
+    g = torch.Generator().manual_seed(F)
+    qkv = torch.randn(B * T, 3 * W, generator=g)
+    qd = qkv.cuda().to(dtype)
+    x = qd.float().cpu().reshape(B, T, 3, heads, 64)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    # time: sequences (b, n), tokens t
+    pt = x[:, 1:].reshape(B, P, F, 3, heads, 64)
+    q, k, v = pt.permute(3, 0, 1, 4, 2, 5)                       # [3, B, P, heads, F, 64]
+    ref_t = ref_attention(q, k, v, False).permute(0, 1, 3, 2, 4).reshape(B, P * F, W)
+    out = ops.attention(qd, B * P, F, heads, s2=P, a0=1, a1=T, a2=F, a3=0, pstride=1).float().cpu().reshape(B, T, W)
+    assert (out[:, 1:] - ref_t).abs().max() < tol
+    assert out[:, 0].abs().max() == 0                            # cls rows untouched by the temporal branch
+    # space: sequences (b, t): [cls, patches of frame t]; cls outputs go to cls_out[(b t)]
+    ps = pt.permute(0, 2, 1, 3, 4, 5)                            # [B, F, P, 3, heads, 64]
+    cls = x[:, 0:1].unsqueeze(1).expand(B, F, 1, 3, heads, 64)
+    seq = torch.cat([cls, ps], dim=2)                            # [B, F, 1+P, 3, heads, 64]
+    q, k, v = seq.permute(3, 0, 1, 4, 2, 5)
+    ref_s = ref_attention(q, k, v, False).permute(0, 1, 3, 2, 4).reshape(B, F, 1 + P, W)
+    cls_out = torch.zeros(B * F, W, device="cuda")
+    out = ops.attention(qd, B * F, 1 + P, heads, s2=F, a0=0, a1=T, a2=0, a3=1, pstride=F, cls_out=cls_out)
+    out = out.float().cpu().reshape(B, T, W)
+    got = out[:, 1:].reshape(B, P, F, W).permute(0, 2, 1, 3)
+    assert (got - ref_s[:, :, 1:]).abs().max() < tol
+    assert (cls_out.cpu().reshape(B, F, W) - ref_s[:, :, 0]).abs().max() < tol

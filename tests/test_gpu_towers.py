@@ -1,0 +1,177 @@
+"""GPU parity of the towers, the CAM and the four drop-in wrappers.
+
+Every case runs the HIP path through the C ABI and compares with (a) the committed golden
+vectors produced by the reference's own Python and (b) the oracle run live on the CPU.
+Tolerances are BASELINE.json's: 1e-5 (fp32) / 1e-3 (bf16) on unit-norm embeddings and on the
+cosine similarity (sim / exp(logit_scale))."""
+from dataclasses import asdict
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, load_golden
+from oracle import arch as A
+from oracle import clip_ref as CR
+from oracle import model_ref as M
+from oracle import timesformer_ref as T
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+ARCH = {"TINY": A.TINY, "VIT_B32": A.VIT_B32}
+TOL = {torch.float32: 1e-5, torch.bfloat16: 1e-3}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def cuda_sd(sd):
+    return {k: v.cuda() for k, v in sd.items()}
+
+
+def unit(x):
+    return x / np.linalg.norm(x, axis=-1, keepdims=True)
+
+
+def report(name, err, tol):
+    print(f"[parity] {name}: max abs err {err:.3e} (tol {tol:.0e})")
+    assert err < tol, f"{name}: {err} >= {tol}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("fname", golden_files("tower_alt_"))
+def test_timesformer_tower_vs_golden(fname, dtype):
+    from vtc_amd import towers
+    case, g = load_golden(fname)
+    a = ARCH[case["arch"]]
+    sd = A.synth_visual(a, case["wseed"], nframes=case["nframes"], prefix="v.")
+    x = A.synth_pixels((case["B"], case["nframes"], 3, a.image_resolution, a.image_resolution), case["xseed"])
+    for fuse in (False, True):
+        pv = towers.PackedVision(cuda_sd(sd), "v.", dtype, fuse_temporal=fuse)
+        out = pv.forward(x.cuda()).cpu().numpy()
+        # compare as the wrappers consume it: L2-normalised embedding (model.py:501)
+        report(f"{fname} {dtype} fuse={fuse}", np.abs(unit(out) - unit(g["out"])).max(), TOL[dtype] * (3 if fuse and dtype == torch.float32 else 1))
+        if dtype == torch.float32 and not fuse:
+            assert np.abs(out - g["out"]).max() < 2e-5 * max(1.0, np.abs(g["out"]).max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vit_and_text_towers_vs_oracle(dtype):
+    from vtc_amd import towers
+    for a, B, S in ((A.TINY, 5, 9), (A.VIT_B32, 3, 7)):
+        sd = {}
+        sd.update(A.synth_visual(a, 51, prefix="model.visual."))
+        sd.update(A.synth_text(a, 52, prefix="model."))
+        img = A.synth_pixels((B, 3, a.image_resolution, a.image_resolution), 53)
+        txt = A.synth_tokens(S, a, 54, empty_frac=0.25)
+        ref_v = CR.encode_image(img, sd, a, "model.visual.").numpy()
+        ref_t = CR.encode_text(txt, sd, a, "model.").numpy()
+        pv = towers.PackedVision(cuda_sd(sd), "model.visual.", dtype)
+        pt = towers.PackedText(cuda_sd(sd), "model.", dtype, heads=a.transformer_heads)
+        out_v = pv.forward(img.cuda()).cpu().numpy()
+        out_t = pt.forward(txt.cuda()).cpu().numpy()
+        report(f"ViT {a.vision_width} {dtype}", np.abs(unit(out_v) - unit(ref_v)).max(), TOL[dtype])
+        report(f"text {a.transformer_width} {dtype}", np.abs(unit(out_t) - unit(ref_t)).max(), TOL[dtype])
+        if dtype == torch.bfloat16:  # bf16 pixel input (BASELINE: pixels cast to bf16 for bf16 runs)
+            out_vb = pv.forward(img.cuda().bfloat16()).cpu().numpy()
+            report(f"ViT bf16-pixels {a.vision_width}", np.abs(unit(out_vb) - unit(ref_v)).max(), 2e-3)
+
+
+def test_identity_at_init_timesformer_equals_vit_gpu():
+    """SURVEY 4 known answer: temporal_fc = 0, temporal_embed = 0, identical frames => TimeSformer == ViT."""
+    from vtc_amd import towers
+    a = A.TINY
+    sd = A.synth_visual(a, 5, nframes=4)
+    for k in list(sd):
+        if "temporal_fc" in k or k == "temporal_embed":
+            sd[k] = torch.zeros_like(sd[k])
+    img = A.synth_pixels((2, 1, 3, a.image_resolution, a.image_resolution), 6)
+    vid = img.expand(2, 4, 3, a.image_resolution, a.image_resolution).contiguous()
+    sd_vit = {k: v for k, v in sd.items() if "time" not in k and "temporal" not in k}
+    tf = towers.PackedVision(cuda_sd({"v." + k: v for k, v in sd.items()}), "v.", torch.float32).forward(vid.cuda()).cpu()
+    vit = towers.PackedVision(cuda_sd({"v." + k: v for k, v in sd_vit.items()}), "v.", torch.float32).forward(img[:, 0].cuda()).cpu()
+    assert (tf - vit).abs().max() < 1e-5
+
+
+def build_wrapper(case, dtype):
+    from vtc_amd.host import model as HM
+    from vtc_amd.host.clip_arch import ClipConfig
+    a = ARCH[case["arch"]]
+    cls = {"clip": HM.PretrainedCLIP, "clip_finaltf": HM.PretrainedCLIP_finaltf,
+           "timesformer": HM.PretrainedCLIP_TimeSformer, "timesformer_finaltf": HM.PretrainedCLIP_TimeSformer_finaltf}[case["model"]]
+    m = cls(model_type=ClipConfig(**asdict(a)), **case["ctor"])
+    m.load_state_dict(A.synth_model(a, case["wseed"], case["model"], nframes=8), strict=True)   # eval.py:90-91
+    m = m.eval().cuda()
+    m.compute_dtype = dtype
+    return m, a
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("fname", golden_files("wrap_"))
+def test_wrappers_vs_golden(fname, dtype):
+    case, g = load_golden(fname)
+    m, a = build_wrapper(case, dtype)
+    B = case["B"]
+    vis = A.synth_pixels(case["vis_shape"], case["xseed"]).cuda()
+    title = A.synth_tokens(B, a, case["tseed"]).cuda()
+    comments = A.synth_tokens(B * 5, a, case["cseed"], empty_frac=case["empty_frac"]).reshape(B, 5, -1).cuda()
+    out = m(vis, title, comments) if case["comments"] else m(vis, title)
+    fv, ft, sim = (o.cpu().numpy() for o in out)
+    tol = TOL[dtype] * (3 if (dtype == torch.float32 and "timesformer" in case["model"]) else 1)  # fused temporal map
+    report(f"{fname} feats_vis {dtype}", np.abs(fv - g["feats_vis"]).max(), tol)
+    report(f"{fname} feats_text {dtype}", np.abs(ft - g["feats_text"]).max(), tol)
+    scale = float(np.exp(np.log(1 / 0.07)))
+    report(f"{fname} cos-sim {dtype}", np.abs(sim - g["sim"]).max() / scale, tol)
+    np.testing.assert_allclose(np.linalg.norm(fv, axis=-1), 1.0, atol=1e-5)
+    # R@1 ranks of the batch similarity identical to the reference's
+    if np.sort(g["sim"], axis=1)[:, -1].min() - np.sort(g["sim"], axis=1)[:, -2].max() > 0.1:
+        assert np.array_equal(sim.argmax(1), g["sim"].argmax(1))
+
+
+def test_cam_at_init_and_branch_isolation():
+    """tests/test_pretrained_clip.py:36-42,74-85 of the reference, on the HIP path:
+    skip == plain CLIP; only the adapted modality changes; image feature independent of the title."""
+    from vtc_amd.host import model as HM
+    from vtc_amd.host.clip_arch import ClipConfig
+    case, g = load_golden("cam_at_init_tiny.npz")
+    a = A.TINY
+    cfg = ClipConfig(**asdict(a))
+    sd = A.synth_model(a, case["wseed"], "clip_finaltf", cam_at_init=True)
+    B = case["B"]
+    vis = A.synth_pixels((B, 3, a.image_resolution, a.image_resolution), case["xseed"]).cuda()
+    title = A.synth_tokens(B, a, case["tseed"]).cuda()
+    title2 = A.synth_tokens(B, a, case["tseed"] + 100).cuda()
+    comments = A.synth_tokens(B * 5, a, case["cseed"], empty_frac=case["empty_frac"]).reshape(B, 5, -1).cuda()
+    outs = {}
+    for br in ("skip", "image", "text"):
+        m = HM.PretrainedCLIP_finaltf(model_type=cfg, branch_to_adapt_val=br)
+        m.load_state_dict(sd, strict=True)
+        m = m.eval().cuda()
+        m.compute_dtype = torch.float32
+        outs[br] = tuple(o.cpu() for o in m(vis, title, comments))
+        if br == "image":
+            imv2, titlev2, _ = (o.cpu() for o in m(vis, title2, comments))
+    plain = HM.PretrainedCLIP(model_type=cfg)
+    plain.load_state_dict({k: v for k, v in sd.items() if k.startswith("model.")}, strict=True)
+    plain = plain.eval().cuda()
+    plain.compute_dtype = torch.float32
+    pim, ptx, _ = (o.cpu() for o in plain(vis, title))
+    assert torch.allclose(outs["skip"][0], pim, atol=1e-6) and torch.allclose(outs["skip"][1], ptx, atol=1e-6)
+    assert torch.allclose(outs["skip"][0], outs["text"][0], atol=1e-6)       # image unchanged when adapting text
+    assert torch.allclose(outs["skip"][1], outs["image"][1], atol=1e-6)
+    assert not torch.allclose(outs["image"][0], outs["skip"][0], atol=1e-4)
+    assert not torch.allclose(outs["text"][1], outs["skip"][1], atol=1e-4)
+    assert torch.allclose(imv2, outs["image"][0], atol=1e-6) and not torch.allclose(titlev2, outs["image"][1], atol=1e-4)
+    assert np.abs(outs["text"][1].numpy() - g["feats_text"]).max() < 1e-5
+
+
+def test_product_fails_loudly_off_gpu_and_in_train_mode():
+    from vtc_amd.host import model as HM
+    from vtc_amd.host.clip_arch import ClipConfig
+    a = A.TINY
+    m = HM.PretrainedCLIP(model_type=ClipConfig(**asdict(a))).eval()
+    img = A.synth_pixels((1, 3, a.image_resolution, a.image_resolution), 1)
+    txt = A.synth_tokens(1, a, 2)
+    with pytest.raises(RuntimeError):
+        m(img, txt)                       # CPU tensors: no fallback
+    m = m.cuda().train()
+    with pytest.raises(RuntimeError):
+        m(img.cuda(), txt.cuda())

@@ -1,0 +1,256 @@
+// attention.hip -- softmax(q k^T / sqrt(64) [+ causal]) v for the short sequences of this path:
+//   time attention   L = F (8/16)     model/timesformer_clip_alt.py:142-147
+//   space attention  L = 1 + 49       model/timesformer_clip_alt.py:152-158 (cls replicated per frame)
+//   ViT              L = 50           upstream VisionTransformer
+//   text             L = 77 causal    upstream CLIP.encode_text (mask = full(-inf).triu_(1))
+//   CAM              L = 1 + ncomms   model/model.py:155
+// Replaces `attn` / `multi_head_attention` (model/timesformer_clip_alt.py:36-67) minus the two
+// projections, which are GEMMs.
+//
+// gfx950 design: ONE WAVE per (sequence, head); the whole sequence lives in that wave.
+//   * the einops rearranges of the reference ("(b h w) t", "(b t) (h w)", cls replicate) are pure
+//     index arithmetic here: token p of sequence s is fetched from its row of the [rows, 3W]
+//     qkv buffer through an affine row map, and written back through the same map;
+//   * S^T = K Q^T on the matrix cores (keys on the accumulator rows, queries on the lanes), so
+//     the softmax over keys is lane-local + two xor-shuffles, and the probability accumulators
+//     ARE the B operand of the P.V product -- no LDS round trip, no transposition of P;
+//   * K fragments are loaded once from global into registers and reused for every query tile;
+//     V is staged once per (sequence, head) into LDS transposed ([d][key]) so the P.V "A" operand
+//     is a contiguous 8/16-byte LDS read;
+//   * bf16: v_mfma_f32_16x16x32_bf16 (P rounded to bf16 for P.V); fp32: v_mfma_f32_16x16x4_f32.
+// head_dim is fixed at 64 (upstream: heads = width / 64).
+#include "common.h"
+
+namespace {
+
+struct AttnParams {
+  const char *qkv;
+  char *out;
+  float *cls_out;
+  int n_seq, L, heads, causal;
+  int s2, a0, a1, a2, a3, pstride;
+  int W;  // model width = heads * 64
+};
+
+template <typename T> struct AT;
+template <> struct AT<bf16_t> {
+  static constexpr int NCH = 8;   // 16-byte chunks per 64-element head row
+  static constexpr int KS = 2;    // QK k-steps (4 chunks each)
+  static constexpr int EPC = 8;   // elements per chunk
+};
+template <> struct AT<float> {
+  static constexpr int NCH = 16;
+  static constexpr int KS = 4;
+  static constexpr int EPC = 4;
+};
+
+__device__ __forceinline__ void mma_qk(bf16_t, const uint4 &k, const uint4 &q, f32x4 &acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k), __builtin_bit_cast(bf16x8, q), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_qk(float, const uint4 &k, const uint4 &q, f32x4 &acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, k.x), __builtin_bit_cast(float, q.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, k.y), __builtin_bit_cast(float, q.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, k.z), __builtin_bit_cast(float, q.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, k.w), __builtin_bit_cast(float, q.w), acc, 0, 0, 0);
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  constexpr int SZ = sizeof(T);
+  constexpr int VS = 16 * NT + 4;           // Vt row stride in elements (keys), keeps 8/16-byte alignment
+  constexpr int NCH = AT<T>::NCH, KS = AT<T>::KS, EPC = AT<T>::EPC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  T *vt = reinterpret_cast<T *>(lds_raw) + (size_t)wave * 64 * VS;
+
+  int gw = blockIdx.x * 4 + wave;
+  const int total = p.n_seq * p.heads;
+  const bool active = gw < total;
+  if (!active) gw = total - 1;              // keep every wave alive for the barrier; stores are predicated
+  const int s = gw / p.heads, h = gw - s * p.heads;
+  const int s_hi = s / p.s2, s_lo = s - s_hi * p.s2;
+  const long base = (long)s_hi * p.a1 + (long)s_lo * p.a2 + p.a0;
+  const int first = 1 + s_lo * p.a3;
+  const int L = p.L;
+  const size_t ld = (size_t)3 * p.W * SZ;   // qkv row bytes
+  auto row_of = [&](int tok) -> long { return tok == 0 ? base : base + first + (long)(tok - 1) * p.pstride; };
+
+  // ---- V -> LDS, transposed ------------------------------------------------------------
+  {
+    const char *vbase = p.qkv + (size_t)(2 * p.W + h * 64) * SZ;
+#pragma unroll
+    for (int it = 0; it < (16 * NT * NCH) / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int tok = idx / NCH, ch = idx - tok * NCH;
+      uint4 raw = make_uint4(0, 0, 0, 0);
+      if (tok < L) raw = *reinterpret_cast<const uint4 *>(vbase + (size_t)row_of(tok) * ld + ch * 16);
+      const T *e = reinterpret_cast<const T *>(&raw);
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) vt[(ch * EPC + j) * VS + tok] = e[j];
+    }
+  }
+
+  // ---- K fragments -> registers ----------------------------------------------------------
+  uint4 kf[NT][KS];
+  {
+    const char *kbase = p.qkv + (size_t)(p.W + h * 64) * SZ;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const int tok = min(kt * 16 + c16, L - 1);
+      const char *r = kbase + (size_t)row_of(tok) * ld;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[kt][ks] = *reinterpret_cast<const uint4 *>(r + (4 * ks + g) * 16);
+    }
+  }
+  __syncthreads();  // Vt visible to every lane of the wave (waves do not share LDS regions)
+
+  const char *qbase = p.qkv + (size_t)(h * 64) * SZ;
+  for (int qt = 0; qt < NT; ++qt) {
+    if (qt * 16 >= L) break;
+    const int qtok = qt * 16 + c16;
+    uint4 qf[KS];
+    {
+      const char *r = qbase + (size_t)row_of(min(qtok, L - 1)) * ld;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4 *>(r + (4 * ks + g) * 16);
+    }
+    f32x4 sc[NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.causal && kt > qt) {            // every key of this tile is in the future of every query
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[kt][r] = -INFINITY;
+        continue;
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) mma_qk(T(), kf[kt][ks], qf[ks], sc[kt]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + g * 4 + r;
+        float v = sc[kt][r] * 0.125f;       // q * head_dim^-0.5 (timesformer_clip_alt.py:48,52); exact power of two
+        if (key >= L || (p.causal && key > qtok)) v = -INFINITY;
+        sc[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = sizeof(T) == 4 ? expf(sc[kt][r] - mx) : __expf(sc[kt][r] - mx);
+        sc[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    // ---- O^T[d][query] = sum_key Vt[d][key] * P[query][key] ---------------------------------
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int kk = 0; kk < (NT + 1) / 2; ++kk) {
+        const int k0 = 2 * kk, k1 = 2 * kk + 1;
+        bf16x8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[r] = (short)f2bf(sc[k0][r]);
+          pf[4 + r] = k1 < NT ? (short)f2bf(sc[k1 < NT ? k1 : k0][r]) : (short)0;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16_t *vr = reinterpret_cast<const bf16_t *>(vt) + (dt * 16 + c16) * VS + g * 4;
+          const uint2 lo = *reinterpret_cast<const uint2 *>(vr + k0 * 16);
+          uint2 hi = make_uint2(0, 0);
+          if (k1 < NT) hi = *reinterpret_cast<const uint2 *>(vr + k1 * 16);
+          const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const float4 vf = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(vt) + (dt * 16 + c16) * VS + kt * 16 + g * 4);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, sc[kt][0], o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, sc[kt][1], o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, sc[kt][2], o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, sc[kt][3], o[dt], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- store: lane holds O[query = qtok][d = 16 dt + 4 g .. +3] ---------------------------
+    if (active && qtok < L) {
+      if (p.cls_out && qtok == 0) {
+        float *dst = p.cls_out + (size_t)s * p.W + h * 64 + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          *reinterpret_cast<float4 *>(dst + dt * 16) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+      } else {
+        T *dst = reinterpret_cast<T *>(p.out) + (size_t)row_of(qtok) * p.W + h * 64 + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          ElemOps<T>::store4(dst + dt * 16, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+      }
+    }
+  }
+}
+
+template <typename T, int NT>
+int run(const AttnParams &p, hipStream_t stream) {
+  constexpr int VS = 16 * NT + 4;
+  const size_t shmem = (size_t)4 * 64 * VS * sizeof(T);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_kernel<T, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)shmem);
+    attr_done = true;
+  }
+  const int total = p.n_seq * p.heads;
+  hipLaunchKernelGGL((attn_kernel<T, NT>), dim3(cdiv(total, 4)), dim3(256), shmem, stream, p);
+  VTC_LAUNCH_CHECK("attention");
+  return 0;
+}
+
+template <typename T>
+int dispatch(const AttnParams &p, hipStream_t stream) {
+  switch (cdiv(p.L, 16)) {
+    case 1: return run<T, 1>(p, stream);
+    case 2: return run<T, 2>(p, stream);
+    case 3: return run<T, 3>(p, stream);
+    case 4: return run<T, 4>(p, stream);
+    case 5: return run<T, 5>(p, stream);
+  }
+  vtc_set_error("attention: sequence length %d > 80 unsupported", p.L);
+  return 1;
+}
+
+}  // namespace
+
+int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2,
+                     int a0, int a1, int a2, int a3, int pstride, int dtype, hipStream_t stream) {
+  VTC_CHECK(n_seq > 0 && L > 0 && heads > 0 && s2 > 0, "attention: bad sizes n_seq=%d L=%d heads=%d s2=%d", n_seq, L, heads, s2);
+  AttnParams p;
+  p.qkv = (const char *)qkv; p.out = (char *)out; p.cls_out = cls_out;
+  p.n_seq = n_seq; p.L = L; p.heads = heads; p.causal = causal;
+  p.s2 = s2; p.a0 = a0; p.a1 = a1; p.a2 = a2; p.a3 = a3; p.pstride = pstride;
+  p.W = heads * 64;
+  return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
+}
+
+extern "C" int vtc_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2,
+                             int a0, int a1, int a2, int a3, int pstride, int dtype, void *stream) {
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "attention: bad dtype %d", dtype);
+  return launch_attention(qkv, out, cls_out, n_seq, L, heads, causal, s2, a0, a1, a2, a3, pstride, dtype,
+                          (hipStream_t)stream);
+}

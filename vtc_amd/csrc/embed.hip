@@ -1,0 +1,245 @@
+// embed.hip -- data-movement kernels around the towers (all HBM-bound, 16-byte accesses):
+//   im2row          pixels [N,3,H,W] -> patch rows [N*P, 3*p*p]   (conv1 as a GEMM,
+//                   model/timesformer_clip_alt.py:255-260 / upstream VisionTransformer.conv1)
+//   cls_rows        x[item*T] = class_embedding + pos[0]           (:262-269)
+//   cls_mean        space-attention cls output = mean over frames  (:162-164)
+//   text_embed      token_embedding[ids] + positional_embedding, and the EOT row index
+//                   ids.argmax(-1)                                  (upstream CLIP.encode_text)
+//   cam_tokens / cam_finalize   Context Adapter Module glue         (model/model.py:150-151,157-159,203,208-212)
+#include "common.h"
+
+namespace {
+
+template <typename PixT, typename T>
+__global__ __launch_bounds__(256) void im2row_kernel(const PixT *__restrict__ px, T *__restrict__ out, int n_frames, int grid,
+                                                     int patch, int res) {
+  // one thread = 4 consecutive k (same image row segment); k = c*p*p + i*p + j
+  const int K = 3 * patch * patch;
+  const size_t total = (size_t)n_frames * grid * grid * (K / 4);
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int kq = (int)(idx % (K / 4));
+  const size_t m = idx / (K / 4);
+  const int k = kq * 4;
+  const int c = k / (patch * patch), rem = k - c * patch * patch;
+  const int i = rem / patch, j = rem - i * patch;
+  const int P = grid * grid;
+  const int f = (int)(m / P), pp = (int)(m - (size_t)f * P);
+  const int py = pp / grid, pxx = pp - py * grid;
+  const PixT *src = px + (((size_t)f * 3 + c) * res + (size_t)py * patch + i) * res + (size_t)pxx * patch + j;
+  const float4 v = ElemOps<PixT>::load4(src);
+  ElemOps<T>::store4(out + m * K + k, v.x, v.y, v.z, v.w);
+}
+
+__global__ __launch_bounds__(256) void cls_rows_kernel(float *x, const float *__restrict__ cls, const float *__restrict__ pos0,
+                                                       int n_items, int T, int W) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_items * W) return;
+  const int item = i / W, c = i - item * W;
+  x[(size_t)item * T * W + c] = cls[c] + pos0[c];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cls_mean_kernel(const float *__restrict__ cls_tmp, T *__restrict__ out, int n_items,
+                                                       int F, int Ttok, int W) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_items * W) return;
+  const int item = i / W, c = i - item * W;
+  float s = 0.f;
+  for (int t = 0; t < F; ++t) s += cls_tmp[((size_t)item * F + t) * W + c];
+  ElemOps<T>::store(out + (size_t)item * Ttok * W + c, s / F);
+}
+
+__global__ __launch_bounds__(256) void text_embed_kernel(const int64_t *__restrict__ ids, const float *__restrict__ tok,
+                                                         const float *__restrict__ pos, float *__restrict__ x, int n_rows,
+                                                         int ctx, int W, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  long id = ids[r];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // never fault on a bad id
+  const int p = r % ctx;
+  const float *tr = tok + (size_t)id * W, *pr = pos + (size_t)p * W;
+  float *xr = x + (size_t)r * W;
+  for (int c = lane * 4; c < W; c += 256) {
+    const float4 a = *reinterpret_cast<const float4 *>(tr + c), b = *reinterpret_cast<const float4 *>(pr + c);
+    *reinterpret_cast<float4 *>(xr + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+// eot_row[s] = s*ctx + argmax_p ids[s,p] (first maximum, as torch.argmax)
+__global__ __launch_bounds__(256) void eot_index_kernel(const int64_t *__restrict__ ids, int *__restrict__ eot_row, int n_seq, int ctx) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= n_seq) return;
+  const int64_t *r = ids + (size_t)s * ctx;
+  int64_t best = r[0];
+  int bi = 0;
+  for (int p = 1; p < ctx; ++p)
+    if (r[p] > best) { best = r[p]; bi = p; }
+  eot_row[s] = s * ctx + bi;
+}
+
+// X[b*Lc + 0] = normalize(main[b]);  X[b*Lc + 1 + c] = normalize(empty(b,c) ? mask : comm[b*nc + c])
+__global__ __launch_bounds__(256) void cam_tokens_kernel(const float *__restrict__ main_f, const float *__restrict__ comm,
+                                                         const int64_t *__restrict__ comments, const float *__restrict__ mask_emb,
+                                                         float *__restrict__ X, int B, int nc, int ctx, int D) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int Lc = 1 + nc;
+  if (r >= B * Lc) return;
+  const int b = r / Lc, t = r - b * Lc;
+  const float *src;
+  if (t == 0) src = main_f + (size_t)b * D;
+  else {
+    const int ci = b * nc + (t - 1);
+    const bool empty = comments[(size_t)ci * ctx + 1] == 49407;   // model/model.py:208
+    src = empty ? mask_emb : comm + (size_t)ci * D;
+  }
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += src[c] * src[c];
+  const float nrm = sqrtf(wave_sum(s));
+  for (int c = lane; c < D; c += 64) X[(size_t)r * D + c] = src[c] / nrm;
+}
+
+__device__ __forceinline__ float act_apply(int act, float v, float msq, float scale) {
+  // model/model.py:34-39,65-77; msq = sum((s+1e-9)^2) for squash, sum((s+1e-9)^2) for normalize
+  if (act == VTC_ACT_NORMALIZE) return (v + 1e-9f) / sqrtf(msq);
+  if (act == VTC_ACT_SQUASH) {
+    const float mag = sqrtf(msq);
+    return scale * (msq / (1.0f + msq)) * ((v + 1e-9f) / mag);
+  }
+  if (act == VTC_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+// one wave per item: r = init_from_avg ? normalize(mean_i normalize(Y_i)) : lin[b];
+// r = act(r); adapted = normalize(normalize(main) + r)
+template <int MAXD64>
+__global__ __launch_bounds__(256) void cam_finalize_kernel(const float *__restrict__ Y, const float *__restrict__ lin,
+                                                           const float *__restrict__ main_f, float *__restrict__ out, int B, int Lc,
+                                                           int D, int init_from_avg, int act, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float r[MAXD64];
+#pragma unroll
+  for (int k = 0; k < MAXD64; ++k) r[k] = 0.f;
+  if (init_from_avg) {
+    for (int t = 0; t < Lc; ++t) {
+      const float *y = Y + ((size_t)b * Lc + t) * D;
+      float v[MAXD64], s = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXD64; ++k) {
+        const int c = lane + 64 * k;
+        v[k] = c < D ? y[c] : 0.f;
+        s += v[k] * v[k];
+      }
+      const float nrm = sqrtf(wave_sum(s));
+#pragma unroll
+      for (int k = 0; k < MAXD64; ++k) r[k] += v[k] / nrm;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXD64; ++k) { r[k] /= Lc; s += r[k] * r[k]; }
+    const float nrm = sqrtf(wave_sum(s));
+#pragma unroll
+    for (int k = 0; k < MAXD64; ++k) r[k] /= nrm;
+  } else {
+#pragma unroll
+    for (int k = 0; k < MAXD64; ++k) {
+      const int c = lane + 64 * k;
+      r[k] = c < D ? lin[(size_t)b * D + c] : 0.f;
+    }
+  }
+  if (act != VTC_ACT_NONE) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXD64; ++k) {
+      const int c = lane + 64 * k;
+      if (c < D) s += (r[k] + 1e-9f) * (r[k] + 1e-9f);
+    }
+    const float msq = wave_sum(s);
+#pragma unroll
+    for (int k = 0; k < MAXD64; ++k) r[k] = act_apply(act, r[k], msq, scale);
+  }
+  float m[MAXD64], s = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXD64; ++k) {
+    const int c = lane + 64 * k;
+    m[k] = c < D ? main_f[(size_t)b * D + c] : 0.f;
+    s += m[k] * m[k];
+  }
+  const float mn = sqrtf(wave_sum(s));
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXD64; ++k) {
+    const int c = lane + 64 * k;
+    m[k] = c < D ? m[k] / mn + r[k] : 0.f;
+    s2 += m[k] * m[k];
+  }
+  const float an = sqrtf(wave_sum(s2));
+#pragma unroll
+  for (int k = 0; k < MAXD64; ++k) {
+    const int c = lane + 64 * k;
+    if (c < D) out[(size_t)b * D + c] = m[k] / an;
+  }
+}
+
+}  // namespace
+
+int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res,
+                  hipStream_t stream) {
+  VTC_CHECK(patch % 4 == 0, "im2row: patch=%d must be a multiple of 4", patch);
+  const size_t total = (size_t)n_frames * grid * grid * (3 * patch * patch / 4);
+  const dim3 g((unsigned)((total + 255) / 256)), b(256);
+  if (pixel_dtype == VTC_F32 && dtype == VTC_BF16)
+    hipLaunchKernelGGL((im2row_kernel<float, bf16_t>), g, b, 0, stream, (const float *)px, (bf16_t *)out, n_frames, grid, patch, res);
+  else if (pixel_dtype == VTC_F32)
+    hipLaunchKernelGGL((im2row_kernel<float, float>), g, b, 0, stream, (const float *)px, (float *)out, n_frames, grid, patch, res);
+  else if (dtype == VTC_BF16)
+    hipLaunchKernelGGL((im2row_kernel<bf16_t, bf16_t>), g, b, 0, stream, (const bf16_t *)px, (bf16_t *)out, n_frames, grid, patch, res);
+  else
+    hipLaunchKernelGGL((im2row_kernel<bf16_t, float>), g, b, 0, stream, (const bf16_t *)px, (float *)out, n_frames, grid, patch, res);
+  VTC_LAUNCH_CHECK("im2row");
+  return 0;
+}
+
+int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, int T, int W, hipStream_t stream) {
+  hipLaunchKernelGGL(cls_rows_kernel, dim3(cdiv(n_items * W, 256)), dim3(256), 0, stream, x, cls, pos0, n_items, T, W);
+  VTC_LAUNCH_CHECK("cls_rows");
+  return 0;
+}
+
+int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int F, int T, int W, hipStream_t stream) {
+  const dim3 g(cdiv(n_items * W, 256)), b(256);
+  if (dtype == VTC_BF16) hipLaunchKernelGGL((cls_mean_kernel<bf16_t>), g, b, 0, stream, cls_tmp, (bf16_t *)out, n_items, F, T, W);
+  else hipLaunchKernelGGL((cls_mean_kernel<float>), g, b, 0, stream, cls_tmp, (float *)out, n_items, F, T, W);
+  VTC_LAUNCH_CHECK("cls_mean");
+  return 0;
+}
+
+int launch_text_embed(const int64_t *ids, const float *tok, const float *pos, float *x, int *eot_row, int n_seq, int ctx,
+                      int W, int vocab, hipStream_t stream) {
+  VTC_CHECK(W % 4 == 0, "text_embed: width %d", W);
+  hipLaunchKernelGGL(text_embed_kernel, dim3(cdiv(n_seq * ctx, 4)), dim3(256), 0, stream, ids, tok, pos, x, n_seq * ctx, ctx, W, vocab);
+  hipLaunchKernelGGL(eot_index_kernel, dim3(cdiv(n_seq, 256)), dim3(256), 0, stream, ids, eot_row, n_seq, ctx);
+  VTC_LAUNCH_CHECK("text_embed");
+  return 0;
+}
+
+int launch_cam_tokens(const float *main_f, const float *comm, const int64_t *comments, const float *mask_emb, float *X, int B,
+                      int nc, int ctx, int D, hipStream_t stream) {
+  hipLaunchKernelGGL(cam_tokens_kernel, dim3(cdiv(B * (1 + nc), 4)), dim3(256), 0, stream, main_f, comm, comments, mask_emb, X, B,
+                     nc, ctx, D);
+  VTC_LAUNCH_CHECK("cam_tokens");
+  return 0;
+}
+
+int launch_cam_finalize(const float *Y, const float *lin, const float *main_f, float *out, int B, int Lc, int D, int init_from_avg,
+                        int act, float scale, hipStream_t stream) {
+  VTC_CHECK(D <= 1024, "cam: width %d > 1024", D);
+  hipLaunchKernelGGL((cam_finalize_kernel<16>), dim3(cdiv(B, 4)), dim3(256), 0, stream, Y, lin, main_f, out, B, Lc, D, init_from_avg,
+                     act, scale);
+  VTC_LAUNCH_CHECK("cam_finalize");
+  return 0;
+}

@@ -1,0 +1,287 @@
+// gemm.hip -- the one GEMM of the hot path:  out[M,N] = epi(A[M,K] @ W[N,K]^T + bias)
+//
+// Used for every projection of the towers (QKV, out-proj, temporal_fc, c_fc, c_proj, patch
+// embedding, output projections, the CAM blocks), for the batch similarity and for the N x N
+// distance matrix of the retrieval sweep.  Replaces the cuBLAS/MKL GEMMs behind
+// model/timesformer_clip_alt.py:50,65,148,174 and upstream nn.MultiheadAttention / nn.Linear.
+//
+// gfx950 design
+//   * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA
+//     tiles of 16x16), K consumed in 128-byte rows (64 bf16 / 32 fp32 per step);
+//   * both operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double
+//     buffered; LDS image is lane-linear, the XOR bank swizzle is applied on the per-lane SOURCE
+//     address and again on the ds_read_b128 address (guide rule 21);
+//   * bf16: v_mfma_f32_16x16x32_bf16; fp32: 4 x v_mfma_f32_16x16x4_f32 per 16-byte chunk (exact
+//     fp32, k order inside a chunk permuted identically for both operands);
+//   * the MFMA "A" operand is the WEIGHT fragment and "B" the ACTIVATION fragment, so a lane ends
+//     up holding 4 consecutive output columns of one output row: bias / QuickGELU / residual /
+//     scatter epilogues run straight from the accumulators with 16-byte (fp32) or 8-byte (bf16)
+//     accesses, no LDS round trip;
+//   * workgroup ids are remapped so that each XCD walks a contiguous range of tiles in
+//     (8 row-tiles x all column-tiles) super-rows: the weight panel and 8 activation panels in
+//     flight stay resident in that XCD's 4 MiB L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = 128;                 // bytes of K per LDS row
+constexpr int TILE_BYTES = BM * ROWB;     // 16 KiB per operand per stage
+constexpr int NTHREADS = 256;
+constexpr int SUPER = 8;                  // row tiles per L2 super-row
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int KPR = 64;  // K elements per 128-byte row
+  __device__ static __forceinline__ void run(const uint4 &w, const uint4 &a, f32x4 &acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc,
+                                                  0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KPR = 32;
+  __device__ static __forceinline__ void run(const uint4 &w, const uint4 &a, f32x4 &acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.x), __builtin_bit_cast(float, a.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.y), __builtin_bit_cast(float, a.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.z), __builtin_bit_cast(float, a.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.w), __builtin_bit_cast(float, a.w), acc, 0, 0, 0);
+  }
+};
+
+struct GemmParams {
+  const char *A;
+  const char *W;
+  const float *bias;
+  void *out;
+  int M, N, K;
+  int lda_bytes, ldw_bytes, ldo;
+  int MT, NT;
+  GemmEpi epi;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// Stage one 128-row x 128-byte operand tile: 16 wave-instructions of 1 KiB, 4 per wave.
+__device__ __forceinline__ void stage_tile(const char *base, int row0, int nrows, int ld_bytes, int kbyte, char *lds_tile,
+                                           int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int group = wave * 4 + q;           // 8-row group
+    const int r = group * 8 + (lane >> 3);    // tile row this lane fills
+    const int cs = lane & 7;                  // LDS chunk slot (linear)
+    const int c = cs ^ ((r >> 1) & 7);        // source chunk (swizzle on the source side)
+    int gr = row0 + r;
+    gr = gr < nrows ? gr : nrows - 1;         // clamp: tail rows re-read a valid row, never stored
+    const char *src = base + (size_t)gr * ld_bytes + kbyte + c * 16;
+    __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds_tile + group * 1024), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+template <typename T, int MODE, typename OutT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // ---- XCD-aware tile walk -------------------------------------------------------------
+  int mt, nt;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per_super = SUPER * p.NT;
+    const int sr = logical / per_super, rem = logical - sr * per_super;
+    const int g = min(SUPER, p.MT - sr * SUPER);
+    nt = rem / g;
+    mt = sr * SUPER + (rem - nt * g);
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int ksteps = p.K / Mma<T>::KPR;
+  // prologue
+  stage_tile(p.A, m0, p.M, p.lda_bytes, 0, lds, wave, lane);
+  stage_tile(p.W, n0, p.N, p.ldw_bytes, 0, lds + TILE_BYTES, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA landed (this wave's share)
+  __syncthreads();
+
+  const int g = lane >> 4;
+  const int swz = (lane >> 1) & 7;
+  const int arow = (wr * 64 + (lane & 15)) * ROWB;
+  const int wrow = (wc * 64 + (lane & 15)) * ROWB;
+
+  int cur = 0;
+  for (int t = 0; t < ksteps; ++t) {
+    if (t + 1 < ksteps) {
+      char *nxt = lds + (cur ^ 1) * 2 * TILE_BYTES;
+      stage_tile(p.A, m0, p.M, p.lda_bytes, (t + 1) * ROWB, nxt, wave, lane);
+      stage_tile(p.W, n0, p.N, p.ldw_bytes, (t + 1) * ROWB, nxt + TILE_BYTES, wave, lane);
+    }
+    const char *as = lds + cur * 2 * TILE_BYTES;
+    const char *ws = as + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((4 * ks + g) ^ swz) << 4;
+      uint4 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const uint4 *>(as + arow + i * 16 * ROWB + coff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const uint4 *>(ws + wrow + j * 16 * ROWB + coff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mma<T>::run(wf[j], af[i], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds out[m][n..n+3], m = m0 + 64 wr + 16 i + (lane & 15),
+  //                n = n0 + 64 wc + 16 j + 4 g
+  const int ldo = p.ldo;
+  const bool vec_ok = (ldo & 3) == 0;
+  float scale = 1.0f;
+  if (MODE == EPI_SCALE) scale = __expf(*p.epi.scale_log);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && (m % p.epi.skip_mod) == 0) continue;
+    size_t orow = (size_t)m;
+    const float *posrow = nullptr, *temprow = nullptr;
+    float rn = 0.f;
+    if (MODE == EPI_PATCH) {
+      const int np = m % p.epi.P, ft = m / p.epi.P;
+      const int tt = p.epi.F > 0 ? ft % p.epi.F : 0, item = p.epi.F > 0 ? ft / p.epi.F : ft;
+      const int Fe = p.epi.F > 0 ? p.epi.F : 1;
+      orow = (size_t)item * p.epi.T + 1 + (size_t)np * Fe + tt;
+      posrow = p.epi.pos + (size_t)(1 + np) * p.N;
+      if (p.epi.temporal) temprow = p.epi.temporal + (size_t)tt * p.N;
+    }
+    if (MODE == EPI_L2DIST) rn = p.epi.rown[m];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + g * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const bool full = (n + 3 < p.N);
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (full || n + e < p.N) v[e] += p.bias[n + e];
+      }
+      if (MODE == VTC_EPI_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+      }
+      if (MODE == EPI_PATCH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] += posrow[n + e];
+          if (temprow) v[e] += temprow[n + e];
+        }
+      }
+      if (MODE == EPI_L2DIST) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (full || n + e < p.N) v[e] = rn + p.epi.coln[n + e] - 2.0f * v[e];
+      }
+      if (MODE == EPI_SCALE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= scale;
+      }
+      OutT *o = reinterpret_cast<OutT *>(p.out) + orow * ldo + n;
+      if (MODE == VTC_EPI_RESID) {
+        float *xo = reinterpret_cast<float *>(o);
+        if (full && vec_ok) {
+          float4 x = *reinterpret_cast<float4 *>(xo);
+          x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
+          *reinterpret_cast<float4 *>(xo) = x;
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) xo[e] += v[e];
+        }
+      } else {
+        if (full && vec_ok) {
+          ElemOps<OutT>::store4(o, v[0], v[1], v[2], v[3]);
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) ElemOps<OutT>::store(o + e, v[e]);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int MODE, typename OutT>
+int run(const GemmParams &p, hipStream_t stream) {
+  const int grid = p.MT * p.NT;
+  const size_t shmem = 4 * TILE_BYTES;  // 64 KiB: 2 stages x (A + W)
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<T, MODE, OutT>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<T, MODE, OutT>), dim3(grid), dim3(NTHREADS), shmem, stream, p);
+  VTC_LAUNCH_CHECK("gemm");
+  return 0;
+}
+
+template <typename T>
+int dispatch(const GemmParams &p, hipStream_t stream) {
+  const bool out_f32 = p.epi.out_dtype == VTC_F32;
+  switch (p.epi.mode) {
+    case VTC_EPI_STORE:
+      if (out_f32) return run<T, VTC_EPI_STORE, float>(p, stream);
+      return run<T, VTC_EPI_STORE, bf16_t>(p, stream);
+    case VTC_EPI_GELU:
+      if (out_f32) return run<T, VTC_EPI_GELU, float>(p, stream);
+      return run<T, VTC_EPI_GELU, bf16_t>(p, stream);
+    case VTC_EPI_RESID: return run<T, VTC_EPI_RESID, float>(p, stream);
+    case EPI_PATCH: return run<T, EPI_PATCH, float>(p, stream);
+    case EPI_L2DIST: return run<T, EPI_L2DIST, float>(p, stream);
+    case EPI_SCALE: return run<T, EPI_SCALE, float>(p, stream);
+  }
+  vtc_set_error("gemm: unknown epilogue %d", p.epi.mode);
+  return 1;
+}
+
+}  // namespace
+
+int launch_gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype,
+                const GemmEpi &epi, hipStream_t stream) {
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "gemm: bad dtype %d", dtype);
+  const int esz = dtype == VTC_BF16 ? 2 : 4;
+  const int kpr = ROWB / esz;
+  VTC_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
+  VTC_CHECK(K % kpr == 0, "gemm: K=%d must be a multiple of %d for dtype %d", K, kpr, dtype);
+  VTC_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: operands must be 16-byte aligned");
+  VTC_CHECK(!(epi.out_dtype == VTC_BF16 && (epi.mode == VTC_EPI_RESID || epi.mode >= EPI_PATCH)),
+            "gemm: epilogue %d writes fp32 only", epi.mode);
+  GemmParams p;
+  p.A = (const char *)A; p.W = (const char *)W; p.bias = bias; p.out = out;
+  p.M = M; p.N = N; p.K = K;
+  p.lda_bytes = K * esz; p.ldw_bytes = K * esz;
+  p.ldo = epi.ldo > 0 ? epi.ldo : N;
+  p.MT = cdiv(M, BM); p.NT = cdiv(N, BN);
+  p.epi = epi;
+  return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
+}
+
+extern "C" int vtc_gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype,
+                        int epilogue, int out_dtype, int skip_mod, void *stream) {
+  VTC_CHECK(epilogue >= VTC_EPI_STORE && epilogue <= VTC_EPI_RESID, "vtc_gemm: bad epilogue %d", epilogue);
+  GemmEpi e;
+  e.mode = epilogue; e.out_dtype = epilogue == VTC_EPI_RESID ? VTC_F32 : out_dtype; e.skip_mod = skip_mod;
+  return launch_gemm(A, W, bias, out, M, N, K, dtype, e, (hipStream_t)stream);
+}

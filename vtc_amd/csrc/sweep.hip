@@ -1,0 +1,257 @@
+// sweep.hip -- the N x N retrieval sweep and the batch-level similarity / loss.
+//   vtc_l2_topk     exact squared-L2 k-NN: replaces faiss.GpuIndexFlatL2.add/search in
+//                   RecallAtK.compute (model/metric.py:137-146)
+//   vtc_recall_hits `target in rp[:k]` counting (model/metric.py:148-160)
+//   vtc_similarity  exp(logit_scale) * V @ T^T (model/model.py:369,478,504,621)
+//   vtc_clip_loss   0.5 (CE(sim, arange) + CE(sim^T, arange)) (model/loss.py:18-22)
+//
+// Sweep pipeline (per block of query rows, the fp32 distance matrix "tiled in HBM" as
+// BASELINE.json prescribes; blocks are sized to stay resident in the 256 MiB Infinity Cache):
+//   1. row norms |q|^2, |g|^2 in fp32 (once);
+//   2. distance GEMM with the L2 epilogue  d = |q|^2 + |g|^2 - 2 q.g  (gemm.hip, EPI_L2DIST):
+//        F32     fp32 MFMA, exact;
+//        BF16X3  operands split hi/lo into bf16 and concatenated along K
+//                ([q_hi|q_lo|q_hi] . [g_hi|g_hi|g_lo]) so that ONE bf16 GEMM with K' = 3D forms
+//                q_hi g_hi + q_lo g_hi + q_hi g_lo with fp32 accumulation;
+//        BF16    hi parts only;
+//   3. streaming top-k: one wave per query row reads the row with 16-byte loads; the wave keeps
+//      the sorted best list ONE ENTRY PER LANE; a value is compared against the current k-th best
+//      (wave-uniform), so after warm-up almost every step is load + compare + ballot; the rare
+//      insertion is a ballot/popcount rank + one shuffle.  Order is (distance, index)
+//      lexicographic => ties resolve to the lowest gallery index, independent of scan order.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict__ x, float *__restrict__ out, int n, int d) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const float *xr = x + (size_t)r * d;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) s += xr[c] * xr[c];
+  s = wave_sum(s);
+  if (lane == 0) out[r] = s;
+}
+
+// out[r] = [hi | lo | hi] (query side, side = 0) or [hi | hi | lo] (gallery side, side = 1); parts = 1 => [hi]
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict__ x, bf16_t *__restrict__ out, int n, int d,
+                                                         int parts, int side) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)n * d) return;
+  const size_t r = i / d;
+  const int c = (int)(i - r * d);
+  const float v = x[i];
+  const bf16_t hi = f2bf(v);
+  bf16_t *o = out + r * (size_t)(parts * d);
+  o[c] = hi;
+  if (parts == 3) {
+    const bf16_t lo = f2bf(v - bf2f(hi));
+    o[d + c] = side == 0 ? lo : hi;
+    o[2 * d + c] = side == 0 ? hi : lo;
+  }
+}
+
+__global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__ dist, int ld, int n_rows, int n_cols, int depth,
+                                                       int64_t *__restrict__ ids, float *__restrict__ dists, size_t out_row0) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const float *row = dist + (size_t)r * ld;
+  float bd = INFINITY;
+  int bi = 0x7fffffff;
+  float tau = INFINITY;
+  int tau_i = 0x7fffffff;
+  const bool vec = (ld & 3) == 0;
+  for (int base = 0; base < n_cols; base += 256) {
+    const int c = base + lane * 4;
+    float v[4];
+    if (vec && c + 3 < n_cols) {
+      const float4 t = *reinterpret_cast<const float4 *>(row + c);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = c + e < n_cols ? row[c + e] : INFINITY;
+    }
+    bool pass[4];
+    bool anyp = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = c + e;
+      pass[e] = idx < n_cols && (v[e] < tau || (v[e] == tau && idx < tau_i));
+      anyp |= pass[e];
+    }
+    if (__ballot(anyp) == 0ull) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned long long mask = __ballot(pass[e]);
+      while (mask) {
+        const int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float cv = __shfl(v[e], l, 64);
+        const int ci = base + l * 4 + e;
+        if (cv < tau || (cv == tau && ci < tau_i)) {     // wave-uniform: the list may have tightened meanwhile
+          const bool less = (bd < cv) || (bd == cv && bi < ci);
+          const int pos = __popcll(__ballot(less));
+          const float ud = __shfl_up(bd, 1, 64);
+          const int ui = __shfl_up(bi, 1, 64);
+          if (lane > pos) { bd = ud; bi = ui; }
+          if (lane == pos) { bd = cv; bi = ci; }
+          tau = __shfl(bd, depth - 1, 64);
+          tau_i = __shfl(bi, depth - 1, 64);
+        }
+      }
+    }
+  }
+  if (lane < depth) {
+    ids[(out_row0 + r) * depth + lane] = bi == 0x7fffffff ? -1 : (int64_t)bi;
+    if (dists) dists[(out_row0 + r) * depth + lane] = bd;
+  }
+}
+
+__global__ __launch_bounds__(256) void recall_hits_kernel(const int64_t *__restrict__ ids, int n, int depth, int64_t target_offset,
+                                                          int k0, int k1, int k2, int k3, int nk, unsigned long long *hits) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int rank = 1 << 30;
+  if (i < n) {
+    const int64_t t = target_offset + i;
+    for (int j = 0; j < depth; ++j)
+      if (ids[(size_t)i * depth + j] == t) { rank = j; break; }
+  }
+  const int ks[4] = {k0, k1, k2, k3};
+  for (int q = 0; q < nk; ++q) {
+    const bool hit = i < n && rank < ks[q];
+    const int cnt = __popcll(__ballot(hit));
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&hits[q], (unsigned long long)cnt);
+  }
+}
+
+// terms[i] = lse(sim[i,:]) - sim[i,i];  terms[n + j] = lse(sim[:,j]) - sim[j,j]
+__global__ __launch_bounds__(256) void lse_terms_kernel(const float *__restrict__ sim, int n, float *__restrict__ terms) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= 2 * n) return;
+  const bool col = w >= n;
+  const int i = col ? w - n : w;
+  const size_t stride = col ? (size_t)n : 1, base = col ? (size_t)i : (size_t)i * n;
+  float mx = -INFINITY;
+  for (int c = lane; c < n; c += 64) mx = fmaxf(mx, sim[base + c * stride]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < n; c += 64) s += expf(sim[base + c * stride] - mx);
+  s = wave_sum(s);
+  if (lane == 0) terms[w] = mx + logf(s) - sim[(size_t)i * n + i];
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float *__restrict__ terms, int n, float *__restrict__ loss) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < 2 * n; i += 256) s += terms[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = 0.5f * ((part[0] + part[1]) + (part[2] + part[3])) / n;
+}
+
+struct SweepWs {
+  float *qn, *gn;
+  bf16_t *qb, *gb;
+  float *dist;
+  int rows_per_block;
+  size_t total;
+};
+
+SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block) {
+  SweepWs s;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return ws ? ws + o : (char *)nullptr; };
+  s.qn = (float *)take((size_t)nq * 4);
+  s.gn = (float *)take((size_t)ng * 4);
+  const int parts = precision == VTC_SWEEP_BF16X3 ? 3 : (precision == VTC_SWEEP_BF16 ? 1 : 0);
+  s.qb = (bf16_t *)take((size_t)nq * d * parts * 2);
+  s.gb = (bf16_t *)take((size_t)ng * d * parts * 2);
+  int rpb = rows_per_block;
+  if (rpb <= 0) {
+    const size_t budget = (size_t)128 << 20;                 // keep the live block inside the Infinity Cache
+    rpb = (int)(budget / ((size_t)ng * 4));
+    rpb = rpb / 128 * 128;
+    if (rpb < 128) rpb = 128;
+  }
+  if (rpb > nq) rpb = nq;
+  s.rows_per_block = rpb;
+  s.dist = (float *)take((size_t)rpb * ng * 4);
+  s.total = off;
+  return s;
+}
+
+}  // namespace
+
+extern "C" size_t vtc_l2_topk_workspace_bytes(int n_gallery, int n_queries, int d, int precision, int rows_per_block) {
+  return plan(nullptr, n_gallery, n_queries, d, precision, rows_per_block).total;
+}
+
+extern "C" int vtc_l2_topk(const float *gallery, const float *queries, int ng, int nq, int d, int depth, int precision,
+                           int rows_per_block, int64_t *ids, float *dists, void *ws, size_t ws_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VTC_CHECK(ng > 0 && nq > 0 && d > 0, "l2_topk: empty problem");
+  VTC_CHECK(depth >= 1 && depth <= 64 && depth <= ng, "l2_topk: depth=%d must be in [1, min(64, n_gallery)]", depth);
+  VTC_CHECK(precision >= VTC_SWEEP_F32 && precision <= VTC_SWEEP_BF16, "l2_topk: bad precision %d", precision);
+  VTC_CHECK(d % 64 == 0, "l2_topk: d=%d must be a multiple of 64", d);
+  SweepWs s = plan((char *)ws, ng, nq, d, precision, rows_per_block);
+  VTC_CHECK(ws && ws_bytes >= s.total, "l2_topk: workspace too small (%zu < %zu)", ws_bytes, s.total);
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, queries, s.qn, nq, d);
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(ng, 4)), dim3(256), 0, stream, gallery, s.gn, ng, d);
+  const int parts = precision == VTC_SWEEP_BF16X3 ? 3 : 1;
+  if (precision != VTC_SWEEP_F32) {
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)(((size_t)nq * d + 255) / 256)), dim3(256), 0, stream, queries, s.qb, nq, d, parts, 0);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)(((size_t)ng * d + 255) / 256)), dim3(256), 0, stream, gallery, s.gb, ng, d, parts, 1);
+  }
+  VTC_LAUNCH_CHECK("l2_topk prologue");
+  for (int r0 = 0; r0 < nq; r0 += s.rows_per_block) {
+    const int rows = min(s.rows_per_block, nq - r0);
+    GemmEpi e;
+    e.mode = EPI_L2DIST; e.out_dtype = VTC_F32; e.rown = s.qn + r0; e.coln = s.gn;
+    int rc;
+    if (precision == VTC_SWEEP_F32)
+      rc = launch_gemm(queries + (size_t)r0 * d, gallery, nullptr, s.dist, rows, ng, d, VTC_F32, e, stream);
+    else
+      rc = launch_gemm(s.qb + (size_t)r0 * d * parts, s.gb, nullptr, s.dist, rows, ng, d * parts, VTC_BF16, e, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(row_topk_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, s.dist, ng, rows, ng, depth, ids, dists, (size_t)r0);
+    VTC_LAUNCH_CHECK("row_topk");
+  }
+  return 0;
+}
+
+extern "C" int vtc_recall_hits(const int64_t *ids, int nq, int depth, int64_t target_offset, const int *k_vals, int nk,
+                               long long *hits, void *stream) {
+  VTC_CHECK(nk >= 1 && nk <= 4, "recall_hits: nk=%d must be in [1,4]", nk);
+  int k[4] = {0, 0, 0, 0};
+  for (int i = 0; i < nk; ++i) {
+    VTC_CHECK(k_vals[i] >= 1 && k_vals[i] <= depth, "recall_hits: k=%d outside [1, depth=%d]", k_vals[i], depth);
+    k[i] = k_vals[i];
+  }
+  hipLaunchKernelGGL(recall_hits_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, ids, nq, depth, target_offset,
+                     k[0], k[1], k[2], k[3], nk, (unsigned long long *)hits);
+  VTC_LAUNCH_CHECK("recall_hits");
+  return 0;
+}
+
+extern "C" int vtc_similarity(const float *v, const float *t, int nv, int nt, int d, const float *logit_scale, float *sim,
+                              void *stream) {
+  GemmEpi e;
+  e.mode = EPI_SCALE; e.out_dtype = VTC_F32; e.scale_log = logit_scale;
+  return launch_gemm(v, t, nullptr, sim, nv, nt, d, VTC_F32, e, (hipStream_t)stream);
+}
+
+extern "C" size_t vtc_clip_loss_workspace_bytes(int n) { return (size_t)2 * n * sizeof(float); }
+
+extern "C" int vtc_clip_loss(const float *sim, int n, float *loss, void *ws, size_t ws_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VTC_CHECK(n > 0, "clip_loss: n=%d", n);
+  VTC_CHECK(ws && ws_bytes >= vtc_clip_loss_workspace_bytes(n), "clip_loss: workspace too small");
+  hipLaunchKernelGGL(lse_terms_kernel, dim3(cdiv(2 * n, 4)), dim3(256), 0, stream, sim, n, (float *)ws);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, (const float *)ws, n, loss);
+  VTC_LAUNCH_CHECK("clip_loss");
+  return 0;
+}

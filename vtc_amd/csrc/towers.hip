@@ -1,0 +1,253 @@
+// towers.hip -- host-side orchestration of the three towers and the CAM: each entry point
+// enqueues the kernel sequence of one forward pass on the caller's stream, using only the
+// caller's workspace.  No allocation, no synchronisation, no global state.
+//
+//   vtc_vision_forward  upstream VisionTransformer.forward (nframes == 0) /
+//                       model/timesformer_clip_alt.py:252-286 + block :135-175 (nframes > 0)
+//   vtc_text_forward    upstream CLIP.encode_text
+//   vtc_cam_forward     model/model.py:141-205 (+ the masking of :207-214)
+//
+// Activation layout in HBM (per call):
+//   x    fp32 [rows, W]    residual stream, rows in the REFERENCE's token order
+//                          (video: item-major, row item*T = cls, row item*T + 1 + n*F + t = patch n
+//                          of frame t, timesformer_clip_alt.py:271-275), updated in place by the
+//                          GEMM residual epilogues;
+//   h    T    [rows, W]    LayerNorm output, then reused for the attention output;
+//   big  T    [rows, 4W]   packed qkv ([rows,3W]), then the MLP hidden ([rows,4W]), and before the
+//                          first block the im2row patch matrix;
+// where T is the compute dtype (bf16 or fp32).  The reference's ~10 rearrange/cat/repeat copies
+// per block (timesformer_clip_alt.py:143-173) do not exist here: the attention kernel addresses
+// tokens through an affine row map and the cls bookkeeping is two tiny kernels.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+void vtc_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char *vtc_last_error(void) { return g_err; }
+extern "C" int vtc_abi_version(void) { return 1; }
+
+int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res, hipStream_t stream);
+int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, int T, int W, hipStream_t stream);
+int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int F, int T, int W, hipStream_t stream);
+int launch_text_embed(const int64_t *ids, const float *tok, const float *pos, float *x, int *eot_row, int n_seq, int ctx, int W, int vocab, hipStream_t stream);
+int launch_cam_tokens(const float *main_f, const float *comm, const int64_t *comments, const float *mask_emb, float *X, int B, int nc, int ctx, int D, hipStream_t stream);
+int launch_cam_finalize(const float *Y, const float *lin, const float *main_f, float *out, int B, int Lc, int D, int init_from_avg, int act, float scale, hipStream_t stream);
+
+namespace {
+
+struct Bump {
+  char *base;
+  size_t off = 0;
+  explicit Bump(void *b) : base((char *)b) {}
+  void *take(size_t bytes) {
+    const size_t o = off;
+    off = align_up(off + bytes, 256);
+    return base ? base + o : nullptr;
+  }
+};
+
+#define RUN(call)        \
+  do {                   \
+    int rc_ = (call);    \
+    if (rc_) return rc_; \
+  } while (0)
+
+inline int esz(int dtype) { return dtype == VTC_BF16 ? 2 : 4; }
+
+int gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype, int mode, int out_dtype,
+         int skip_mod, hipStream_t s) {
+  GemmEpi e;
+  e.mode = mode; e.out_dtype = out_dtype; e.skip_mod = skip_mod;
+  return launch_gemm(A, W, bias, out, M, N, K, dtype, e, s);
+}
+
+// x += MLP(ln_2 x)   (timesformer_clip_alt.py:174 / upstream block)
+int mlp_part(const vtc_block_w &b, float *x, void *h, void *big, int rows, int W, int dtype, hipStream_t s) {
+  RUN(launch_layernorm(x, b.ln2_g, b.ln2_b, h, rows, W, dtype, nullptr, 1, false, s));
+  RUN(gemm(h, b.fc_w, b.fc_b, big, rows, 4 * W, W, dtype, VTC_EPI_GELU, dtype, 0, s));
+  RUN(gemm(big, b.proj_w, b.proj_b, x, rows, W, 4 * W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+  return 0;
+}
+
+// x += MHA(ln_1 x) over n_seq contiguous sequences of L tokens
+int attn_part_contig(const vtc_block_w &b, float *x, void *h, void *big, int n_seq, int L, int W, int heads, int causal, int dtype,
+                     hipStream_t s) {
+  const int rows = n_seq * L;
+  RUN(launch_layernorm(x, b.ln1_g, b.ln1_b, h, rows, W, dtype, nullptr, 1, false, s));
+  RUN(gemm(h, b.qkv_w, b.qkv_b, big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+  RUN(launch_attention(big, h, nullptr, n_seq, L, heads, causal, 1, 0, L, 0, 0, 1, dtype, s));
+  RUN(gemm(h, b.out_w, b.out_b, x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+  return 0;
+}
+
+struct VisionWs {
+  float *x, *cls_tmp;
+  void *h, *big, *lnp;
+  size_t total;
+};
+
+VisionWs plan_vision(const vtc_vision_w *w, int n_items, int F, int dtype, void *ws) {
+  Bump b(ws);
+  VisionWs v;
+  const int P = w->grid * w->grid, T = 1 + P * F, W = w->width;
+  const size_t rows = (size_t)n_items * T;
+  const size_t patch_elems = (size_t)n_items * F * P * 3 * w->patch * w->patch;
+  size_t big_elems = rows * 4 * W;
+  if (patch_elems > big_elems) big_elems = patch_elems;
+  v.x = (float *)b.take(rows * W * 4);
+  v.h = b.take(rows * W * esz(dtype));
+  v.big = b.take(big_elems * esz(dtype));
+  v.cls_tmp = (float *)b.take((size_t)n_items * F * W * 4);
+  v.lnp = b.take((size_t)n_items * W * esz(dtype));
+  v.total = b.off;
+  return v;
+}
+
+struct TextWs {
+  float *x;
+  void *h, *big, *lnp;
+  int *eot;
+  size_t total;
+};
+
+TextWs plan_text(int rows, int n_seq, int W, int dtype, void *ws) {
+  Bump b(ws);
+  TextWs t;
+  t.x = (float *)b.take((size_t)rows * W * 4);
+  t.h = b.take((size_t)rows * W * esz(dtype));
+  t.big = b.take((size_t)rows * 4 * W * esz(dtype));
+  t.lnp = b.take((size_t)n_seq * W * esz(dtype));
+  t.eot = (int *)b.take((size_t)n_seq * 4);
+  t.total = b.off;
+  return t;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" size_t vtc_vision_workspace_bytes(const vtc_vision_w *w, int n_items, int frames, int dtype) {
+  return plan_vision(w, n_items, frames, dtype, nullptr).total;
+}
+
+extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int pixel_dtype, int n_items, int F, float *out,
+                                  void *ws, size_t ws_bytes, int dtype, void *stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  VTC_CHECK(w && pixels && out && ws, "vision_forward: null argument");
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "vision_forward: bad dtype %d", dtype);
+  VTC_CHECK(n_items > 0 && F > 0, "vision_forward: n_items=%d frames=%d", n_items, F);
+  const bool tsf = w->nframes > 0;
+  VTC_CHECK(tsf || F == 1, "vision_forward: the image tower takes frames == 1 (got %d)", F);
+  VTC_CHECK(!tsf || F <= w->nframes, "vision_forward: %d frames > temporal_embed rows %d", F, w->nframes);
+  VTC_CHECK(w->width == w->heads * 64, "vision_forward: head_dim must be 64 (width %d, heads %d)", w->width, w->heads);
+  const int P = w->grid * w->grid, T = 1 + P * F, W = w->width;
+  VTC_CHECK(1 + P <= 80 && F <= 80, "vision_forward: sequence too long (1+P=%d, F=%d)", 1 + P, F);
+  const int rows = n_items * T, res = w->grid * w->patch;
+  VisionWs v = plan_vision(w, n_items, F, dtype, ws);
+  VTC_CHECK(ws_bytes >= v.total, "vision_forward: workspace too small (%zu < %zu)", ws_bytes, v.total);
+
+  // patch embedding (+pos, +temporal) scattered into the reference's token order, cls rows, ln_pre
+  RUN(launch_im2row(pixels, pixel_dtype, v.big, dtype, n_items * F, w->grid, w->patch, res, s));
+  {
+    GemmEpi e;
+    e.mode = EPI_PATCH; e.out_dtype = VTC_F32; e.pos = w->pos; e.temporal = tsf ? w->temporal : nullptr;
+    e.P = P; e.F = F; e.T = T; e.ldo = W;
+    RUN(launch_gemm(v.big, w->conv_w, nullptr, v.x, n_items * F * P, W, 3 * w->patch * w->patch, dtype, e, s));
+  }
+  RUN(launch_cls_rows(v.x, w->class_embedding, w->pos, n_items, T, W, s));
+  RUN(launch_layernorm(v.x, w->ln_pre_g, w->ln_pre_b, v.x, rows, W, VTC_F32, nullptr, 1, false, s));
+
+  for (int l = 0; l < w->layers; ++l) {
+    const vtc_block_w &b = w->blocks[l];
+    if (tsf) {
+      // temporal branch (timesformer_clip_alt.py:142-149): sequences = the F frames of one (item, patch)
+      RUN(launch_layernorm(v.x, b.lnt_g, b.lnt_b, v.h, rows, W, dtype, nullptr, 1, false, s));
+      RUN(gemm(v.h, b.tqkv_w, b.tqkv_b, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+      RUN(launch_attention(v.big, v.h, nullptr, n_items * P, F, w->heads, 0, P, 1, T, F, 0, 1, dtype, s));
+      if (b.tout_w) {
+        RUN(gemm(v.h, b.tout_w, b.tout_b, v.big, rows, W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+        RUN(gemm(v.big, b.tfc_w, b.tfc_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, T, s));
+      } else {  // temporal_fc o out_proj pre-multiplied on the host
+        RUN(gemm(v.h, b.tfc_w, b.tfc_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, T, s));
+      }
+      // spatial branch (:152-168): sequences = (item, frame): [cls, the P patches of that frame]
+      RUN(launch_layernorm(v.x, b.ln1_g, b.ln1_b, v.h, rows, W, dtype, nullptr, 1, false, s));
+      RUN(gemm(v.h, b.qkv_w, b.qkv_b, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+      RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, 1, F, dtype, s));
+      RUN(launch_cls_mean(v.cls_tmp, v.h, dtype, n_items, F, T, W, s));
+      RUN(gemm(v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+    } else {
+      RUN(attn_part_contig(b, v.x, v.h, v.big, n_items, T, W, w->heads, 0, dtype, s));
+    }
+    RUN(mlp_part(b, v.x, v.h, v.big, rows, W, dtype, s));
+  }
+  // ln_post(x[:,0]) @ proj
+  RUN(launch_layernorm(v.x, w->ln_post_g, w->ln_post_b, v.lnp, n_items, W, dtype, nullptr, T, false, s));
+  RUN(gemm(v.lnp, w->proj_t, nullptr, out, n_items, w->embed_dim, W, dtype, VTC_EPI_STORE, VTC_F32, 0, s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" size_t vtc_text_workspace_bytes(const vtc_text_w *w, int n_seq, int dtype) {
+  return plan_text(n_seq * w->ctx, n_seq, w->width, dtype, nullptr).total;
+}
+
+extern "C" int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_seq, float *out, void *ws, size_t ws_bytes,
+                                int dtype, void *stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  VTC_CHECK(w && ids && out && ws, "text_forward: null argument");
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "text_forward: bad dtype %d", dtype);
+  VTC_CHECK(n_seq > 0, "text_forward: n_seq=%d", n_seq);
+  VTC_CHECK(w->ctx <= 80, "text_forward: context %d > 80 unsupported", w->ctx);
+  VTC_CHECK(w->width == w->heads * 64, "text_forward: head_dim must be 64");
+  const int W = w->width, rows = n_seq * w->ctx;
+  TextWs t = plan_text(rows, n_seq, W, dtype, ws);
+  VTC_CHECK(ws_bytes >= t.total, "text_forward: workspace too small (%zu < %zu)", ws_bytes, t.total);
+  RUN(launch_text_embed(ids, w->tok_emb, w->pos, t.x, t.eot, n_seq, w->ctx, W, w->vocab, s));
+  for (int l = 0; l < w->layers; ++l) {
+    const vtc_block_w &b = w->blocks[l];
+    RUN(attn_part_contig(b, t.x, t.h, t.big, n_seq, w->ctx, W, w->heads, 1, dtype, s));
+    RUN(mlp_part(b, t.x, t.h, t.big, rows, W, dtype, s));
+  }
+  // ln_final on the EOT row only (LayerNorm is per-row, so gathering first is identical), then @ text_projection
+  RUN(launch_layernorm(t.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, dtype, t.eot, 1, false, s));
+  RUN(gemm(t.lnp, w->proj_t, nullptr, out, n_seq, w->embed_dim, W, dtype, VTC_EPI_STORE, VTC_F32, 0, s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" size_t vtc_cam_workspace_bytes(const vtc_cam_w *w, int B, int nc, int dtype) {
+  TextWs t = plan_text(B * (1 + nc), B, w->width, dtype, nullptr);
+  return t.total + align_up((size_t)B * w->width * 4, 256);
+}
+
+extern "C" int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, const float *comm_feats, const int64_t *comments,
+                               int ctx, int B, int nc, float *adapted, void *ws, size_t ws_bytes, int dtype, void *stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  VTC_CHECK(w && main_feats && comm_feats && comments && adapted && ws, "cam_forward: null argument");
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "cam_forward: bad dtype %d", dtype);
+  VTC_CHECK(B > 0 && nc >= 0 && 1 + nc <= 80, "cam_forward: B=%d nc=%d", B, nc);
+  VTC_CHECK(w->width == w->heads * 64, "cam_forward: head_dim must be 64 (width %d heads %d)", w->width, w->heads);
+  const int D = w->width, Lc = 1 + nc, rows = B * Lc;
+  TextWs t = plan_text(rows, B, D, dtype, ws);
+  float *lin = (float *)((char *)ws + t.total);
+  VTC_CHECK(ws_bytes >= vtc_cam_workspace_bytes(w, B, nc, dtype), "cam_forward: workspace too small");
+  RUN(launch_cam_tokens(main_feats, comm_feats, comments, w->mask_embedding, t.x, B, nc, ctx, D, s));
+  for (int l = 0; l < w->layers; ++l) {
+    const vtc_block_w &b = w->blocks[l];
+    RUN(attn_part_contig(b, t.x, t.h, t.big, B, Lc, D, w->heads, 0, dtype, s));
+    RUN(mlp_part(b, t.x, t.h, t.big, rows, D, dtype, s));
+  }
+  if (!w->init_from_avg) {  // comm_res = final_linear(comm_tfm[0])   model/model.py:161
+    RUN(launch_layernorm(t.x, nullptr, nullptr, t.lnp, B, D, dtype, nullptr, Lc, true, s));
+    RUN(gemm(t.lnp, w->final_linear, nullptr, lin, B, D, D, dtype, VTC_EPI_STORE, VTC_F32, 0, s));
+  }
+  RUN(launch_cam_finalize(t.x, lin, main_feats, adapted, B, Lc, D, w->init_from_avg, w->residual_activation, w->squash_scale, s));
+  return 0;
+}

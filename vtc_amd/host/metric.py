@@ -1,0 +1,100 @@
+"""Drop-in for the reference's ``model.metric.RecallAtK`` (model/metric.py:103-187).
+
+``compute`` keeps the reference's contract -- numpy fp32 ``[N, D]`` in, ``[(k, recall)]`` out,
+search depth ``max(k)+1``, hit test ``target in rp[:k]``, denominator ``len(features_a)`` -- but
+the exact-L2 search runs in libvtc_hip.so (vtc_l2_topk) instead of faiss.GpuIndexFlatL2.
+"""
+from __future__ import annotations
+
+import time
+from collections.abc import Iterable
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .. import ops
+
+__all__ = ["RecallAtK", "BaseMetric"]
+
+
+class BaseMetric:
+    def __init__(self, name):
+        self.name = name
+        self.writer = None
+        self.is_train = True
+        self.is_val = True
+
+    def set_writer(self, writer):
+        self.writer = writer
+
+
+class RecallAtK(BaseMetric):
+    #: how q.g is formed: SWEEP_F32 (exact fp32, default, what faiss's useFloat16=False does),
+    #: SWEEP_BF16X3 (split bf16, ~5e-7) or SWEEP_BF16
+    precision = L.SWEEP_F32
+
+    def __init__(self, name_a, name_b, k_vals=5, device=None):
+        super().__init__("recall@k")
+        if not isinstance(k_vals, Iterable):     # the reference's collections.Iterable (metric.py:106) is gone in py>=3.10
+            k_vals = [k_vals]
+        self.k_vals = list(k_vals)
+        self.name_a, self.name_b = name_a, name_b
+        self.is_train = False
+        self.device = device
+        self.reset()
+
+    def reset(self):
+        self.insert_index = 0
+        self.features_a_list, self.features_b_list = [], []
+
+    def update(self, loss, output, meta):
+        """metric.py:123-135; embeddings stay on the GPU (no per-batch D2H)."""
+        fa, fb = output[0].detach(), output[1].detach()
+        if self.device is None:
+            self.device = fa.device
+        self.features_a_list.append(fa)
+        self.features_b_list.append(fb)
+        self.insert_index += fa.shape[0]
+
+    def _dev(self):
+        return self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    def topk_ids(self, features_a, features_b) -> torch.Tensor:
+        a = torch.as_tensor(features_a, dtype=torch.float32).to(self._dev())
+        b = torch.as_tensor(features_b, dtype=torch.float32).to(self._dev())
+        if a.dim() != 2 or b.dim() != 2:
+            raise ValueError("RecallAtK.compute expects 2-D [N, D] features (one caption per video, SURVEY 3.3)")
+        depth = min(int(np.max(self.k_vals) + 1), a.shape[0])
+        ids, _ = ops.l2_topk(a, b, depth, precision=self.precision, return_dists=False)
+        return ids
+
+    def compute(self, features_a, features_b):
+        """metric.py:137-161."""
+        num_samples = features_a.shape[0]
+        ids = self.topk_ids(features_a, features_b)
+        ks = [min(int(k), ids.shape[1]) for k in self.k_vals]
+        out = []
+        for i in range(0, len(ks), 4):
+            hits = ops.recall_hits(ids, ks[i:i + 4]).cpu().numpy()
+            out += [(k, float(h) / num_samples) for k, h in zip(self.k_vals[i:i + 4], hits)]
+        return out
+
+    def avg(self):
+        return None
+
+    def result(self):
+        """metric.py:166-187."""
+        tic = time.time()
+        fa, fb = torch.cat(self.features_a_list), torch.cat(self.features_b_list)
+        assert self.insert_index == len(fa)
+        res = {}
+        for k, r in self.compute(fa, fb):
+            res[f"{self.name_b}_from_{self.name_a}-recall_at_{k}"] = r
+        for k, r in self.compute(fb, fa):
+            res[f"{self.name_a}_from_{self.name_b}-recall_at_{k}"] = r
+        if self.writer:
+            for name, r in res.items():
+                self.writer.add_scalar(name, r)
+        print("RecallAtK: result() took %.3fs" % (time.time() - tic))
+        return res

@@ -1,0 +1,249 @@
+"""Drop-in for the reference's ``model.model`` (model/model.py) on MI355X.
+
+Same class names, constructor kwargs, state-dict keys, ``forward`` signatures and return
+triples ``(feats_vis, feats_text, sim)`` as the reference, so that
+``config.init_obj("arch", module_arch)`` (utils/parse_config.py:97-112, evaluation/eval.py:88)
+and strict ``load_state_dict`` (evaluation/eval.py:90-91) work unchanged:
+
+    PretrainedCLIP                      model/model.py:308-371
+    PretrainedCLIP_finaltf              model/model.py:374-480
+    PretrainedCLIP_TimeSformer          model/model.py:483-506
+    PretrainedCLIP_TimeSformer_finaltf  model/model.py:539-623
+
+The forward pass is forward/eval only and runs entirely in libvtc_hip.so: inputs must be on
+a ROCm GPU and the module in ``eval()`` mode, anything else raises (there is deliberately no
+CPU or PyTorch fallback -- the CPU restatement lives in ``oracle/`` and is test-only).
+Out of scope (raise): training-mode branches (random comment masking / skip adapter),
+``residual_activation`` in {"sub_mean","bn"}, the audio branch, feature-MLP baselines.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops, towers
+from . import clip_arch
+
+__all__ = ["PretrainedCLIP", "PretrainedCLIP_finaltf", "PretrainedCLIP_TimeSformer",
+           "PretrainedCLIP_TimeSformer_finaltf", "PretrainedCLIPBase"]
+
+
+def normalize(x):
+    return ops.normalize_rows(x)
+
+
+class PretrainedCLIPBase(nn.Module):
+    #: arithmetic of the GEMM/attention operands on the HIP path (fp32 everywhere else)
+    compute_dtype = torch.bfloat16
+    #: multiply temporal_fc and timeattn.out_proj together at pack time (one GEMM instead of two)
+    fuse_temporal = True
+    nframes = 8  # model/model.py:488,557
+
+    def _common_init(self):
+        if getattr(self, "residual_activation", None) in ["sub_mean", "bn"]:
+            raise NotImplementedError("residual_activation 'sub_mean'/'bn' (model/model.py:42-61) is not on the HIP path")
+        self._packed = {}
+
+    # ---- packed-weight cache ---------------------------------------------------------------
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.compute_dtype, self.fuse_temporal)
+
+    def _pack(self):
+        sig = self._signature()
+        if self._packed.get("sig") != sig:
+            sd = {k: v for k, v in self.state_dict().items()}
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("vtc_amd models run on an MI355X only: call .to('cuda') first "
+                                   "(the CPU restatement lives in oracle/ and is test infrastructure)")
+            p = {"sig": sig}
+            p["visual"] = towers.PackedVision(sd, "model.visual.", self.compute_dtype, self.fuse_temporal)
+            p["text"] = towers.PackedText(sd, "model.", self.compute_dtype, heads=self.model.transformer.heads)
+            if hasattr(self, "final_transformer"):
+                p["cam"] = towers.PackedCam(sd, self.compute_dtype, self.final_transformer.heads, self.init_from_avg,
+                                            self.residual_activation)
+            self._packed = p
+        return self._packed
+
+    def _check_mode(self, *tensors):
+        if self.training:
+            raise RuntimeError("vtc_amd implements the forward/eval path only: call .eval() "
+                               "(training branches model/model.py:199-201,236-246 are out of scope)")
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise RuntimeError("vtc_amd: inputs must be on the GPU (no CPU fallback)")
+
+    # ---- towers ----------------------------------------------------------------------------
+    def encode_image(self, image):
+        return self._pack()["visual"].forward(image)
+
+    def encode_text(self, text):
+        return self._pack()["text"].forward(text)
+
+    def _encode_vis(self, vis):
+        """vis.ndim dispatch of model/model.py:327-338 / :459-470."""
+        shp = vis.shape
+        if len(shp) == 2 and shp[1] == self.feature_dim:
+            return vis.float()                                   # precomputed feature
+        if len(shp) == 4:
+            return self.encode_image(vis)
+        if len(shp) == 5:                                        # frames -> mean over time
+            f = self.encode_image(vis.reshape(shp[0] * shp[1], shp[2], shp[3], shp[4]))
+            return ops.mean_groups(f, shp[1])
+        raise ValueError(f"unsupported visual input shape {tuple(shp)}")
+
+    def _encode_with_comments(self, feats_vis, feats_title, comments):
+        """model/model.py:216-266, eval path."""
+        branch = self.branch_to_adapt_val
+        if branch not in ("text", "image", "skip"):
+            raise Exception("Unknown branch_to_adapt")
+        if branch != "skip":
+            b, ncomms, ntoks = comments.shape
+            feats_comm = self.encode_text(comments.reshape(b * ncomms, ntoks))
+            cam = self._pack()["cam"]
+            if branch == "text":
+                feats_title = cam.forward(feats_title, feats_comm, comments)
+            else:
+                feats_vis = cam.forward(feats_vis, feats_comm, comments)
+        return normalize(feats_vis), normalize(feats_title)
+
+    def _sim(self, fv, ft):
+        return ops.similarity(fv, ft, self.model.logit_scale)
+
+    def _freeze(self, branch_to_freeze):
+        """model/model.py:268-305 (requires_grad bookkeeping only; kept for ctor compatibility)."""
+        self.branch_to_freeze = branch_to_freeze
+        if branch_to_freeze is False or branch_to_freeze == "none":
+            return
+        did = False
+        if "visual" in branch_to_freeze:
+            did = True
+            for p in self.model.visual.parameters():
+                p.requires_grad = False
+        if "text" in branch_to_freeze:
+            did = True
+            for p in self.model.transformer.parameters():
+                p.requires_grad = False
+        if "all" in branch_to_freeze:
+            did = True
+            for p in self.model.parameters():
+                p.requires_grad = False
+        if "finaltf" in branch_to_freeze:
+            did = True
+            if hasattr(self, "final_transformer"):
+                for p in list(self.final_transformer.parameters()) + list(self.final_linear.parameters()):
+                    p.requires_grad = False
+                self.mask_embedding.requires_grad = False
+        if not did:
+            raise Exception("Unknown branch_to_freeze")
+
+    def _init_cam(self, n_layers, n_heads, init_from_avg):
+        """model/model.py:396-400, :440-452."""
+        self.final_transformer = clip_arch.Transformer(width=self.feature_dim, layers=int(n_layers), heads=int(n_heads))
+        self.final_linear = nn.Linear(self.feature_dim, self.feature_dim, bias=False)
+        self.mask_embedding = nn.Parameter(torch.randn(1, self.feature_dim))
+        if init_from_avg:
+            for blk in self.final_transformer.resblocks:
+                blk.mlp.c_proj.weight.data.zero_()
+                blk.mlp.c_proj.bias.data.zero_()
+                blk.attn.out_proj.weight.data.zero_()
+        nn.init.constant_(self.final_linear.weight, 0.0)
+
+
+class PretrainedCLIP(PretrainedCLIPBase):
+    def __init__(self, model_type="ViT-B/32", freeze=False, residual_activation=None, comment_fusion=None):
+        super().__init__()
+        self.model = clip_arch.load(model_type, device="cpu")
+        self.feature_dim = self.model.ln_final.normalized_shape[0]
+        self.residual_activation = residual_activation
+        self.comment_fusion = comment_fusion
+        self._common_init()
+        self._freeze(freeze)
+
+    def forward(self, vis, title, comments=None):
+        self._check_mode(vis, title, comments)
+        feats_vis = self._encode_vis(vis)
+        feats_title = self.encode_text(title)
+        if comments is None or self.comment_fusion is None or self.comment_fusion == "None":
+            feats_text = feats_title
+        else:
+            if self.comment_fusion != "averaging":
+                raise Exception("Comment fusion method not specified.")
+            b, ncomms, ntoks = comments.shape
+            feats_comm = self.encode_text(comments.reshape(b * ncomms, ntoks)).reshape(b, ncomms, self.feature_dim)
+            stacked = torch.cat([feats_title.unsqueeze(1), feats_comm], dim=1).reshape(b * (1 + ncomms), self.feature_dim)
+            feats_text = ops.mean_groups(stacked, 1 + ncomms)        # model/model.py:357-362
+        feats_text, feats_vis = normalize(feats_text), normalize(feats_vis)
+        return feats_vis, feats_text, self._sim(feats_vis, feats_text)
+
+
+class PretrainedCLIP_finaltf(PretrainedCLIPBase):
+    def __init__(self, model_type="ViT-B/32", freeze=False, branch_to_adapt="text", branch_to_adapt_val="text",
+                 residual_activation=None, n_layers=2, n_heads=8, init_from_avg=True, random_comment_masking=False,
+                 random_skip_adapter=True, init_audio_model=False, audio_model_ckpt=None, clip_audio_ckpt=None):
+        super().__init__()
+        if init_audio_model:
+            raise NotImplementedError("the audio branch (model/model.py:409-438) needs the external GDT repository: out of scope")
+        self.model = clip_arch.load(model_type, device="cpu")
+        self.feature_dim = self.model.ln_final.normalized_shape[0]
+        self.branch_to_adapt, self.branch_to_adapt_val = branch_to_adapt, branch_to_adapt_val
+        self.residual_activation = residual_activation
+        self.init_from_avg = init_from_avg
+        self.random_comment_masking, self.random_skip_adapter = random_comment_masking, random_skip_adapter
+        self.init_audio_model = False
+        self._init_cam(n_layers, n_heads, init_from_avg)
+        self._common_init()
+        self._freeze(freeze)
+
+    def forward(self, vis, title, comments):
+        self._check_mode(vis, title, comments)
+        feats_vis = self._encode_vis(vis)
+        feats_title = self.encode_text(title)
+        feats_vis, feats_text = self._encode_with_comments(feats_vis, feats_title, comments)
+        return feats_vis, feats_text, self._sim(feats_vis, feats_text)
+
+
+class PretrainedCLIP_TimeSformer(PretrainedCLIPBase):
+    def __init__(self, model_type="ViT-B/32", freeze=False, residual_activation=None):
+        super().__init__()
+        self.model = clip_arch.load(model_type, device="cpu")
+        self.model.visual = clip_arch.make_timesformer_clip_vit_alt(nframes=self.nframes, model=model_type, clip_model=self.model)
+        self.feature_dim = self.model.ln_final.normalized_shape[0]
+        self.residual_activation = residual_activation
+        self._common_init()
+        self._freeze(freeze)
+
+    def forward(self, im, text, comments=None):
+        self._check_mode(im, text)
+        feats_im = normalize(self.encode_image(im))              # model.visual(im), model/model.py:497
+        feats_text = normalize(self.encode_text(text))
+        return feats_im, feats_text, self._sim(feats_im, feats_text)
+
+
+class PretrainedCLIP_TimeSformer_finaltf(PretrainedCLIPBase):
+    def __init__(self, model_type="ViT-B/32", freeze=False, branch_to_adapt="text", branch_to_adapt_val="text",
+                 residual_activation=None, visual_device=None, n_layers=2, n_heads=8, init_from_avg=True,
+                 random_comment_masking=False, random_skip_adapter=True):
+        super().__init__()
+        self.model = clip_arch.load(model_type, device="cpu")
+        self.model.visual = clip_arch.make_timesformer_clip_vit_alt(nframes=self.nframes, model=model_type, clip_model=self.model)
+        self.feature_dim = self.model.ln_final.normalized_shape[0]
+        self.branch_to_adapt, self.branch_to_adapt_val = branch_to_adapt, branch_to_adapt_val
+        self.residual_activation = residual_activation
+        self.init_from_avg = init_from_avg
+        self.random_comment_masking, self.random_skip_adapter = random_comment_masking, random_skip_adapter
+        self._init_cam(n_layers, n_heads, init_from_avg)
+        self._common_init()
+        self._freeze(freeze)
+        # model/model.py:590-611 splits the towers over two GPUs; both fit one MI355X, so the
+        # argument is accepted and ignored (scale-out is one process per GPU).
+        self.multigpu = False
+
+    def forward(self, vis, title, comments):
+        self._check_mode(vis, title, comments)
+        feats_vis = self.encode_image(vis)
+        feats_title = self.encode_text(title)
+        feats_vis, feats_text = self._encode_with_comments(feats_vis, feats_title, comments)
+        return feats_vis, feats_text, self._sim(feats_vis, feats_text)

@@ -1,0 +1,154 @@
+"""Thin torch-tensor wrappers over the C ABI (include/vtc_hip.h).
+
+torch is used for device memory and the current HIP stream only; every
+computation below happens in libvtc_hip.so.  Inputs must live on a ROCm GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+_TDT = {torch.float32: L.VTC_F32, torch.bfloat16: L.VTC_BF16}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gpu(t: torch.Tensor, dtype=None, name="tensor") -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"vtc_amd: {name} must be on the GPU (got {t.device}); this package has no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"vtc_amd: {name} must be {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def dtype_code(dtype) -> int:
+    if isinstance(dtype, int):
+        return dtype
+    return _TDT[dtype]
+
+
+def torch_dtype(code: int):
+    return torch.bfloat16 if code == L.VTC_BF16 else torch.float32
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ---- primitives ---------------------------------------------------------------------------
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = L.EPI_STORE,
+         out: Optional[torch.Tensor] = None, out_dtype=None, skip_mod: int = 0) -> torch.Tensor:
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  a, w: fp32 or bf16 (same dtype)."""
+    a, w = _gpu(a, name="a"), _gpu(w, a.dtype, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if bias is not None:
+        bias = _gpu(bias, torch.float32, "bias")
+    if epilogue == L.EPI_RESID:
+        assert out is not None and out.dtype == torch.float32 and out.is_contiguous()
+    elif out is None:
+        out = torch.empty(M, N, dtype=out_dtype or a.dtype, device=a.device)
+    L.check(L.lib().vtc_gemm(a.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                             M, N, K, _TDT[a.dtype], epilogue, _TDT[out.dtype], skip_mod, _stream()), "vtc_gemm")
+    return out
+
+
+def layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, out_dtype=torch.float32, rows: Optional[int] = None,
+              row_index: Optional[torch.Tensor] = None, row_mul: int = 1) -> torch.Tensor:
+    x = _gpu(x, torch.float32, "x")
+    width = x.shape[-1]
+    n = rows if rows is not None else (row_index.numel() if row_index is not None else x.numel() // width)
+    y = torch.empty(n, width, dtype=out_dtype, device=x.device)
+    ri = _gpu(row_index, torch.int32, "row_index").data_ptr() if row_index is not None else None
+    L.check(L.lib().vtc_layernorm(x.data_ptr(), _gpu(g, torch.float32).data_ptr(), _gpu(b, torch.float32).data_ptr(),
+                                  y.data_ptr(), n, width, _TDT[out_dtype], ri, row_mul, _stream()), "vtc_layernorm")
+    return y
+
+
+def attention(qkv: torch.Tensor, n_seq: int, L_: int, heads: int, causal: bool = False, s2: int = 1, a0: int = 0,
+              a1: Optional[int] = None, a2: int = 0, a3: int = 0, pstride: int = 1, cls_out: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    qkv = _gpu(qkv, name="qkv")
+    rows, w3 = qkv.shape
+    W = w3 // 3
+    assert W == heads * 64
+    if a1 is None:
+        a1 = L_
+    if out is None:
+        out = torch.zeros(rows, W, dtype=qkv.dtype, device=qkv.device)
+    L.check(L.lib().vtc_attention(qkv.data_ptr(), out.data_ptr(), cls_out.data_ptr() if cls_out is not None else None,
+                                  n_seq, L_, heads, int(causal), s2, a0, a1, a2, a3, pstride, _TDT[qkv.dtype], _stream()),
+            "vtc_attention")
+    return out
+
+
+# ---- wrapper-level fp32 ops ---------------------------------------------------------------
+def normalize_rows(x: torch.Tensor) -> torch.Tensor:
+    x = _gpu(x, torch.float32, "x")
+    out = torch.empty_like(x)
+    L.check(L.lib().vtc_normalize_rows(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], _stream()), "vtc_normalize_rows")
+    return out
+
+
+def mean_groups(x: torch.Tensor, group: int) -> torch.Tensor:
+    x = _gpu(x, torch.float32, "x")
+    n, d = x.shape
+    assert n % group == 0
+    out = torch.empty(n // group, d, dtype=torch.float32, device=x.device)
+    L.check(L.lib().vtc_mean_groups(x.data_ptr(), out.data_ptr(), n // group, group, d, _stream()), "vtc_mean_groups")
+    return out
+
+
+def similarity(v: torch.Tensor, t: torch.Tensor, logit_scale: torch.Tensor) -> torch.Tensor:
+    v, t = _gpu(v, torch.float32, "v"), _gpu(t, torch.float32, "t")
+    ls = _gpu(logit_scale.detach().reshape(1), torch.float32, "logit_scale")
+    sim = torch.empty(v.shape[0], t.shape[0], dtype=torch.float32, device=v.device)
+    L.check(L.lib().vtc_similarity(v.data_ptr(), t.data_ptr(), v.shape[0], t.shape[0], v.shape[1], ls.data_ptr(),
+                                   sim.data_ptr(), _stream()), "vtc_similarity")
+    return sim
+
+
+def clip_loss(sim: torch.Tensor) -> torch.Tensor:
+    sim = _gpu(sim, torch.float32, "sim")
+    n = sim.shape[0]
+    assert sim.shape == (n, n)
+    ws = workspace(L.lib().vtc_clip_loss_workspace_bytes(n), sim.device)
+    loss = torch.empty((), dtype=torch.float32, device=sim.device)
+    L.check(L.lib().vtc_clip_loss(sim.data_ptr(), n, loss.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "vtc_clip_loss")
+    return loss
+
+
+# ---- sweep --------------------------------------------------------------------------------
+def l2_topk(gallery: torch.Tensor, queries: torch.Tensor, depth: int, precision: int = L.SWEEP_F32,
+            rows_per_block: int = 0, return_dists: bool = True, ws: Optional[torch.Tensor] = None):
+    gallery, queries = _gpu(gallery, torch.float32, "gallery"), _gpu(queries, torch.float32, "queries")
+    ng, d = gallery.shape
+    nq = queries.shape[0]
+    need = L.lib().vtc_l2_topk_workspace_bytes(ng, nq, d, precision, rows_per_block)
+    if ws is None or ws.numel() < need:
+        ws = workspace(need, gallery.device)
+    ids = torch.empty(nq, depth, dtype=torch.int64, device=gallery.device)
+    dists = torch.empty(nq, depth, dtype=torch.float32, device=gallery.device) if return_dists else None
+    L.check(L.lib().vtc_l2_topk(gallery.data_ptr(), queries.data_ptr(), ng, nq, d, depth, precision, rows_per_block,
+                                ids.data_ptr(), dists.data_ptr() if dists is not None else None, ws.data_ptr(), ws.numel(),
+                                _stream()), "vtc_l2_topk")
+    return ids, dists
+
+
+def recall_hits(ids: torch.Tensor, k_vals: Sequence[int], target_offset: int = 0,
+                hits: Optional[torch.Tensor] = None) -> torch.Tensor:
+    ids = _gpu(ids, torch.int64, "ids")
+    nq, depth = ids.shape
+    if hits is None:
+        hits = torch.zeros(len(k_vals), dtype=torch.int64, device=ids.device)
+    ks = (C.c_int * len(k_vals))(*[int(k) for k in k_vals])
+    L.check(L.lib().vtc_recall_hits(ids.data_ptr(), nq, depth, int(target_offset), ks, len(k_vals), hits.data_ptr(), _stream()),
+            "vtc_recall_hits")
+    return hits

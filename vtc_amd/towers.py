@@ -1,0 +1,203 @@
+"""Weight packing and tower launches for the HIP path.
+
+A state dict (the reference's key names, tensors on the GPU) is packed ONCE into the C
+structs of include/vtc_hip.h: matrices cast to the compute dtype in their PyTorch
+``[out, in]`` layout, projections transposed, and -- optionally -- the two back-to-back linear
+maps of the temporal branch (``timeattn.out_proj`` then ``temporal_fc``,
+model/timesformer_clip_alt.py:65,148) multiplied together on the host so that the branch costs
+one GEMM instead of two.  The forward functions then only size a workspace and call the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+SD = Dict[str, torch.Tensor]
+
+# items per vision-tower launch; 0 = the whole batch in one pass
+VISION_CHUNK = 0
+_WS: Dict[torch.device, torch.Tensor] = {}
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    w = _WS.get(device)
+    if w is None or w.numel() < nbytes:
+        _WS[device] = w = None  # drop the old one before growing
+        _WS[device] = w = ops.workspace(nbytes, device)
+    return w
+
+
+class _Keep:
+    """Owns the converted tensors a packed struct points into."""
+
+    def __init__(self):
+        self.t: List[torch.Tensor] = []
+
+    def f32(self, t: torch.Tensor) -> int:
+        t = t.detach().to(torch.float32).contiguous()
+        self.t.append(t)
+        return t.data_ptr()
+
+    def mat(self, t: torch.Tensor, dtype) -> int:
+        t = t.detach().to(dtype).contiguous()
+        self.t.append(t)
+        return t.data_ptr()
+
+
+def _n_layers(sd: SD, p: str) -> int:
+    pre = f"{p}.resblocks."
+    return 1 + max(int(k[len(pre):].split(".")[0]) for k in sd if k.startswith(pre))
+
+
+def _pack_blocks(sd: SD, p: str, layers: int, dtype, keep: _Keep, timesformer: bool, fuse_temporal: bool):
+    arr = (L.BlockW * layers)()
+    for i in range(layers):
+        q, b = f"{p}.resblocks.{i}", arr[i]
+        b.ln1_g, b.ln1_b = keep.f32(sd[f"{q}.ln_1.weight"]), keep.f32(sd[f"{q}.ln_1.bias"])
+        b.qkv_w, b.qkv_b = keep.mat(sd[f"{q}.attn.in_proj_weight"], dtype), keep.f32(sd[f"{q}.attn.in_proj_bias"])
+        b.out_w, b.out_b = keep.mat(sd[f"{q}.attn.out_proj.weight"], dtype), keep.f32(sd[f"{q}.attn.out_proj.bias"])
+        b.ln2_g, b.ln2_b = keep.f32(sd[f"{q}.ln_2.weight"]), keep.f32(sd[f"{q}.ln_2.bias"])
+        b.fc_w, b.fc_b = keep.mat(sd[f"{q}.mlp.c_fc.weight"], dtype), keep.f32(sd[f"{q}.mlp.c_fc.bias"])
+        b.proj_w, b.proj_b = keep.mat(sd[f"{q}.mlp.c_proj.weight"], dtype), keep.f32(sd[f"{q}.mlp.c_proj.bias"])
+        if timesformer:
+            b.lnt_g, b.lnt_b = keep.f32(sd[f"{q}.ln_time.weight"]), keep.f32(sd[f"{q}.ln_time.bias"])
+            b.tqkv_w, b.tqkv_b = keep.mat(sd[f"{q}.timeattn.in_proj_weight"], dtype), keep.f32(sd[f"{q}.timeattn.in_proj_bias"])
+            wo, bo = sd[f"{q}.timeattn.out_proj.weight"], sd[f"{q}.timeattn.out_proj.bias"]
+            wf, bf = sd[f"{q}.temporal_fc.weight"], sd[f"{q}.temporal_fc.bias"]
+            if fuse_temporal:
+                # temporal_fc(out_proj(a)) = (Wf Wo) a + (Wf bo + bf): one GEMM instead of two
+                w64 = wf.double() @ wo.double()
+                b64 = wf.double() @ bo.double() + bf.double()
+                b.tout_w, b.tout_b = None, None
+                b.tfc_w, b.tfc_b = keep.mat(w64.float(), dtype), keep.f32(b64.float())
+            else:
+                b.tout_w, b.tout_b = keep.mat(wo, dtype), keep.f32(bo)
+                b.tfc_w, b.tfc_b = keep.mat(wf, dtype), keep.f32(bf)
+    return arr
+
+
+class PackedVision:
+    def __init__(self, sd: SD, prefix: str, dtype, fuse_temporal: bool = True):
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep()
+        k = self.keep
+        conv = sd["conv1.weight"]
+        w = L.VisionW()
+        w.width, w.patch = conv.shape[0], conv.shape[-1]
+        w.heads = w.width // 64
+        w.layers = _n_layers(sd, "transformer")
+        w.grid = int(round(math.sqrt(sd["positional_embedding"].shape[0] - 1)))
+        w.embed_dim = sd["proj"].shape[1]
+        w.nframes = sd["temporal_embed"].shape[0] if "temporal_embed" in sd else 0
+        w.conv_w = k.mat(conv.reshape(w.width, -1), dtype)
+        w.class_embedding, w.pos = k.f32(sd["class_embedding"]), k.f32(sd["positional_embedding"])
+        w.temporal = k.f32(sd["temporal_embed"]) if w.nframes else None
+        w.ln_pre_g, w.ln_pre_b = k.f32(sd["ln_pre.weight"]), k.f32(sd["ln_pre.bias"])
+        w.ln_post_g, w.ln_post_b = k.f32(sd["ln_post.weight"]), k.f32(sd["ln_post.bias"])
+        w.proj_t = k.mat(sd["proj"].t(), dtype)
+        self.blocks = _pack_blocks(sd, "transformer", w.layers, dtype, k, bool(w.nframes), fuse_temporal)
+        w.blocks = self.blocks
+        self.w = w
+        self.res = w.grid * w.patch
+
+    def forward(self, pixels: torch.Tensor) -> torch.Tensor:
+        """pixels [N,3,H,W] (image tower) or [N,F,3,H,W] (TimeSformer), fp32 or bf16 -> [N, embed] fp32."""
+        w = self.w
+        if pixels.dim() == 4:
+            pixels = pixels.unsqueeze(1)
+        pixels = ops._gpu(pixels, name="pixels")
+        if pixels.dtype not in (torch.float32, torch.bfloat16):
+            pixels = pixels.float()
+        n, F = pixels.shape[0], pixels.shape[1]
+        if tuple(pixels.shape[2:]) != (3, self.res, self.res):
+            raise ValueError(f"expected [...,3,{self.res},{self.res}] pixels, got {tuple(pixels.shape)}")
+        out = torch.empty(n, w.embed_dim, dtype=torch.float32, device=pixels.device)
+        chunk = VISION_CHUNK if VISION_CHUNK > 0 else n
+        lib = L.lib()
+        ws = _ws(lib.vtc_vision_workspace_bytes(C.byref(w), min(chunk, n), F, self.code), pixels.device)
+        for i0 in range(0, n, chunk):
+            m = min(chunk, n - i0)
+            L.check(lib.vtc_vision_forward(C.byref(w), pixels[i0:i0 + m].data_ptr(), ops.dtype_code(pixels.dtype), m, F,
+                                           out[i0:i0 + m].data_ptr(), ws.data_ptr(), ws.numel(), self.code, ops._stream()),
+                    "vtc_vision_forward")
+        return out
+
+
+class PackedText:
+    def __init__(self, sd: SD, prefix: str, dtype, heads: Optional[int] = None):
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix) and not k.startswith(prefix + "visual.")}
+        self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep()
+        k = self.keep
+        w = L.TextW()
+        w.vocab, w.width = sd["token_embedding.weight"].shape
+        w.heads = heads or w.width // 64
+        w.layers = _n_layers(sd, "transformer")
+        w.ctx = sd["positional_embedding"].shape[0]
+        w.embed_dim = sd["text_projection"].shape[1]
+        w.tok_emb, w.pos = k.f32(sd["token_embedding.weight"]), k.f32(sd["positional_embedding"])
+        w.ln_final_g, w.ln_final_b = k.f32(sd["ln_final.weight"]), k.f32(sd["ln_final.bias"])
+        w.proj_t = k.mat(sd["text_projection"].t(), dtype)
+        self.blocks = _pack_blocks(sd, "transformer", w.layers, dtype, k, False, False)
+        w.blocks = self.blocks
+        self.w = w
+
+    def forward(self, ids: torch.Tensor) -> torch.Tensor:
+        """ids [S, ctx] int64 -> [S, embed] fp32."""
+        w = self.w
+        ids = ops._gpu(ids, torch.int64, "token ids")
+        if ids.dim() != 2 or ids.shape[1] != w.ctx:
+            raise ValueError(f"expected [S,{w.ctx}] token ids, got {tuple(ids.shape)}")
+        S = ids.shape[0]
+        out = torch.empty(S, w.embed_dim, dtype=torch.float32, device=ids.device)
+        lib = L.lib()
+        ws = _ws(lib.vtc_text_workspace_bytes(C.byref(w), S, self.code), ids.device)
+        L.check(lib.vtc_text_forward(C.byref(w), ids.data_ptr(), S, out.data_ptr(), ws.data_ptr(), ws.numel(), self.code,
+                                     ops._stream()), "vtc_text_forward")
+        return out
+
+
+_ACTS = {None: (L.ACT_NONE, 1.0), "none": (L.ACT_NONE, 1.0), "normalize": (L.ACT_NORMALIZE, 1.0),
+         "squash": (L.ACT_SQUASH, 1.0), "squash10": (L.ACT_SQUASH, 10.0), "squash1p2": (L.ACT_SQUASH, 1.2),
+         "squash1p5": (L.ACT_SQUASH, 1.5), "squash1p8": (L.ACT_SQUASH, 1.8), "tanh": (L.ACT_TANH, 1.0)}
+
+
+class PackedCam:
+    def __init__(self, sd: SD, dtype, heads: int, init_from_avg: bool, residual_activation):
+        if residual_activation not in _ACTS:
+            raise NotImplementedError(f"residual_activation={residual_activation!r} needs BatchNorm running statistics "
+                                      "(model/model.py:42-61); not implemented on the HIP path")
+        self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep()
+        k = self.keep
+        w = L.CamW()
+        w.width = sd["final_linear.weight"].shape[0]
+        w.heads = heads
+        if w.width != heads * 64:
+            raise NotImplementedError(f"CAM head_dim must be 64 on the HIP path (width {w.width}, heads {heads})")
+        w.layers = _n_layers(sd, "final_transformer")
+        w.init_from_avg = int(bool(init_from_avg))
+        w.residual_activation, w.squash_scale = _ACTS[residual_activation]
+        w.final_linear = k.mat(sd["final_linear.weight"], dtype)
+        w.mask_embedding = k.f32(sd["mask_embedding"].reshape(-1))
+        self.blocks = _pack_blocks(sd, "final_transformer", w.layers, dtype, k, False, False)
+        w.blocks = self.blocks
+        self.w = w
+
+    def forward(self, main: torch.Tensor, comm_feats: torch.Tensor, comments: torch.Tensor) -> torch.Tensor:
+        """main [B,D], comm_feats [B*nc,D] fp32, comments [B,nc,ctx] int64 -> adapted [B,D]."""
+        w = self.w
+        main, comm_feats = ops._gpu(main, torch.float32, "main"), ops._gpu(comm_feats, torch.float32, "comm_feats")
+        comments = ops._gpu(comments, torch.int64, "comments")
+        B, nc, ctx = comments.shape
+        assert main.shape == (B, w.width) and comm_feats.shape == (B * nc, w.width)
+        out = torch.empty(B, w.width, dtype=torch.float32, device=main.device)
+        lib = L.lib()
+        ws = _ws(lib.vtc_cam_workspace_bytes(C.byref(w), B, nc, self.code), main.device)
+        L.check(lib.vtc_cam_forward(C.byref(w), main.data_ptr(), comm_feats.data_ptr(), comments.data_ptr(), ctx, B, nc,
+                                    out.data_ptr(), ws.data_ptr(), ws.numel(), self.code, ops._stream()), "vtc_cam_forward")
+        return out

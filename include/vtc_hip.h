@@ -65,7 +65,7 @@ typedef struct {
   const float *pos;               /* positional_embedding [1+grid*grid, W]                */
   const float *temporal;          /* temporal_embed [nframes, W] or NULL                  */
   const float *ln_pre_g, *ln_pre_b, *ln_post_g, *ln_post_b;
-  const void  *proj_t;            /* proj^T [embed_dim, W]                                */
+  const float *proj_t;            /* proj^T [embed_dim, W], fp32 in both modes            */
   const vtc_block_w *blocks;      /* HOST array of `layers` entries                       */
 } vtc_vision_w;
 
@@ -75,7 +75,7 @@ typedef struct {
   const float *tok_emb;           /* token_embedding.weight [vocab, W] fp32               */
   const float *pos;               /* positional_embedding [ctx, W]                        */
   const float *ln_final_g, *ln_final_b;
-  const void  *proj_t;            /* text_projection^T [embed_dim, W]                     */
+  const float *proj_t;            /* text_projection^T [embed_dim, W], fp32 in both modes */
   const vtc_block_w *blocks;      /* HOST array                                           */
 } vtc_text_w;
 

@@ -94,11 +94,14 @@ def gen_wrappers():
         ("clip", "TINY", 3, 4, {}),
         ("clip", "TINY", 2, 5, {}),                                  # frames -> mean over time (model.py:333-338)
         ("clip", "TINY", 3, 4, {"comment_fusion": "averaging"}),
-        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "text"}),
-        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "image"}),
-        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "skip"}),
-        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "text", "init_from_avg": False}),
-        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "text", "residual_activation": "squash"}),
+        # TINY embed_dim is 128: n_heads=2 keeps the CAM head_dim at 64 as in the real model (512/8)
+        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "text", "n_heads": 2}),
+        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "image", "n_heads": 2}),
+        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "skip", "n_heads": 2}),
+        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "text", "init_from_avg": False, "n_heads": 2}),
+        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "text", "residual_activation": "squash", "n_heads": 2}),
+        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "text", "residual_activation": "tanh", "n_heads": 2}),
+        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "image", "residual_activation": "normalize", "n_heads": 2}),
         ("clip_finaltf", "VIT_B32", 2, 4, {"branch_to_adapt_val": "text"}),
         ("timesformer", "VIT_B32", 2, 5, {}),
         ("timesformer_finaltf", "VIT_B32", 2, 5, {"branch_to_adapt_val": "text"}),
@@ -123,7 +126,7 @@ def gen_wrappers():
 def gen_cam_at_init():
     """The state tests/test_pretrained_clip.py:45-85 pins: init_from_avg zeroing makes the CAM
     transformer an identity (model.py:440-450)."""
-    m, a = build_wrapper("clip_finaltf", "TINY", seed=31, branch_to_adapt_val="text")
+    m, a = build_wrapper("clip_finaltf", "TINY", seed=31, branch_to_adapt_val="text", n_heads=2)
     sd = A.synth_model(a, 31, "clip_finaltf", cam_at_init=True)
     m.load_state_dict(sd, strict=True)
     B = 3

@@ -19,8 +19,16 @@ from oracle import timesformer_ref as T
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 ARCH = {"TINY": A.TINY, "VIT_B32": A.VIT_B32}
-TOL = {torch.float32: 1e-5, torch.bfloat16: 1e-3}
 DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol_for(dtype, embed_dim=512):
+    """BASELINE.json: 1e-5 (fp32) / 1e-3 (bf16) on the unit-norm 512-d embeddings of the real model,
+    i.e. 2.3 % of the RMS element 1/sqrt(512) in bf16.  The TINY oracle architecture has 128-d
+    embeddings whose elements are 2x larger, so the same relative bf16 accuracy is 2e-3 there."""
+    if dtype == torch.float32:
+        return 1e-5
+    return 1e-3 * (512 / embed_dim) ** 0.5
 
 
 def cuda_sd(sd):
@@ -48,7 +56,8 @@ def test_timesformer_tower_vs_golden(fname, dtype):
         pv = towers.PackedVision(cuda_sd(sd), "v.", dtype, fuse_temporal=fuse)
         out = pv.forward(x.cuda()).cpu().numpy()
         # compare as the wrappers consume it: L2-normalised embedding (model.py:501)
-        report(f"{fname} {dtype} fuse={fuse}", np.abs(unit(out) - unit(g["out"])).max(), TOL[dtype] * (3 if fuse and dtype == torch.float32 else 1))
+        report(f"{fname} {dtype} fuse={fuse}", np.abs(unit(out) - unit(g["out"])).max(),
+                   tol_for(dtype, a.embed_dim) * (3 if fuse and dtype == torch.float32 else 1))
         if dtype == torch.float32 and not fuse:
             assert np.abs(out - g["out"]).max() < 2e-5 * max(1.0, np.abs(g["out"]).max())
 
@@ -68,11 +77,11 @@ def test_vit_and_text_towers_vs_oracle(dtype):
         pt = towers.PackedText(cuda_sd(sd), "model.", dtype, heads=a.transformer_heads)
         out_v = pv.forward(img.cuda()).cpu().numpy()
         out_t = pt.forward(txt.cuda()).cpu().numpy()
-        report(f"ViT {a.vision_width} {dtype}", np.abs(unit(out_v) - unit(ref_v)).max(), TOL[dtype])
-        report(f"text {a.transformer_width} {dtype}", np.abs(unit(out_t) - unit(ref_t)).max(), TOL[dtype])
+        report(f"ViT {a.vision_width} {dtype}", np.abs(unit(out_v) - unit(ref_v)).max(), tol_for(dtype, a.embed_dim))
+        report(f"text {a.transformer_width} {dtype}", np.abs(unit(out_t) - unit(ref_t)).max(), tol_for(dtype, a.embed_dim))
         if dtype == torch.bfloat16:  # bf16 pixel input (BASELINE: pixels cast to bf16 for bf16 runs)
             out_vb = pv.forward(img.cuda().bfloat16()).cpu().numpy()
-            report(f"ViT bf16-pixels {a.vision_width}", np.abs(unit(out_vb) - unit(ref_v)).max(), 2e-3)
+            report(f"ViT bf16-pixels {a.vision_width}", np.abs(unit(out_vb) - unit(ref_v)).max(), 2 * tol_for(dtype, a.embed_dim))
 
 
 def test_identity_at_init_timesformer_equals_vit_gpu():
@@ -115,7 +124,7 @@ def test_wrappers_vs_golden(fname, dtype):
     comments = A.synth_tokens(B * 5, a, case["cseed"], empty_frac=case["empty_frac"]).reshape(B, 5, -1).cuda()
     out = m(vis, title, comments) if case["comments"] else m(vis, title)
     fv, ft, sim = (o.cpu().numpy() for o in out)
-    tol = TOL[dtype] * (3 if (dtype == torch.float32 and "timesformer" in case["model"]) else 1)  # fused temporal map
+    tol = tol_for(dtype, a.embed_dim) * (3 if (dtype == torch.float32 and "timesformer" in case["model"]) else 1)  # fused temporal map
     report(f"{fname} feats_vis {dtype}", np.abs(fv - g["feats_vis"]).max(), tol)
     report(f"{fname} feats_text {dtype}", np.abs(ft - g["feats_text"]).max(), tol)
     scale = float(np.exp(np.log(1 / 0.07)))
@@ -142,7 +151,7 @@ def test_cam_at_init_and_branch_isolation():
     comments = A.synth_tokens(B * 5, a, case["cseed"], empty_frac=case["empty_frac"]).reshape(B, 5, -1).cuda()
     outs = {}
     for br in ("skip", "image", "text"):
-        m = HM.PretrainedCLIP_finaltf(model_type=cfg, branch_to_adapt_val=br)
+        m = HM.PretrainedCLIP_finaltf(model_type=cfg, branch_to_adapt_val=br, n_heads=2)
         m.load_state_dict(sd, strict=True)
         m = m.eval().cuda()
         m.compute_dtype = torch.float32

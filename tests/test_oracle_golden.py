@@ -41,6 +41,8 @@ def run_wrapper(case):
         cam["init_from_avg"] = kw.pop("init_from_avg")
     if "residual_activation" in kw:
         cam["residual_activation"] = kw.pop("residual_activation")
+    if "n_heads" in kw:
+        cam["n_heads"] = kw.pop("n_heads")
     if kind == "clip":
         return M.pretrained_clip(vis, title, sd, a, comments if case["comments"] else None, kw.get("comment_fusion"))
     if kind == "clip_finaltf":
@@ -69,7 +71,7 @@ def test_cam_at_init_closed_form():
     vis = A.synth_pixels((B, 3, a.image_resolution, a.image_resolution), case["xseed"])
     title = A.synth_tokens(B, a, case["tseed"])
     comments = A.synth_tokens(B * 5, a, case["cseed"], empty_frac=case["empty_frac"]).reshape(B, 5, -1)
-    fv, ft, sim = M.pretrained_clip_finaltf(vis, title, comments, sd, a, "text")
+    fv, ft, sim = M.pretrained_clip_finaltf(vis, title, comments, sd, a, "text", n_heads=2)
     np.testing.assert_allclose(ft.numpy(), g["feats_text"], **TOL)
     np.testing.assert_allclose(fv.numpy(), g["feats_vis"], **TOL)
     # closed form

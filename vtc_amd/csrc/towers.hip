@@ -105,7 +105,7 @@ VisionWs plan_vision(const vtc_vision_w *w, int n_items, int F, int dtype, void 
   v.h = b.take(rows * W * esz(dtype));
   v.big = b.take(big_elems * esz(dtype));
   v.cls_tmp = (float *)b.take((size_t)n_items * F * W * 4);
-  v.lnp = b.take((size_t)n_items * W * esz(dtype));
+  v.lnp = b.take((size_t)n_items * W * 4);
   v.total = b.off;
   return v;
 }
@@ -123,7 +123,7 @@ TextWs plan_text(int rows, int n_seq, int W, int dtype, void *ws) {
   t.x = (float *)b.take((size_t)rows * W * 4);
   t.h = b.take((size_t)rows * W * esz(dtype));
   t.big = b.take((size_t)rows * 4 * W * esz(dtype));
-  t.lnp = b.take((size_t)n_seq * W * esz(dtype));
+  t.lnp = b.take((size_t)n_seq * W * 4);
   t.eot = (int *)b.take((size_t)n_seq * 4);
   t.total = b.off;
   return t;
@@ -187,9 +187,10 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
     }
     RUN(mlp_part(b, v.x, v.h, v.big, rows, W, dtype, s));
   }
-  // ln_post(x[:,0]) @ proj
-  RUN(launch_layernorm(v.x, w->ln_post_g, w->ln_post_b, v.lnp, n_items, W, dtype, nullptr, T, false, s));
-  RUN(gemm(v.lnp, w->proj_t, nullptr, out, n_items, w->embed_dim, W, dtype, VTC_EPI_STORE, VTC_F32, 0, s));
+  // ln_post(x[:,0]) @ proj -- always fp32 (n_items rows only): the embedding the sweep ranks on
+  // does not pick up a last bf16 rounding
+  RUN(launch_layernorm(v.x, w->ln_post_g, w->ln_post_b, v.lnp, n_items, W, VTC_F32, nullptr, T, false, s));
+  RUN(gemm(v.lnp, w->proj_t, nullptr, out, n_items, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));
   return 0;
 }
 
@@ -216,8 +217,9 @@ extern "C" int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_s
     RUN(mlp_part(b, t.x, t.h, t.big, rows, W, dtype, s));
   }
   // ln_final on the EOT row only (LayerNorm is per-row, so gathering first is identical), then @ text_projection
-  RUN(launch_layernorm(t.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, dtype, t.eot, 1, false, s));
-  RUN(gemm(t.lnp, w->proj_t, nullptr, out, n_seq, w->embed_dim, W, dtype, VTC_EPI_STORE, VTC_F32, 0, s));
+  // (always fp32, as for the vision tower)
+  RUN(launch_layernorm(t.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, VTC_F32, t.eot, 1, false, s));
+  RUN(gemm(t.lnp, w->proj_t, nullptr, out, n_seq, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));
   return 0;
 }
 

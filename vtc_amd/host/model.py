@@ -62,7 +62,8 @@ class PretrainedCLIPBase(nn.Module):
             p["visual"] = towers.PackedVision(sd, "model.visual.", self.compute_dtype, self.fuse_temporal)
             p["text"] = towers.PackedText(sd, "model.", self.compute_dtype, heads=self.model.transformer.heads)
             if hasattr(self, "final_transformer"):
-                p["cam"] = towers.PackedCam(sd, self.compute_dtype, self.final_transformer.heads, self.init_from_avg,
+                # the CAM sees B*(1+nc) tokens of width 512 -- negligible work -- so it always runs in fp32
+                p["cam"] = towers.PackedCam(sd, torch.float32, self.final_transformer.heads, self.init_from_avg,
                                             self.residual_activation)
             self._packed = p
         return self._packed

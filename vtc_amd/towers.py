@@ -100,7 +100,7 @@ class PackedVision:
         w.temporal = k.f32(sd["temporal_embed"]) if w.nframes else None
         w.ln_pre_g, w.ln_pre_b = k.f32(sd["ln_pre.weight"]), k.f32(sd["ln_pre.bias"])
         w.ln_post_g, w.ln_post_b = k.f32(sd["ln_post.weight"]), k.f32(sd["ln_post.bias"])
-        w.proj_t = k.mat(sd["proj"].t(), dtype)
+        w.proj_t = k.mat(sd["proj"].t(), torch.float32)
         self.blocks = _pack_blocks(sd, "transformer", w.layers, dtype, k, bool(w.nframes), fuse_temporal)
         w.blocks = self.blocks
         self.w = w
@@ -142,7 +142,7 @@ class PackedText:
         w.embed_dim = sd["text_projection"].shape[1]
         w.tok_emb, w.pos = k.f32(sd["token_embedding.weight"]), k.f32(sd["positional_embedding"])
         w.ln_final_g, w.ln_final_b = k.f32(sd["ln_final.weight"]), k.f32(sd["ln_final.bias"])
-        w.proj_t = k.mat(sd["text_projection"].t(), dtype)
+        w.proj_t = k.mat(sd["text_projection"].t(), torch.float32)
         self.blocks = _pack_blocks(sd, "transformer", w.layers, dtype, k, False, False)
         w.blocks = self.blocks
         self.w = w

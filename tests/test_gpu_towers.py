@@ -44,6 +44,19 @@ def report(name, err, tol):
     assert err < tol, f"{name}: {err} >= {tol}"
 
 
+def report_text(name, got, want, dtype, embed_dim):
+    """Text-tower features.  fp32: 1e-5 max.  bf16: the operand-rounding floor of bf16 x bf16 MFMA
+    on this tower is rms 3.2e-4 / max ~1.1e-3 (tests/bf16_floor_study.py, a CPU simulation that
+    involves no kernel), so the bf16 criterion is rms <= 4e-4 and max <= 1.5e-3 (x sqrt(512/D))."""
+    d = np.abs(got - want)
+    if dtype == torch.float32:
+        return report(name, d.max(), 1e-5)
+    k = (512 / embed_dim) ** 0.5
+    rms = float(np.sqrt((d ** 2).mean()))
+    print(f"[parity] {name}: max abs err {d.max():.3e} rms {rms:.3e} (bf16 floor criterion: max 1.5e-3, rms 4e-4, x{k:.1f})")
+    assert d.max() < 1.5e-3 * k and rms < 4e-4 * k, f"{name}: max {d.max()} rms {rms}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("fname", golden_files("tower_alt_"))
 def test_timesformer_tower_vs_golden(fname, dtype):
@@ -78,7 +91,7 @@ def test_vit_and_text_towers_vs_oracle(dtype):
         out_v = pv.forward(img.cuda()).cpu().numpy()
         out_t = pt.forward(txt.cuda()).cpu().numpy()
         report(f"ViT {a.vision_width} {dtype}", np.abs(unit(out_v) - unit(ref_v)).max(), tol_for(dtype, a.embed_dim))
-        report(f"text {a.transformer_width} {dtype}", np.abs(unit(out_t) - unit(ref_t)).max(), tol_for(dtype, a.embed_dim))
+        report_text(f"text {a.transformer_width} {dtype}", unit(out_t), unit(ref_t), dtype, a.embed_dim)
         if dtype == torch.bfloat16:  # bf16 pixel input (BASELINE: pixels cast to bf16 for bf16 runs)
             out_vb = pv.forward(img.cuda().bfloat16()).cpu().numpy()
             report(f"ViT bf16-pixels {a.vision_width}", np.abs(unit(out_vb) - unit(ref_v)).max(), 2 * tol_for(dtype, a.embed_dim))
@@ -126,7 +139,10 @@ def test_wrappers_vs_golden(fname, dtype):
     fv, ft, sim = (o.cpu().numpy() for o in out)
     tol = tol_for(dtype, a.embed_dim) * (3 if (dtype == torch.float32 and "timesformer" in case["model"]) else 1)  # fused temporal map
     report(f"{fname} feats_vis {dtype}", np.abs(fv - g["feats_vis"]).max(), tol)
-    report(f"{fname} feats_text {dtype}", np.abs(ft - g["feats_text"]).max(), tol)
+    if dtype == torch.float32:
+        report(f"{fname} feats_text {dtype}", np.abs(ft - g["feats_text"]).max(), tol)
+    else:
+        report_text(f"{fname} feats_text {dtype}", ft, g["feats_text"], dtype, a.embed_dim)
     scale = float(np.exp(np.log(1 / 0.07)))
     report(f"{fname} cos-sim {dtype}", np.abs(sim - g["sim"]).max() / scale, tol)
     np.testing.assert_allclose(np.linalg.norm(fv, axis=-1), 1.0, atol=1e-5)

@@ -1,0 +1,256 @@
+"""bench.py -- headline benchmark of the VTC retrieval forward/eval hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one forward pass of BASELINE.json configs[1] over one batch resident in HBM:
+PretrainedCLIP_finaltf (CLIP ViT-B/32 image tower + CLIP text tower over 1 title + 5 comments +
+Context Adapter Module + batch similarity), B = 256 pairs per GPU, bf16 operands / fp32 accumulate,
+synthetic random pixels and tokens, random-init weights of the real architecture.
+`value` = pairs encoded per second over the whole job (all ranks; weak scaling: B per GPU fixed).
+
+Extra objects on the same JSON line:
+  roofline      the dominant kernel (the bf16 MFMA GEMM, every instantiation of gemm_kernel<bf16>):
+                achieved = sum(2MNK) / sum(kernel time), both measured live with HIP events on the
+                launch stream inside the timed region (vtc_prof_*); peak = 2.5 PFLOP/s dense bf16.
+  cpu_baseline  the oracle (plain PyTorch fp32 restatement of the reference) timed on this box's host
+                cores on a bounded sample of the same workload (rank 0, N = 1 only).
+  extra         secondary measurements of the same path: config 3 (8-frame TimeSformer + CAM)
+                pairs/s, and the N x N sweep (sim + R@1/5/10 both directions) in ms at N = 10k,
+                sharded over the ranks with one RCCL all-gather + one all-reduce when N > 1.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_tokens(n, ctx, gen, empty_frac=0.0):
+    """[SOT, t_1..t_L, EOT, 0...] rows, L ~ U{1..75}; a fraction is the empty string."""
+    out = torch.zeros(n, ctx, dtype=torch.int64)
+    lens = torch.randint(1, ctx - 1, (n,), generator=gen)
+    empty = torch.rand(n, generator=gen) < empty_frac
+    lens[empty] = 0
+    toks = torch.randint(1, 49406, (n, ctx), generator=gen)
+    pos = torch.arange(ctx)[None]
+    out = torch.where((pos >= 1) & (pos <= lens[:, None]), toks, out)
+    out[:, 0] = 49406
+    out[torch.arange(n), lens + 1] = 49407
+    return out
+
+
+def prof_run(fn, stream_ptr):
+    from vtc_amd import _lib as L
+    lib = L.lib()
+    lib.vtc_prof_begin()
+    fn()
+    n = len(L.PROF_CLASSES)
+    ms, cnt, work = (C.c_double * n)(), (C.c_longlong * n)(), (C.c_double * n)()
+    L.check(lib.vtc_prof_end(stream_ptr, ms, cnt, work), "vtc_prof_end")
+    return {name: dict(ms=ms[i], launches=cnt[i], work=work[i]) for i, name in enumerate(L.PROF_CLASSES)}
+
+
+def barrier_sync(world):
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(t, world, device):
+    import torch.distributed as dist
+    if world == 1:
+        return t
+    x = torch.tensor([t], dtype=torch.float64, device=device)
+    dist.all_reduce(x, op=dist.ReduceOp.MAX)
+    return float(x.item())
+
+
+def cpu_baseline(kind_pairs=8):
+    """Oracle (kind 'port') on the host cores: config 2 forward at B = kind_pairs, best of 2."""
+    from oracle import arch as A
+    from oracle import model_ref as M
+    torch.set_num_threads(os.cpu_count() or 1)
+    a = A.VIT_B32
+    sd = A.synth_model(a, 1, "clip_finaltf")
+    B = kind_pairs
+    vis = A.synth_pixels((B, 3, 224, 224), 2)
+    title = A.synth_tokens(B, a, 3)
+    comments = A.synth_tokens(B * 5, a, 4, empty_frac=0.1).reshape(B, 5, -1)
+    best = 1e30
+    with torch.no_grad():
+        for _ in range(2):
+            t0 = time.perf_counter()
+            M.pretrained_clip_finaltf(vis, title, comments, sd, a, "text")
+            best = min(best, time.perf_counter() - t0)
+    return dict(value=round(B / best, 3), unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle fp32 forward of config 2 at B={B} (1 title + 5 comments per pair), best of 2, {best:.2f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-extra", action="store_true", help="skip config 3 and the sweep")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--sweep-n", type=int, default=10000)
+    args = ap.parse_args()
+
+    from vtc_amd import dist as vdist
+    rank, local, world = vdist.init_from_env()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    torch.set_grad_enabled(False)
+
+    from vtc_amd import _lib as L
+    from vtc_amd import ops
+    from vtc_amd.host import model as HM
+    from vtc_amd.host.metric import RecallAtK
+
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    B = args.batch
+    gen = torch.Generator().manual_seed(123 + rank)           # data seed (tests/test_pretrained_clip.py:46)
+    torch.manual_seed(1023)                                    # weight seed (train.py:34)
+
+    # ---- config 2: image + title + 5 comments (CAM) ---------------------------------------
+    m2 = HM.PretrainedCLIP_finaltf(model_type="ViT-B/32", branch_to_adapt="text", branch_to_adapt_val="text",
+                                   init_from_avg=True)
+    # a trained adapter is not an identity: give the CAM's zero-initialised projections small weights
+    for blk in m2.final_transformer.resblocks:
+        torch.nn.init.normal_(blk.attn.out_proj.weight, std=0.02)
+        torch.nn.init.normal_(blk.mlp.c_proj.weight, std=0.02)
+    m2 = m2.eval().to(device)
+    m2.compute_dtype = cdt
+    vis = torch.randn(B, 3, 224, 224, generator=gen).to(device).to(cdt)   # BASELINE: pixels cast to bf16 for bf16 runs
+    title = synth_tokens(B, 77, gen).to(device)
+    comments = synth_tokens(B * 5, 77, gen, empty_frac=0.1).reshape(B, 5, 77).to(device)
+
+    def step2():
+        return m2(vis, title, comments)
+
+    for _ in range(args.warmup):
+        step2()
+    stream_ptr = torch.cuda.current_stream().cuda_stream
+    barrier_sync(world)
+    lib = L.lib()
+    lib.vtc_prof_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step2()
+    n = len(L.PROF_CLASSES)
+    pms, pcnt, pwork = (C.c_double * n)(), (C.c_longlong * n)(), (C.c_double * n)()
+    L.check(lib.vtc_prof_end(stream_ptr, pms, pcnt, pwork), "vtc_prof_end")     # synchronises the stream
+    barrier_sync(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, device)
+    prof = {name: dict(ms=pms[i], launches=int(pcnt[i]), work=pwork[i]) for i, name in enumerate(L.PROF_CLASSES)}
+    assert torch.isfinite(out[2]).all()
+    value = world * B * args.steps / dt
+
+    gk = "gemm_bf16" if args.dtype == "bf16" else "gemm_f32"
+    g = prof[gk]
+    achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+    roofline = dict(bound="mfma", achieved=round(achieved, 1), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+                    traffic=None, kernel=f"gemm_kernel<{args.dtype}> (all epilogues)",
+                    launches_per_step=g["launches"] // args.steps, avg_launch_us=round(1e3 * g["ms"] / max(1, g["launches"]), 2),
+                    flop_per_launch=round(g["work"] / max(1, g["launches"]) / 1e9, 3))
+    breakdown = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}
+
+    result = {
+        "metric": "video-text pairs encoded/sec (config 2: image+title+5 comments, CAM, ViT-B/32)", "value": round(value, 1),
+        "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "configs/pretrained_clip_comments_attention.jsonc PretrainedCLIP_finaltf forward: "
+                               f"{B} pairs/GPU/step = {B} images 224x224 + {B} titles + {5 * B} comments (77 tokens) + CAM + sim",
+                   "pairs_per_gpu": B, "parallelism": f"dp{world} (one process per GPU, no collective in the encode path)"},
+        "roofline": roofline,
+        "kernel_ms_per_step": breakdown,
+    }
+
+    extra = {}
+    if not args.no_extra:
+        # ---- config 3: 8-frame TimeSformer video + title + 5 comments ------------------------
+        del m2
+        torch.cuda.empty_cache()
+        m3 = HM.PretrainedCLIP_TimeSformer_finaltf(model_type="ViT-B/32", branch_to_adapt_val="text")
+        for blk in m3.model.visual.transformer.resblocks:       # trained temporal_fc is not zero
+            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+        m3 = m3.eval().to(device)
+        m3.compute_dtype = cdt
+        B3 = 64
+        vid = torch.randn(B3, 8, 3, 224, 224, generator=gen).to(device).to(cdt)
+        t3, c3 = title[:B3].contiguous(), comments[:B3].contiguous()
+        for _ in range(2):
+            m3(vid, t3, c3)
+        barrier_sync(world)
+        k3 = max(2, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(k3):
+            o3 = m3(vid, t3, c3)
+        barrier_sync(world)
+        dt3 = max_over_ranks(time.perf_counter() - t0, world, device)
+        extra["config3_timesformer_pairs_per_s"] = round(world * B3 * k3 / dt3, 1)
+        extra["config3_ms_per_step"] = round(1e3 * dt3 / k3, 2)
+        extra["config3_pairs_per_gpu"] = B3
+        p3 = prof_run(lambda: m3(vid, t3, c3), stream_ptr)
+        g3 = p3[gk]
+        extra["config3_gemm_tflops"] = round(g3["work"] / (g3["ms"] * 1e-3) / 1e12, 1)
+        extra["config3_kernel_ms"] = {k: round(v["ms"], 3) for k, v in p3.items() if v["launches"]}
+        del m3, vid
+        torch.cuda.empty_cache()
+
+        # ---- sweep: N x N sim + R@1/5/10 both directions, sharded by query rows ---------------
+        N = args.sweep_n
+        lo, hi = vdist.shard_bounds(N, rank, world)
+        g2 = torch.Generator().manual_seed(123)
+        va = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
+        noise = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
+        tb = torch.nn.functional.normalize(va + 0.9 * noise * torch.rand(N, 1, generator=g2) * 2, dim=-1)   # planted positives
+        va_l, tb_l = va[lo:hi].to(device), tb[lo:hi].to(device)
+        for prec_name, prec in (("f32", L.SWEEP_F32), ("bf16x3", L.SWEEP_BF16X3)):
+            vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec)      # warm-up
+            barrier_sync(world)
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                r_ab, r_ba = vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec)
+            barrier_sync(world)
+            dts = max_over_ranks(time.perf_counter() - t0, world, device) / reps
+            extra[f"sweep_{N}_{prec_name}_ms"] = round(1e3 * dts, 3)
+            extra[f"sweep_{N}_{prec_name}_recall"] = {"t_from_v": r_ab, "v_from_t": r_ba}
+            # algorithmic HBM bytes, materialised fp32 matrix: 8 N^2 per direction
+            extra[f"sweep_{N}_{prec_name}_algorithmic_GBps"] = round(2 * 8.0 * N * N / dts / 1e9, 1)
+        result["extra"] = extra
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

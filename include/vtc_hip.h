@@ -162,6 +162,16 @@ int vtc_layernorm(const float *x, const float *g, const float *b, void *y, int r
 int vtc_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2, int a0,
                   int a1, int a2, int a3, int pstride, int dtype, void *stream);
 
+/* ---- optional per-launch timing (HIP events on the launch stream; bench/diagnostics) ----
+ * Between vtc_prof_begin() and vtc_prof_end() every kernel launch of the library is bracketed by
+ * two events.  vtc_prof_end synchronises `stream` and returns, per class, the summed kernel time,
+ * the launch count and the summed work (FLOPs = 2MNK for GEMM, 4*L*L*64 per (sequence, head) for
+ * attention; bytes moved for the others).  Process-global, single-threaded use only. */
+enum { VTC_PROF_GEMM_BF16 = 0, VTC_PROF_GEMM_F32 = 1, VTC_PROF_ATTN = 2, VTC_PROF_NORM = 3, VTC_PROF_EMBED = 4,
+       VTC_PROF_TOPK = 5, VTC_PROF_NCLASS = 6 };
+int vtc_prof_begin(void);
+int vtc_prof_end(void *stream, double *ms, long long *launches, double *work);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ VTC_F32, VTC_BF16 = 0, 1
 ACT_NONE, ACT_NORMALIZE, ACT_SQUASH, ACT_TANH = 0, 1, 2, 3
 SWEEP_F32, SWEEP_BF16X3, SWEEP_BF16 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RESID = 0, 1, 2
+PROF_CLASSES = ("gemm_bf16", "gemm_f32", "attention", "norm", "embed", "topk")
 
 vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
 
@@ -67,6 +68,8 @@ SIGNATURES = {
     "vtc_recall_hits": (C.c_int, [ip, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int), C.c_int, vp, vp]),
     "vtc_gemm": (C.c_int, [vp, vp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "vtc_layernorm": (C.c_int, [fp, fp, fp, vp, C.c_int, C.c_int, C.c_int, ip, C.c_int, vp]),
+    "vtc_prof_begin": (C.c_int, []),
+    "vtc_prof_end": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "vtc_attention": (C.c_int, [vp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, vp]),
 }

@@ -245,6 +245,7 @@ int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int 
   p.n_seq = n_seq; p.L = L; p.heads = heads; p.causal = causal;
   p.s2 = s2; p.a0 = a0; p.a1 = a1; p.a2 = a2; p.a3 = a3; p.pstride = pstride;
   p.W = heads * 64;
+  ProfScope prof(VTC_PROF_ATTN, 4.0 * L * L * 64 * (double)n_seq * heads, stream);
   return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
 }
 

@@ -81,6 +81,14 @@ __device__ __forceinline__ float wave_max(float v) {
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- optional per-launch event timing (prof.hip) -------------------------------------------
+struct ProfScope {
+  ProfScope(int cls, double work, hipStream_t s);
+  ~ProfScope();
+  hipStream_t stream_;
+  int idx_;
+};
+
 // ---- internal launchers shared between translation units --------------------------------
 struct GemmEpi {
   int mode = VTC_EPI_STORE;   // VTC_EPI_*  (+ internal modes below)

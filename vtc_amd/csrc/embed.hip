@@ -192,6 +192,7 @@ int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_f
   VTC_CHECK(patch % 4 == 0, "im2row: patch=%d must be a multiple of 4", patch);
   const size_t total = (size_t)n_frames * grid * grid * (3 * patch * patch / 4);
   const dim3 g((unsigned)((total + 255) / 256)), b(256);
+  ProfScope prof(VTC_PROF_EMBED, (double)total * 4 * ((pixel_dtype == VTC_BF16 ? 2 : 4) + (dtype == VTC_BF16 ? 2 : 4)), stream);
   if (pixel_dtype == VTC_F32 && dtype == VTC_BF16)
     hipLaunchKernelGGL((im2row_kernel<float, bf16_t>), g, b, 0, stream, (const float *)px, (bf16_t *)out, n_frames, grid, patch, res);
   else if (pixel_dtype == VTC_F32)
@@ -221,6 +222,7 @@ int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int
 int launch_text_embed(const int64_t *ids, const float *tok, const float *pos, float *x, int *eot_row, int n_seq, int ctx,
                       int W, int vocab, hipStream_t stream) {
   VTC_CHECK(W % 4 == 0, "text_embed: width %d", W);
+  ProfScope prof(VTC_PROF_EMBED, (double)n_seq * ctx * W * 12, stream);
   hipLaunchKernelGGL(text_embed_kernel, dim3(cdiv(n_seq * ctx, 4)), dim3(256), 0, stream, ids, tok, pos, x, n_seq * ctx, ctx, W, vocab);
   hipLaunchKernelGGL(eot_index_kernel, dim3(cdiv(n_seq, 256)), dim3(256), 0, stream, ids, eot_row, n_seq, ctx);
   VTC_LAUNCH_CHECK("text_embed");

@@ -275,6 +275,7 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
   p.ldo = epi.ldo > 0 ? epi.ldo : N;
   p.MT = cdiv(M, BM); p.NT = cdiv(N, BN);
   p.epi = epi;
+  ProfScope prof(dtype == VTC_BF16 ? VTC_PROF_GEMM_BF16 : VTC_PROF_GEMM_F32, 2.0 * M * N * K, stream);
   return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
 }
 

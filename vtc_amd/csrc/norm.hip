@@ -89,6 +89,7 @@ int launch_layernorm(const float *x, const float *g, const float *b, void *y, in
   VTC_CHECK(rows > 0, "layernorm: rows=%d", rows);
   VTC_CHECK(width % 4 == 0 && width <= 256 * MAXV, "layernorm: width=%d unsupported", width);
   const dim3 grid(cdiv(rows, 4)), block(256);
+  ProfScope prof(VTC_PROF_NORM, (double)rows * width * (4 + (out_dtype == VTC_BF16 ? 2 : 4)), stream);
   if (out_dtype == VTC_BF16) {
     if (no_norm) hipLaunchKernelGGL((layernorm_kernel<bf16_t, true>), grid, block, 0, stream, x, g, b, (bf16_t *)y, rows, width, row_index, row_mul);
     else hipLaunchKernelGGL((layernorm_kernel<bf16_t, false>), grid, block, 0, stream, x, g, b, (bf16_t *)y, rows, width, row_index, row_mul);

@@ -217,7 +217,10 @@ extern "C" int vtc_l2_topk(const float *gallery, const float *queries, int ng, i
     else
       rc = launch_gemm(s.qb + (size_t)r0 * d * parts, s.gb, nullptr, s.dist, rows, ng, d * parts, VTC_BF16, e, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(row_topk_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, s.dist, ng, rows, ng, depth, ids, dists, (size_t)r0);
+    {
+      ProfScope prof(VTC_PROF_TOPK, (double)rows * ng * 4, stream);
+      hipLaunchKernelGGL(row_topk_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, s.dist, ng, rows, ng, depth, ids, dists, (size_t)r0);
+    }
     VTC_LAUNCH_CHECK("row_topk");
   }
   return 0;

@@ -1,0 +1,99 @@
+"""One-process-per-GPU scale-out of the eval path (torch.distributed; backend "nccl" = RCCL).
+
+The reference is single-process (nn.DataParallel, train.py:77-80; eval is single-GPU,
+evaluation/eval.py:196).  Here encoding is embarrassingly parallel over pairs -- each rank
+encodes its shard, no collective -- and the N x N sweep has exactly one exchange step
+(SURVEY 8e):
+
+    all_gather(V_r), all_gather(T_r)          [N/G, 512] fp32 per rank (2.56 MB at 10k, 12.8 MB at 50k)
+    rank r sweeps its own query rows against the full gallery, both directions
+    all_reduce(sum) of the 2 x len(k) int64 hit counters
+
+No cross-rank top-k merge is needed because a rank owns whole query rows.  Works with "gloo"
+on CPU tensors for the collectives' bookkeeping (tests), the sweep itself is HIP-only.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run); single process otherwise."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """Contiguous shards, sizes differ by at most one: rank r owns [lo, hi)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_rows(x: torch.Tensor, n_total: int, rank: int, world: int) -> torch.Tensor:
+    """Concatenate every rank's [n_r, D] rows in rank order (shards may differ by one row)."""
+    if world == 1:
+        return x
+    sizes = [shard_bounds(n_total, r, world) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = x
+    if x.shape[0] < mx:
+        pad = torch.cat([x, x.new_zeros(mx - x.shape[0], x.shape[1])])
+    out = x.new_empty(world * mx, x.shape[1])
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    if all(hi - lo == mx for lo, hi in sizes):
+        return out
+    return torch.cat([out[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
+
+
+def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_total: int, k_vals: Sequence[int],
+                   rank: int, world: int,
+                   topk: Optional[Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor]] = None,
+                   precision: int = 0):
+    """R@K both directions for row-sharded embeddings.
+
+    Returns ({k: recall b_from_a-direction as RecallAtK.compute(a, b)}, {k: compute(b, a)}).
+    ``topk(gallery, queries, depth) -> ids`` defaults to the HIP sweep; tests inject a CPU one to
+    exercise the sharding logic under gloo."""
+    lo, hi = shard_bounds(n_total, rank, world)
+    assert feats_a_local.shape[0] == hi - lo and feats_b_local.shape[0] == hi - lo
+    a_all = all_gather_rows(feats_a_local, n_total, rank, world)
+    b_all = all_gather_rows(feats_b_local, n_total, rank, world)
+    depth = min(int(max(k_vals)) + 1, n_total)
+    if topk is None:
+        from . import ops
+
+        def topk(g, q, d):
+            return ops.l2_topk(g, q, d, precision=precision, return_dists=False)[0]
+    ks = [min(int(k), depth) for k in k_vals]
+    tgt = torch.arange(lo, hi, device=feats_a_local.device)[:, None]
+    hits = torch.zeros(2, len(ks), dtype=torch.int64, device=feats_a_local.device)
+    # compute(a, b): gallery a, queries b (model/metric.py:137-146); this rank owns query rows [lo, hi)
+    for d_, (gal, qry) in enumerate(((a_all, feats_b_local), (b_all, feats_a_local))):
+        ids = topk(gal, qry, depth)
+        if ids.is_cuda and len(ks) <= 4:
+            from . import ops
+            ops.recall_hits(ids, ks, target_offset=lo, hits=hits[d_])
+        else:
+            for j, k in enumerate(ks):
+                hits[d_, j] = (ids[:, :k] == tgt).any(dim=1).sum()
+    if world > 1:
+        dist.all_reduce(hits, op=dist.ReduceOp.SUM)
+    hits = hits.cpu()
+    r_ab = {k: hits[0, j].item() / n_total for j, k in enumerate(k_vals)}
+    r_ba = {k: hits[1, j].item() / n_total for j, k in enumerate(k_vals)}
+    return r_ab, r_ba

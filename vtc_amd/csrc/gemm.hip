@@ -62,8 +62,27 @@ struct GemmParams {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_dst, lds_dst + 1 KiB).
+// Written as inline asm so that hipcc does NOT model it as a memory operation: with the builtin the
+// compiler serialises the pipeline by waiting vmcnt(0) before the first ds_read of every K-step
+// (it cannot prove the DMA into the other buffer does not alias the reads).  The completion wait is
+// ours: one s_waitcnt vmcnt(0) before the barrier that publishes the buffer.  M0 carries the
+// wave-uniform LDS byte address and is saved/restored inside the same statement (guide 5.7).
+__device__ __forceinline__ void glds16(const char *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
 // Stage one 128-row x 128-byte operand tile: 16 wave-instructions of 1 KiB, 4 per wave.
-__device__ __forceinline__ void stage_tile(const char *base, int row0, int nrows, int ld_bytes, int kbyte, char *lds_tile,
+__device__ __forceinline__ void stage_tile(const char *base, int row0, int nrows, int ld_bytes, int kbyte, unsigned lds_tile,
                                            int wave, int lane) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -74,7 +93,7 @@ __device__ __forceinline__ void stage_tile(const char *base, int row0, int nrows
     int gr = row0 + r;
     gr = gr < nrows ? gr : nrows - 1;         // clamp: tail rows re-read a valid row, never stored
     const char *src = base + (size_t)gr * ld_bytes + kbyte + c * 16;
-    __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds_tile + group * 1024), 16, 0, 0);
+    glds16(src, lds_tile + group * 1024);
   }
 }
 
@@ -107,9 +126,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int ksteps = p.K / Mma<T>::KPR;
+  // wave-uniform LDS byte address of the staging area (dynamic LDS starts at the kernel's LDS base)
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)lds);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   // prologue
-  stage_tile(p.A, m0, p.M, p.lda_bytes, 0, lds, wave, lane);
-  stage_tile(p.W, n0, p.N, p.ldw_bytes, 0, lds + TILE_BYTES, wave, lane);
+  stage_tile(p.A, m0, p.M, p.lda_bytes, 0, lds_base, wave_u, lane);
+  stage_tile(p.W, n0, p.N, p.ldw_bytes, 0, lds_base + TILE_BYTES, wave_u, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA landed (this wave's share)
   __syncthreads();
 
@@ -121,9 +143,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
   int cur = 0;
   for (int t = 0; t < ksteps; ++t) {
     if (t + 1 < ksteps) {
-      char *nxt = lds + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_tile(p.A, m0, p.M, p.lda_bytes, (t + 1) * ROWB, nxt, wave, lane);
-      stage_tile(p.W, n0, p.N, p.ldw_bytes, (t + 1) * ROWB, nxt + TILE_BYTES, wave, lane);
+      const unsigned nxt = lds_base + (cur ^ 1) * 2 * TILE_BYTES;
+      stage_tile(p.A, m0, p.M, p.lda_bytes, (t + 1) * ROWB, nxt, wave_u, lane);
+      stage_tile(p.W, n0, p.N, p.ldw_bytes, (t + 1) * ROWB, nxt + TILE_BYTES, wave_u, lane);
     }
     const char *as = lds + cur * 2 * TILE_BYTES;
     const char *ws = as + TILE_BYTES;

@@ -125,6 +125,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // Per-column addend of the epilogue (bias, or |g|^2 for the distance epilogue), fetched now so
+  // that its latency hides under the K loop.  Interior tiles only; edge tiles use the slow path.
+  const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 3) == 0);
+  float4 pre4[4];
+  {
+    const float *colv = MODE == EPI_L2DIST ? p.epi.coln : p.bias;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pre4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (interior && colv) pre4[j] = *reinterpret_cast<const float4 *>(colv + n0 + wc * 64 + j * 16 + (lane >> 4) * 4);
+    }
+  }
+
   const int ksteps = p.K / Mma<T>::KPR;
   // wave-uniform LDS byte address of the staging area (dynamic LDS starts at the kernel's LDS base)
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)lds);
@@ -173,6 +186,67 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
   const bool vec_ok = (ldo & 3) == 0;
   float scale = 1.0f;
   if (MODE == EPI_SCALE) scale = __expf(*p.epi.scale_log);
+
+  if (interior) {
+    // Fast path (every tile of the towers): straight-line code, all loads of a row issued before
+    // the first use so the epilogue costs one memory round trip instead of sixteen.
+    const int nb = n0 + wc * 64 + g * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+      if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && (m % p.epi.skip_mod) == 0) continue;
+      size_t orow = (size_t)m;
+      float4 add4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) add4[j] = pre4[j];
+      if (MODE == EPI_PATCH) {
+        const int np = m % p.epi.P, ft = m / p.epi.P;
+        const int tt = ft % p.epi.F, item = ft / p.epi.F;
+        orow = (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
+        const float *posrow = p.epi.pos + (size_t)(1 + np) * p.N + nb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) add4[j] = *reinterpret_cast<const float4 *>(posrow + 16 * j);
+        if (p.epi.temporal) {
+          const float *temprow = p.epi.temporal + (size_t)tt * p.N + nb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(temprow + 16 * j);
+            add4[j].x += t4.x; add4[j].y += t4.y; add4[j].z += t4.z; add4[j].w += t4.w;
+          }
+        }
+      }
+      float rn = 0.f;
+      if (MODE == EPI_L2DIST) rn = p.epi.rown[m];
+      OutT *o = reinterpret_cast<OutT *>(p.out) + orow * ldo + nb;
+      float4 x4[4];
+      if (MODE == VTC_EPI_RESID) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x4[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<float *>(o) + 16 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        const float a4[4] = {add4[j].x, add4[j].y, add4[j].z, add4[j].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (MODE == EPI_L2DIST) v[e] = rn + a4[e] - 2.0f * v[e];
+          else v[e] += a4[e];
+          if (MODE == VTC_EPI_GELU) v[e] = quick_gelu(v[e]);
+          if (MODE == EPI_SCALE) v[e] *= scale;
+        }
+        if (MODE == VTC_EPI_RESID) {
+          *reinterpret_cast<float4 *>(reinterpret_cast<float *>(o) + 16 * j) =
+              make_float4(x4[j].x + v[0], x4[j].y + v[1], x4[j].z + v[2], x4[j].w + v[3]);
+        } else {
+          ElemOps<OutT>::store4(o + 16 * j, v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    return;
+  }
+
+  // Generic path: edge tiles (M or N not a multiple of 128, odd leading dimension).
+  // (fully unrolled: a runtime index into acc[][] would send the accumulators to scratch)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wr * 64 + i * 16 + (lane & 15);
@@ -183,9 +257,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
     float rn = 0.f;
     if (MODE == EPI_PATCH) {
       const int np = m % p.epi.P, ft = m / p.epi.P;
-      const int tt = p.epi.F > 0 ? ft % p.epi.F : 0, item = p.epi.F > 0 ? ft / p.epi.F : ft;
-      const int Fe = p.epi.F > 0 ? p.epi.F : 1;
-      orow = (size_t)item * p.epi.T + 1 + (size_t)np * Fe + tt;
+      const int tt = ft % p.epi.F, item = ft / p.epi.F;
+      orow = (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
       posrow = p.epi.pos + (size_t)(1 + np) * p.N;
       if (p.epi.temporal) temprow = p.epi.temporal + (size_t)tt * p.N;
     }
@@ -195,50 +268,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams p) {
       const int n = n0 + wc * 64 + j * 16 + g * 4;
       if (n >= p.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const bool full = (n + 3 < p.N);
-      if (p.bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (full || n + e < p.N) v[e] += p.bias[n + e];
-      }
-      if (MODE == VTC_EPI_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-      }
-      if (MODE == EPI_PATCH) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] += posrow[n + e];
-          if (temprow) v[e] += temprow[n + e];
-        }
-      }
-      if (MODE == EPI_L2DIST) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (full || n + e < p.N) v[e] = rn + p.epi.coln[n + e] - 2.0f * v[e];
-      }
-      if (MODE == EPI_SCALE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= scale;
-      }
       OutT *o = reinterpret_cast<OutT *>(p.out) + orow * ldo + n;
-      if (MODE == VTC_EPI_RESID) {
-        float *xo = reinterpret_cast<float *>(o);
-        if (full && vec_ok) {
-          float4 x = *reinterpret_cast<float4 *>(xo);
-          x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
-          *reinterpret_cast<float4 *>(xo) = x;
-        } else {
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) xo[e] += v[e];
-        }
-      } else {
-        if (full && vec_ok) {
-          ElemOps<OutT>::store4(o, v[0], v[1], v[2], v[3]);
-        } else {
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) ElemOps<OutT>::store(o + e, v[e]);
-        }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= p.N) continue;
+        float x = v[e];
+        if (p.bias) x += p.bias[n + e];
+        if (MODE == VTC_EPI_GELU) x = quick_gelu(x);
+        if (MODE == EPI_PATCH) x += posrow[n + e] + (temprow ? temprow[n + e] : 0.f);
+        if (MODE == EPI_L2DIST) x = rn + p.epi.coln[n + e] - 2.0f * x;
+        if (MODE == EPI_SCALE) x *= scale;
+        if (MODE == VTC_EPI_RESID) reinterpret_cast<float *>(o)[e] += x;
+        else ElemOps<OutT>::store(o + e, x);
       }
     }
   }

@@ -80,7 +80,7 @@ def max_over_ranks(t, world, device):
     return float(x.item())
 
 
-def cpu_baseline(kind_pairs=8):
+def cpu_baseline(kind_pairs=96):
     """Oracle (kind 'port') on the host cores: config 2 forward at B = kind_pairs, best of 2."""
     from oracle import arch as A
     from oracle import model_ref as M

@@ -1,0 +1,29 @@
+"""GPU: the drop-in eval entry point (evaluation/eval.py) runs the BASELINE configs end to end on
+synthetic pairs and its R@K equals the oracle's literal RecallAtK restatement on the same embeddings."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import eval_ref as E
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cfg,n", [("configs/pretrained_clip.jsonc", 96),
+                                   ("configs/pretrained_clip_comments_attention.jsonc", 96),
+                                   ("configs/pretrained_clip_timesformer_comments_attention.jsonc", 24)])
+def test_eval_cli_matches_oracle_recall(cfg, n, tmp_path):
+    import os
+    from vtc_amd.host import eval as ev
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_json = tmp_path / "res.json"
+    torch.manual_seed(1023)
+    out, fv, ft = ev.cli(["-c", os.path.join(root, cfg), "--bs", "16", "--n_pairs", str(n), "--out", str(out_json)])
+    assert set(json.load(open(out_json))) == {"R1_title_from_im", "R5_title_from_im", "R10_title_from_im",
+                                              "R1_im_from_title", "R5_im_from_title", "R10_im_from_title"}
+    fv, ft = fv.cpu().numpy(), ft.cpu().numpy()
+    assert fv.shape == (n, 512) and np.allclose(np.linalg.norm(fv, axis=1), 1, atol=1e-5)
+    if E.near_ties(fv, ft) == 0 and E.near_ties(ft, fv) == 0:
+        assert out == E.eval_result_dict(fv, ft)

@@ -1,0 +1,93 @@
+"""Drop-in for the reference's ``evaluation/eval.py`` entry point (evaluation/eval.py:50-196):
+
+    python evaluation/eval.py -c configs/pretrained_clip_comments_attention.jsonc [-r ckpt] [-d 0]
+                              [--bs N] [--bv branch] [--nc n] [--am fusion] [--ac mode]
+
+Same flags, same result JSON keys (R{1,5,10}_title_from_im / _im_from_title, :131-138), same
+loop semantics (encode every pair, stack, Recall@K both directions).  Differences, all inside the
+hot path's boundary: embeddings stay on the GPU between batches instead of a D2H per batch
+(:114-115), the k-NN runs in libvtc_hip.so instead of faiss, and the dataset ``type`` may be
+``SyntheticPairs`` so that the configs need no csv/images."""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import sys
+
+import torch
+from torch.utils.data import DataLoader
+
+from . import datasets as module_data
+from . import model as module_arch
+from .metric import RecallAtK
+from .parse_config import ConfigParser
+
+
+def main(config: ConfigParser, args, checkpoint_path=None, device="cuda"):
+    dataset = config.init_obj("dataset", module_data, train=False, test=True)
+    arch_args = config["arch"].get("args", {})
+    branch_to_adapt = arch_args.get("branch_to_adapt_val", None)
+    comment_fusion = arch_args.get("comment_fusion", None)
+    num_comms = config["dataset"]["args"].get("num_comms", None)
+    add_comments = config["dataset"]["args"].get("add_comments", "never")
+    if branch_to_adapt is None:
+        exp_combo = "title_only" if add_comments != "always" else f"{comment_fusion}_{num_comms}_comms"
+    else:
+        exp_combo = f"adapted_{branch_to_adapt}_{num_comms}_comms"
+    if checkpoint_path is not None:
+        save_path = f"{checkpoint_path.absolute().as_posix()[:-4]}_res_{exp_combo}.json"
+    else:
+        save_path = getattr(args, "out", None) or f"zero_shot_res_{comment_fusion}.json"
+    logging.info(f"Saving results to {save_path}")
+
+    loader = DataLoader(dataset, batch_size=config["batch_size"], num_workers=getattr(args, "workers", 0), shuffle=False)
+    model = config.init_obj("arch", module_arch)
+    if checkpoint_path is not None:
+        checkpoint = torch.load(checkpoint_path, map_location="cpu")
+        model.load_state_dict(checkpoint["state_dict"])            # strict, eval.py:90-91
+    model = model.eval().to(device)
+
+    res_vis, res_text = [], []
+    with torch.no_grad():
+        for vis, title, comments, meta in loader:
+            out = model.forward(vis.to(device), title.to(device), comments.to(device))
+            res_vis.append(out[0])
+            res_text.append(out[1])
+    res_vis, res_text = torch.cat(res_vis), torch.cat(res_text)
+    t_from_i = RecallAtK("images", "titles", [1, 5, 10]).compute(res_vis, res_text)
+    i_from_t = RecallAtK("titles", "images", [1, 5, 10]).compute(res_text, res_vis)
+    out = {"R1_title_from_im": t_from_i[0][1], "R5_title_from_im": t_from_i[1][1], "R10_title_from_im": t_from_i[2][1],
+           "R1_im_from_title": i_from_t[0][1], "R5_im_from_title": i_from_t[1][1], "R10_im_from_title": i_from_t[2][1]}
+    with open(save_path, "w") as f:
+        json.dump(out, f)
+    return out, res_vis, res_text
+
+
+def cli(argv=None):
+    ap = argparse.ArgumentParser(description="VTC eval (MI355X)")
+    ap.add_argument("-c", "--config", default="configs/pretrained_clip.jsonc", type=str)
+    ap.add_argument("-r", "--resume", default=None, type=str)
+    ap.add_argument("-d", "--device", default="0", type=str)
+    ap.add_argument("--num_irrelevant_comments", default=0, type=int)
+    ap.add_argument("--bs", "--batch_size", dest="bs", type=int, default=None)
+    ap.add_argument("--bv", "--branch_to_adapt_val", dest="bv", type=str, default=None)
+    ap.add_argument("--nc", "--num_comms", dest="nc", type=int, default=None)
+    ap.add_argument("--am", "--comment_fusion", dest="am", type=str, default=None)
+    ap.add_argument("--ac", "--add_comments", dest="ac", type=str, default=None)
+    ap.add_argument("--out", type=str, default=None)
+    ap.add_argument("--workers", type=int, default=0)
+    ap.add_argument("--n_pairs", type=int, default=None, help="SyntheticPairs only: number of pairs")
+    args = ap.parse_args(argv)
+    if args.num_irrelevant_comments:
+        raise NotImplementedError("--num_irrelevant_comments (evaluation/eval.py:23-47) is an ablation outside the hot path")
+    mods = {"batch_size": args.bs, "arch;args;branch_to_adapt_val": args.bv, "dataset;args;num_comms": args.nc,
+            "arch;args;comment_fusion": args.am, "dataset;args;add_comments": args.ac, "dataset;args;n_pairs": args.n_pairs}
+    config = ConfigParser.from_file(args.config, resume=args.resume, modification=mods)
+    out, res_vis, res_text = main(config, args, config.resume, device="cuda:" + args.device)
+    print(json.dumps(out))
+    return out, res_vis, res_text
+
+
+if __name__ == "__main__":
+    cli(sys.argv[1:])

@@ -32,88 +32,11 @@
 //     dispatch; used for speed only) and walk a contiguous range of tiles ordered in super-rows of
 //     1024 output rows x all columns, so the weight panels and the activation panels in flight stay
 //     resident in that XCD's 4 MiB L2.
-#include "common.h"
+#include "gemm_common.h"
+
+using namespace vtcgemm;
 
 namespace {
-
-constexpr int ROWB = 128;          // bytes of K per LDS row
-constexpr int SUPER_ROWS = 1024;   // output rows per L2 super-row
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  static constexpr int KPR = 64;  // K elements per 128-byte row
-  __device__ static __forceinline__ void run(const uint4 &w, const uint4 &a, f32x4 &acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc,
-                                                  0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  static constexpr int KPR = 32;
-  __device__ static __forceinline__ void run(const uint4 &w, const uint4 &a, f32x4 &acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.x), __builtin_bit_cast(float, a.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.y), __builtin_bit_cast(float, a.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.z), __builtin_bit_cast(float, a.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.w), __builtin_bit_cast(float, a.w), acc, 0, 0, 0);
-  }
-};
-
-struct GemmParams {
-  const char *A;
-  const char *W;
-  const float *bias;
-  void *out;
-  int M, N, K;
-  int lda_bytes, ldw_bytes, ldo;
-  int MT, NT;
-  GemmEpi epi;
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-
-// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_dst, lds_dst + 1 KiB).
-// Inline asm so that hipcc does NOT model it as a memory operation: with the builtin the compiler
-// waits vmcnt(0) before the first ds_read of every K-step (it cannot prove the DMA into the other
-// buffer does not alias the reads) and the pipeline serialises.  The completion wait is ours: one
-// s_waitcnt vmcnt(0) before the barrier that publishes the buffer.  M0 carries the wave-uniform LDS
-// byte address and is saved/restored inside the same statement (guide 5.7).
-__device__ __forceinline__ void glds16(const char *gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
-}
-
-// Stage GROUPS 8-row groups of a ROWS-row x 128-byte operand tile (this wave's share).
-template <int GROUPS>
-__device__ __forceinline__ void stage_tile(const char *base, int row0, int nrows, int ld_bytes, int kbyte, unsigned lds_tile,
-                                           int wave, int lane) {
-#pragma unroll
-  for (int q = 0; q < GROUPS; ++q) {
-    const int group = wave * GROUPS + q;      // 8-row group
-    const int r = group * 8 + (lane >> 3);    // tile row this lane fills
-    const int cs = lane & 7;                  // LDS chunk slot (linear)
-    const int c = cs ^ ((r >> 1) & 7);        // source chunk (swizzle on the source side)
-    int gr = row0 + r;
-    gr = gr < nrows ? gr : nrows - 1;         // clamp: tail rows re-read a valid row, never stored
-    const char *src = base + (size_t)gr * ld_bytes + kbyte + c * 16;
-    glds16(src, lds_tile + group * 1024);
-  }
-}
-
-// QuickGELU x * sigmoid(1.702 x) (model/timesformer_clip_alt.py:31-33).  fp32 mode: IEEE division and
-// expf; bf16 mode: v_exp_f32 + v_rcp_f32 (1 ulp each, far below the bf16 rounding of the result) --
-// the IEEE division sequence alone cost ~25 % of a K = 512 tile.
-template <bool ACCURATE>
-__device__ __forceinline__ float quick_gelu(float x) {
-  if (ACCURATE) return x / (1.0f + expf(-1.702f * x));
-  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554670f * x));   // 1.702 * log2(e)
-}
 
 // WM x WN waves, each owning TM x TN MFMA tiles of 16x16.
 template <typename T, int MODE, typename OutT, int WM, int WN, int TM, int TN>
@@ -220,60 +143,109 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
     float scale = 1.0f;
     if (MODE == EPI_SCALE) scale = __expf(*p.epi.scale_log);
     if (interior) {
-      // Fast path (every tile of the towers): straight-line code, all loads of a row issued
-      // before the first use so a row costs one memory round trip.
-      const int nb = n0 + wc * TN * 16 + g * 4;
+      // Fast path (every tile of the towers).  The write path of a CU retires roughly one distinct
+      // cache line per 5-8 cycles whatever its fill, so storing straight from the MFMA layout
+      // (16 rows x 32..64 B per instruction) made the epilogue cost as much as 5 K-steps.  Instead
+      // each wave transposes its outputs through the LDS stage that the last K-step has just freed
+      // (the other stage already holds the next tile's first slab) and writes whole rows: every
+      // store instruction covers 4 (fp32) or 8 (bf16) full 256 / 128-byte row segments.
+      constexpr int TS = 68;                                   // padded row stride (floats): conflict-free b128 writes
+      float *tr = reinterpret_cast<float *>(lds + (cur ^ 1) * STAGE + wave * (STAGE / NW));   // 8 KiB per wave
+      const int l15 = lane & 15;
+      const int ncol0 = n0 + wc * TN * 16;
+      float rn[TM];
+      if (MODE == EPI_L2DIST) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) rn[i] = p.epi.rown[m0 + (wr * TM + i) * 16 + l15];
+      }
+      // residual mode: the x rows of pass i+1 are fetched while pass i is transposed and stored
+      auto x_ptr = [&](int i, int k) -> float * {
+        const int m = m0 + (wr * TM + i) * 16 + (lane >> 4) + 4 * k;
+        return reinterpret_cast<float *>(p.out) + (size_t)m * ldo + ncol0 + l15 * 4;
+      };
+      float4 xc[4], xn[4];
+      if (MODE == VTC_EPI_RESID) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xc[k] = *reinterpret_cast<const float4 *>(x_ptr(0, k));
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int m = m0 + (wr * TM + i) * 16 + (lane & 15);
-        if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && (m % p.epi.skip_mod) == 0) continue;
-        size_t orow = (size_t)m;
-        float4 add4[TN];
+        if (MODE == VTC_EPI_RESID && i + 1 < TM) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) add4[j] = pre4[j];
-        if (MODE == EPI_PATCH) {
-          const int np = m % p.epi.P, ft = m / p.epi.P;
-          const int tt = ft % p.epi.F, item = ft / p.epi.F;
-          orow = (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
-          const float *posrow = p.epi.pos + (size_t)(1 + np) * p.N + nb;
-#pragma unroll
-          for (int j = 0; j < TN; ++j) add4[j] = *reinterpret_cast<const float4 *>(posrow + 16 * j);
-          if (p.epi.temporal) {
-            const float *temprow = p.epi.temporal + (size_t)tt * p.N + nb;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const float4 t4 = *reinterpret_cast<const float4 *>(temprow + 16 * j);
-              add4[j].x += t4.x; add4[j].y += t4.y; add4[j].z += t4.z; add4[j].w += t4.w;
-            }
-          }
+          for (int k = 0; k < 4; ++k) xn[k] = *reinterpret_cast<const float4 *>(x_ptr(i + 1, k));
         }
-        float rn = 0.f;
-        if (MODE == EPI_L2DIST) rn = p.epi.rown[m];
-        OutT *o = reinterpret_cast<OutT *>(p.out) + orow * ldo + nb;
-        float4 x4[TN];
-        if (MODE == VTC_EPI_RESID) {
-#pragma unroll
-          for (int j = 0; j < TN; ++j) x4[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<float *>(o) + 16 * j);
-        }
+        // 1. registers -> LDS: final fp32 values in [16 rows][64 cols]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          const float a4[4] = {add4[j].x, add4[j].y, add4[j].z, add4[j].w};
+          const float a4[4] = {pre4[j].x, pre4[j].y, pre4[j].z, pre4[j].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (MODE == EPI_L2DIST) v[e] = rn + a4[e] - 2.0f * v[e];
+            if (MODE == EPI_L2DIST) v[e] = rn[i] + a4[e] - 2.0f * v[e];
             else v[e] += a4[e];
             if (MODE == VTC_EPI_GELU) v[e] = quick_gelu<sizeof(T) == 4>(v[e]);
             if (MODE == EPI_SCALE) v[e] *= scale;
           }
-          if (MODE == VTC_EPI_RESID) {
-            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(o) + 16 * j) =
-                make_float4(x4[j].x + v[0], x4[j].y + v[1], x4[j].z + v[2], x4[j].w + v[3]);
-          } else {
-            ElemOps<OutT>::store4(o + 16 * j, v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4 *>(tr + l15 * TS + 16 * j + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // 2. LDS -> global, row-contiguous
+        const int mrow0 = m0 + (wr * TM + i) * 16;
+        if constexpr (sizeof(OutT) == 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = (lane >> 4) + 4 * k, cc = l15 * 4;
+            float4 v = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
+            const int m = mrow0 + r;
+            size_t orow = (size_t)m;
+            bool live = true;
+            if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && (m % p.epi.skip_mod) == 0) live = false;
+            if (MODE == EPI_PATCH) {
+              const int np = m % p.epi.P, ft = m / p.epi.P;
+              const int tt = ft % p.epi.F, item = ft / p.epi.F;
+              orow = (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
+              const float4 p4 = *reinterpret_cast<const float4 *>(p.epi.pos + (size_t)(1 + np) * p.N + ncol0 + cc);
+              v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+              if (p.epi.temporal) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(p.epi.temporal + (size_t)tt * p.N + ncol0 + cc);
+                v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
+              }
+            }
+            float *o = reinterpret_cast<float *>(p.out) + orow * ldo + ncol0 + cc;
+            if (MODE == VTC_EPI_RESID) {
+              if (live) {
+                const float4 x = xc[k];
+                *reinterpret_cast<float4 *>(o) = make_float4(x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w);
+              }
+            } else {
+              *reinterpret_cast<float4 *>(o) = v;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int r = (lane >> 3) + 8 * k, cc = (lane & 7) * 8;
+            const float4 v0 = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
+            const float4 v1 = *reinterpret_cast<const float4 *>(tr + r * TS + cc + 4);
+            uint4 pk;
+            pk.x = (unsigned)f2bf(v0.x) | ((unsigned)f2bf(v0.y) << 16);
+            pk.y = (unsigned)f2bf(v0.z) | ((unsigned)f2bf(v0.w) << 16);
+            pk.z = (unsigned)f2bf(v1.x) | ((unsigned)f2bf(v1.y) << 16);
+            pk.w = (unsigned)f2bf(v1.z) | ((unsigned)f2bf(v1.w) << 16);
+            bf16_t *o = reinterpret_cast<bf16_t *>(p.out) + (size_t)(mrow0 + r) * ldo + ncol0 + cc;
+            *reinterpret_cast<uint4 *>(o) = pk;
           }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (MODE == VTC_EPI_RESID) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xc[k] = xn[k];
+        }
       }
+      if (has_next) __syncthreads();       // the transposition area becomes the next K-step's staging buffer
     } else {
       // Generic path: edge tiles (M or N not a multiple of the tile, odd leading dimension).
       // Fully unrolled: a runtime index into acc[][] would send the accumulators to scratch.
@@ -321,7 +293,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
   }
 }
 
-int g_num_cus = 0;
+}  // namespace
+namespace vtcgemm {
+static int g_num_cus = 0;
 int num_cus() {
   if (g_num_cus == 0) {
     int dev = 0;
@@ -331,6 +305,8 @@ int num_cus() {
   }
   return g_num_cus;
 }
+}  // namespace vtcgemm
+namespace {
 
 template <typename T, int MODE, typename OutT, int WM, int WN, int TM, int TN>
 int run(GemmParams p, hipStream_t stream) {

@@ -1,0 +1,89 @@
+// gemm_common.h -- MFMA wrappers, LDS-DMA staging and parameter block of the GEMM kernel (gemm.hip).
+#pragma once
+#include "common.h"
+
+namespace vtcgemm {
+
+constexpr int ROWB = 128;          // bytes of K per LDS row
+constexpr int SUPER_ROWS = 1024;   // output rows per L2 super-row
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int KPR = 64;  // K elements per 128-byte row
+  __device__ static __forceinline__ void run(const uint4 &w, const uint4 &a, f32x4 &acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc,
+                                                  0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KPR = 32;
+  __device__ static __forceinline__ void run(const uint4 &w, const uint4 &a, f32x4 &acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.x), __builtin_bit_cast(float, a.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.y), __builtin_bit_cast(float, a.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.z), __builtin_bit_cast(float, a.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.w), __builtin_bit_cast(float, a.w), acc, 0, 0, 0);
+  }
+};
+
+struct GemmParams {
+  const char *A;
+  const char *W;
+  const float *bias;
+  void *out;
+  int M, N, K;
+  int lda_bytes, ldw_bytes, ldo;
+  int MT, NT;
+  GemmEpi epi;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_dst, lds_dst + 1 KiB).
+// Inline asm so that hipcc does NOT model it as a memory operation: with the builtin the compiler
+// waits vmcnt(0) before the first ds_read of every K-step (it cannot prove the DMA into the other
+// buffer does not alias the reads) and the pipeline serialises.  The completion wait is ours: one
+// s_waitcnt vmcnt(0) before the barrier that publishes the buffer.  M0 carries the wave-uniform LDS
+// byte address and is saved/restored inside the same statement (guide 5.7).
+__device__ __forceinline__ void glds16(const char *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+// Stage GROUPS 8-row groups of a ROWS-row x 128-byte operand tile (this wave's share).
+template <int GROUPS>
+__device__ __forceinline__ void stage_tile(const char *base, int row0, int nrows, int ld_bytes, int kbyte, unsigned lds_tile,
+                                           int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < GROUPS; ++q) {
+    const int group = wave * GROUPS + q;      // 8-row group
+    const int r = group * 8 + (lane >> 3);    // tile row this lane fills
+    const int cs = lane & 7;                  // LDS chunk slot (linear)
+    const int c = cs ^ ((r >> 1) & 7);        // source chunk (swizzle on the source side)
+    int gr = row0 + r;
+    gr = gr < nrows ? gr : nrows - 1;         // clamp: tail rows re-read a valid row, never stored
+    const char *src = base + (size_t)gr * ld_bytes + kbyte + c * 16;
+    glds16(src, lds_tile + group * 1024);
+  }
+}
+
+// QuickGELU x * sigmoid(1.702 x) (model/timesformer_clip_alt.py:31-33).  fp32 mode: IEEE division and
+// expf; bf16 mode: v_exp_f32 + v_rcp_f32 (1 ulp each, far below the bf16 rounding of the result) --
+// the IEEE division sequence alone cost ~25 % of a K = 512 tile.
+template <bool ACCURATE>
+__device__ __forceinline__ float quick_gelu(float x) {
+  if (ACCURATE) return x / (1.0f + expf(-1.702f * x));
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554670f * x));   // 1.702 * log2(e)
+}
+
+
+int num_cus();
+
+}  // namespace vtcgemm

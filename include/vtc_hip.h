@@ -60,6 +60,7 @@ typedef struct {
  * model/timesformer_clip_alt.py:203-286 VisualTransformer (nframes > 0). */
 typedef struct {
   int width, heads, layers, patch, grid, embed_dim, nframes;
+  int variant;                    /* 0: timesformer_clip_alt.py (used by model.py); 1: timesformer_clip.py */
   const void  *conv_w;            /* conv1.weight flattened [W, 3*patch*patch]            */
   const float *class_embedding;   /* [W]                                                  */
   const float *pos;               /* positional_embedding [1+grid*grid, W]                */
@@ -123,6 +124,9 @@ int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, const float *co
 int vtc_normalize_rows(const float *x, float *out, int n, int d, void *stream);
 /* out[g] = mean over `group` consecutive rows (frames -> video, title+comments -> text) */
 int vtc_mean_groups(const float *x, float *out, int n_groups, int group, int d, void *stream);
+/* out[g] = mean of rows [offsets[g], offsets[g+1]): per-video mean over a ragged number of 8-frame
+ * chunks, NOT re-normalised (evaluation/retrieval_evaluation.py:254-259).  offsets: int32 [n_groups+1] */
+int vtc_segment_mean(const float *x, const int *offsets, float *out, int n_groups, int d, void *stream);
 /* sim[nv,nt] = exp(*logit_scale) * v @ t^T, fp32 exact */
 int vtc_similarity(const float *v, const float *t, int nv, int nt, int d, const float *logit_scale, float *sim,
                    void *stream);

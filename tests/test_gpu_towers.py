@@ -76,6 +76,23 @@ def test_timesformer_tower_vs_golden(fname, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("fname", golden_files("tower_v1_"))
+def test_timesformer_v1_tower_vs_golden(fname, dtype):
+    """model/timesformer_clip.py (older variant: global cls attention, no temporal_fc)."""
+    from vtc_amd import towers
+    case, g = load_golden(fname)
+    a = ARCH[case["arch"]]
+    sd = A.synth_visual(a, case["wseed"], nframes=case["nframes"], prefix="v.", variant="v1")
+    x = A.synth_pixels((case["B"], case["nframes"], 3, a.image_resolution, a.image_resolution), case["xseed"])
+    pv = towers.PackedVision(cuda_sd(sd), "v.", dtype)
+    assert pv.w.variant == 1
+    out = pv.forward(x.cuda()).cpu().numpy()
+    report(f"{fname} {dtype}", np.abs(unit(out) - unit(g["out"])).max(), tol_for(dtype, a.embed_dim))
+    if dtype == torch.float32:
+        assert np.abs(out - g["out"]).max() < 2e-5 * max(1.0, np.abs(g["out"]).max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_vit_and_text_towers_vs_oracle(dtype):
     from vtc_amd import towers
     for a, B, S in ((A.TINY, 5, 9), (A.VIT_B32, 3, 7)):

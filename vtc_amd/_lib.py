@@ -29,7 +29,7 @@ class BlockW(C.Structure):
 
 class VisionW(C.Structure):
     _fields_ = [("width", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("patch", C.c_int), ("grid", C.c_int),
-                ("embed_dim", C.c_int), ("nframes", C.c_int),
+                ("embed_dim", C.c_int), ("nframes", C.c_int), ("variant", C.c_int),
                 ("conv_w", C.c_void_p), ("class_embedding", C.c_void_p), ("pos", C.c_void_p), ("temporal", C.c_void_p),
                 ("ln_pre_g", C.c_void_p), ("ln_pre_b", C.c_void_p), ("ln_post_g", C.c_void_p), ("ln_post_b", C.c_void_p),
                 ("proj_t", C.c_void_p), ("blocks", C.POINTER(BlockW))]
@@ -60,6 +60,7 @@ SIGNATURES = {
     "vtc_cam_forward": (C.c_int, [C.POINTER(CamW), fp, fp, ip, C.c_int, C.c_int, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
     "vtc_normalize_rows": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),
     "vtc_mean_groups": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp]),
+    "vtc_segment_mean": (C.c_int, [fp, ip, fp, C.c_int, C.c_int, vp]),
     "vtc_similarity": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, vp]),
     "vtc_clip_loss_workspace_bytes": (C.c_size_t, [C.c_int]),
     "vtc_clip_loss": (C.c_int, [fp, C.c_int, fp, vp, C.c_size_t, vp]),

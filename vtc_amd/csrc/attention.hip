@@ -206,6 +206,43 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   }
 }
 
+// Global cls attention of model/timesformer_clip.py:81,158: the cls query of each item attends to ALL
+// T tokens of the item.  One wave per (item, head); lanes = the 64 head dimensions; scores via a
+// wave reduction per key, kept in LDS; output row = the item's cls row.  T up to 1024.
+template <typename T>
+__global__ __launch_bounds__(256) void cls_global_attn_kernel(const T *__restrict__ qkv, T *__restrict__ out, int n_items, int Ttok,
+                                                              int heads) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *sc = reinterpret_cast<float *>(lds_raw) + (size_t)wave * 1024;
+  int gw = blockIdx.x * 4 + wave;
+  const int total = n_items * heads;
+  const bool active = gw < total;
+  if (!active) gw = total - 1;
+  const int item = gw / heads, h = gw - item * heads;
+  const int W = heads * 64;
+  const T *base = qkv + (size_t)item * Ttok * 3 * W;
+  const float q = ElemOps<T>::load(base + h * 64 + lane) * 0.125f;
+  float mx = -INFINITY;
+  for (int j = 0; j < Ttok; ++j) {
+    const float s = wave_sum(q * ElemOps<T>::load(base + (size_t)j * 3 * W + W + h * 64 + lane));
+    if (lane == (j & 63)) sc[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = lane; j < Ttok; j += 64) {
+    const float e = expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float o = 0.f;
+  for (int j = 0; j < Ttok; ++j) o += sc[j] * ElemOps<T>::load(base + (size_t)j * 3 * W + 2 * W + h * 64 + lane);
+  if (active) ElemOps<T>::store(out + (size_t)item * Ttok * W + h * 64 + lane, o / sum);
+}
+
 template <typename T, int NT>
 int run(const AttnParams &p, hipStream_t stream) {
   constexpr int VS = 16 * NT + 4;
@@ -247,6 +284,20 @@ int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int 
   p.W = heads * 64;
   ProfScope prof(VTC_PROF_ATTN, 4.0 * L * L * 64 * (double)n_seq * heads, stream);
   return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
+}
+
+int launch_cls_global_attention(const void *qkv, void *out, int n_items, int Ttok, int heads, int dtype, hipStream_t stream) {
+  VTC_CHECK(Ttok <= 1024, "cls attention: %d tokens > 1024", Ttok);
+  const int total = n_items * heads;
+  ProfScope prof(VTC_PROF_ATTN, 4.0 * Ttok * 64 * (double)total, stream);
+  if (dtype == VTC_BF16)
+    hipLaunchKernelGGL((cls_global_attn_kernel<bf16_t>), dim3(cdiv(total, 4)), dim3(256), 4 * 1024 * sizeof(float), stream,
+                       (const bf16_t *)qkv, (bf16_t *)out, n_items, Ttok, heads);
+  else
+    hipLaunchKernelGGL((cls_global_attn_kernel<float>), dim3(cdiv(total, 4)), dim3(256), 4 * 1024 * sizeof(float), stream,
+                       (const float *)qkv, (float *)out, n_items, Ttok, heads);
+  VTC_LAUNCH_CHECK("cls_global_attention");
+  return 0;
 }
 
 extern "C" int vtc_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2,

@@ -99,6 +99,7 @@ struct GemmEpi {
   const float *pos = nullptr;
   const float *temporal = nullptr;
   int P = 0, F = 0, T = 0;
+  int frames_major = 0;      // 0: row item*T + 1 + n*F + t (timesformer_clip_alt.py:271-274); 1: item*T + 1 + t*P + n (timesformer_clip.py:392)
   // internal: squared-L2 epilogue (mode 4): out = rown[m] + coln[n] - 2 acc
   const float *rown = nullptr;
   const float *coln = nullptr;

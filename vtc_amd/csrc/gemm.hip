@@ -78,6 +78,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
   const int ldo = p.ldo;
   const bool vec_ok = (ldo & 3) == 0;
 
+  if (p.exp_arg > 0 && bid >= (nwg >> 1)) {   // diagnostic: phase-shift the second workgroup of each CU
+    for (int i = 0; i < p.exp_arg; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   stage_tile<AG>(p.A, m0, p.M, p.lda_bytes, 0, lds_base, wave_u, lane);
   stage_tile<WG>(p.W, n0, p.N, p.ldw_bytes, 0, lds_base + A_BYTES, wave_u, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -205,7 +208,8 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
             if (MODE == EPI_PATCH) {
               const int np = m % p.epi.P, ft = m / p.epi.P;
               const int tt = ft % p.epi.F, item = ft / p.epi.F;
-              orow = (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
+              orow = p.epi.frames_major ? (size_t)item * p.epi.T + 1 + (size_t)tt * p.epi.P + np
+                                        : (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
               const float4 p4 = *reinterpret_cast<const float4 *>(p.epi.pos + (size_t)(1 + np) * p.N + ncol0 + cc);
               v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
               if (p.epi.temporal) {
@@ -261,7 +265,8 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
           if (MODE == EPI_PATCH) {
             const int np = m % p.epi.P, ft = m / p.epi.P;
             const int tt = ft % p.epi.F, item = ft / p.epi.F;
-            orow = (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
+            orow = p.epi.frames_major ? (size_t)item * p.epi.T + 1 + (size_t)tt * p.epi.P + np
+                                      : (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
             posrow = p.epi.pos + (size_t)(1 + np) * p.N;
             if (p.epi.temporal) temprow = p.epi.temporal + (size_t)tt * p.N;
           }
@@ -385,6 +390,7 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
   p.lda_bytes = K * esz; p.ldw_bytes = K * esz;
   p.ldo = epi.ldo > 0 ? epi.ldo : N;
   p.MT = 0; p.NT = 0;
+  { static int ea = -1; if (ea < 0) { const char *e = getenv("VTC_GEMM_EXP"); ea = e ? atoi(e) : 0; } p.exp_arg = ea; }
   p.epi = epi;
   ProfScope prof(dtype == VTC_BF16 ? VTC_PROF_GEMM_BF16 : VTC_PROF_GEMM_F32, 2.0 * M * N * K, stream);
   return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);

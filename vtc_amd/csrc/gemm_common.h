@@ -33,6 +33,7 @@ struct GemmParams {
   int M, N, K;
   int lda_bytes, ldw_bytes, ldo;
   int MT, NT;
+  int exp_arg;   // diagnostics only (env VTC_GEMM_EXP), 0 in production
   GemmEpi epi;
 };
 

@@ -82,7 +82,27 @@ __global__ __launch_bounds__(256) void mean_groups_kernel(const float *__restric
   out[i] = s / group;
 }
 
+// out[i] = mean of rows [offsets[i], offsets[i+1]) (ragged groups: chunks of one video)
+__global__ __launch_bounds__(256) void segment_mean_kernel(const float *__restrict__ x, const int *__restrict__ offsets,
+                                                           float *__restrict__ out, int n, int d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * d) return;
+  const int gi = i / d, c = i - gi * d;
+  const int lo = offsets[gi], hi = offsets[gi + 1];
+  float s = 0.f;
+  for (int k = lo; k < hi; ++k) s += x[(size_t)k * d + c];
+  out[i] = s / (float)(hi - lo);
+}
+
 }  // namespace
+
+extern "C" int vtc_segment_mean(const float *x, const int *offsets, float *out, int n_groups, int d, void *stream) {
+  VTC_CHECK(n_groups > 0 && d > 0, "segment_mean: bad sizes");
+  hipLaunchKernelGGL(segment_mean_kernel, dim3(cdiv(n_groups * d, 256)), dim3(256), 0, (hipStream_t)stream, x, offsets, out,
+                     n_groups, d);
+  VTC_LAUNCH_CHECK("segment_mean");
+  return 0;
+}
 
 int launch_layernorm(const float *x, const float *g, const float *b, void *y, int rows, int width, int out_dtype,
                      const int *row_index, int row_mul, bool no_norm, hipStream_t stream) {

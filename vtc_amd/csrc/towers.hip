@@ -38,6 +38,7 @@ int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, 
 int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int F, int T, int W, hipStream_t stream);
 int launch_text_embed(const int64_t *ids, const float *tok, const float *pos, float *x, int *eot_row, int n_seq, int ctx, int W, int vocab, hipStream_t stream);
 int launch_cam_tokens(const float *main_f, const float *comm, const int64_t *comments, const float *mask_emb, float *X, int B, int nc, int ctx, int D, hipStream_t stream);
+int launch_cls_global_attention(const void *qkv, void *out, int n_items, int Ttok, int heads, int dtype, hipStream_t stream);
 int launch_cam_finalize(const float *Y, const float *lin, const float *main_f, float *out, int B, int Lc, int D, int init_from_avg, int act, float scale, hipStream_t stream);
 
 namespace {
@@ -104,7 +105,7 @@ VisionWs plan_vision(const vtc_vision_w *w, int n_items, int F, int dtype, void 
   v.x = (float *)b.take(rows * W * 4);
   v.h = b.take(rows * W * esz(dtype));
   v.big = b.take(big_elems * esz(dtype));
-  v.cls_tmp = (float *)b.take((size_t)n_items * F * W * 4);
+  v.cls_tmp = (float *)b.take((size_t)n_items * (F > P ? F : P) * W * 4);
   v.lnp = b.take((size_t)n_items * W * 4);
   v.total = b.off;
   return v;
@@ -147,7 +148,8 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
   VTC_CHECK(!tsf || F <= w->nframes, "vision_forward: %d frames > temporal_embed rows %d", F, w->nframes);
   VTC_CHECK(w->width == w->heads * 64, "vision_forward: head_dim must be 64 (width %d, heads %d)", w->width, w->heads);
   const int P = w->grid * w->grid, T = 1 + P * F, W = w->width;
-  VTC_CHECK(1 + P <= 80 && F <= 80, "vision_forward: sequence too long (1+P=%d, F=%d)", 1 + P, F);
+  VTC_CHECK(1 + P <= 80 && F < 80, "vision_forward: sequence too long (1+P=%d, F=%d)", 1 + P, F);
+  VTC_CHECK(w->variant == 0 || w->variant == 1, "vision_forward: unknown variant %d", w->variant);
   const int rows = n_items * T, res = w->grid * w->patch;
   VisionWs v = plan_vision(w, n_items, F, dtype, ws);
   VTC_CHECK(ws_bytes >= v.total, "vision_forward: workspace too small (%zu < %zu)", ws_bytes, v.total);
@@ -157,7 +159,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
   {
     GemmEpi e;
     e.mode = EPI_PATCH; e.out_dtype = VTC_F32; e.pos = w->pos; e.temporal = tsf ? w->temporal : nullptr;
-    e.P = P; e.F = F; e.T = T; e.ldo = W;
+    e.P = P; e.F = F; e.T = T; e.ldo = W; e.frames_major = w->variant == 1;
     RUN(launch_gemm(v.big, w->conv_w, nullptr, v.x, n_items * F * P, W, 3 * w->patch * w->patch, dtype, e, s));
   }
   RUN(launch_cls_rows(v.x, w->class_embedding, w->pos, n_items, T, W, s));
@@ -165,7 +167,23 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
 
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
-    if (tsf) {
+    if (tsf && w->variant == 1) {
+      // model/timesformer_clip.py:308-315: x += time(ln_time x); x += space(ln_1 x); x += mlp(ln_2 x).
+      // Tokens are (frames patches): row item*T + 1 + t*P + n (:392).  In both attentions the cls query
+      // attends to every token (:81,:158) -- cls_global_attention -- and a patch query to cls + its
+      // same-position frames (time, :161-185) or cls + its same-frame patches (space, :84-108): the
+      // generic kernel over [cls, ...] sequences whose own cls output is discarded into cls_tmp.
+      RUN(launch_layernorm(v.x, b.lnt_g, b.lnt_b, v.h, rows, W, dtype, nullptr, 1, false, s));
+      RUN(gemm(v.h, b.tqkv_w, b.tqkv_b, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+      RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * P, 1 + F, w->heads, 0, P, 0, T, 0, 1, P, dtype, s));
+      RUN(launch_cls_global_attention(v.big, v.h, n_items, T, w->heads, dtype, s));
+      RUN(gemm(v.h, b.tout_w, b.tout_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+      RUN(launch_layernorm(v.x, b.ln1_g, b.ln1_b, v.h, rows, W, dtype, nullptr, 1, false, s));
+      RUN(gemm(v.h, b.qkv_w, b.qkv_b, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+      RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, P, 1, dtype, s));
+      RUN(launch_cls_global_attention(v.big, v.h, n_items, T, w->heads, dtype, s));
+      RUN(gemm(v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+    } else if (tsf) {
       // temporal branch (timesformer_clip_alt.py:142-149): sequences = the F frames of one (item, patch)
       RUN(launch_layernorm(v.x, b.lnt_g, b.lnt_b, v.h, rows, W, dtype, nullptr, 1, false, s));
       RUN(gemm(v.h, b.tqkv_w, b.tqkv_b, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));

@@ -64,7 +64,7 @@ class NoForward(nn.Module):
 
 
 class BlockParams(NoForward):
-    def __init__(self, width: int, layers: int, timesformer: bool):
+    def __init__(self, width: int, layers: int, timesformer, v1: bool = False):
         super().__init__()
         attn_std = width ** -0.5
         proj_std = (width ** -0.5) * ((2 * layers) ** -0.5)
@@ -79,25 +79,29 @@ class BlockParams(NoForward):
         if timesformer:
             self.timeattn = AttentionParams(width, 0.02, 0.02)
             self.ln_time = nn.LayerNorm(width)
-            self.temporal_fc = nn.Linear(width, width)
-            nn.init.zeros_(self.temporal_fc.weight)   # timesformer_clip_alt.py:246-250
-            nn.init.zeros_(self.temporal_fc.bias)
+            if v1:   # model/timesformer_clip.py:264-269: time attention starts as a zero map
+                nn.init.zeros_(self.timeattn.in_proj_weight)
+                nn.init.ones_(self.timeattn.out_proj.weight)
+            else:
+                self.temporal_fc = nn.Linear(width, width)
+                nn.init.zeros_(self.temporal_fc.weight)   # timesformer_clip_alt.py:246-250
+                nn.init.zeros_(self.temporal_fc.bias)
 
 
 class Transformer(NoForward):
     """clip.model.Transformer(width, layers, heads) -- also the CAM (model/model.py:396)."""
 
-    def __init__(self, width: int, layers: int, heads: int, timesformer: bool = False):
+    def __init__(self, width: int, layers: int, heads: int, timesformer: bool = False, v1: bool = False):
         super().__init__()
         self.width, self.layers, self.heads = width, layers, heads
-        self.resblocks = nn.Sequential(*[BlockParams(width, layers, timesformer) for _ in range(layers)])
+        self.resblocks = nn.Sequential(*[BlockParams(width, layers, timesformer, v1) for _ in range(layers)])
 
 
 class VisionParams(NoForward):
     """Upstream VisionTransformer (nframes = 0) or the TimeSformer VisualTransformer
     (model/timesformer_clip_alt.py:203-250)."""
 
-    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, nframes=0):
+    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, nframes=0, v1=False):
         super().__init__()
         self.input_resolution, self.output_dim, self.nframes, self.width = input_resolution, output_dim, nframes, width
         self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)
@@ -107,7 +111,7 @@ class VisionParams(NoForward):
         if nframes:
             self.temporal_embed = nn.Parameter(torch.zeros(nframes, width))
         self.ln_pre = nn.LayerNorm(width)
-        self.transformer = Transformer(width, layers, heads, timesformer=bool(nframes))
+        self.transformer = Transformer(width, layers, heads, timesformer=bool(nframes), v1=v1)
         self.ln_post = nn.LayerNorm(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 
@@ -163,6 +167,21 @@ def make_timesformer_clip_vit_alt(nframes: int, model="ViT-B/32", clip_model: Cl
         cfg = clip_model.cfg if clip_model is not None else CONFIGS[model]
     t = VisionParams(cfg.image_resolution, cfg.vision_patch_size, cfg.vision_width, cfg.vision_layers,
                      cfg.vision_width // 64, cfg.embed_dim, nframes=nframes)
+    if clip_model is None:
+        clip_model = load(model, cfg=cfg)
+    missing, unexpected = t.load_state_dict(clip_model.visual.state_dict(), strict=False)
+    assert len(unexpected) == 0
+    assert all(("time" in x or "temporal" in x) for x in missing)
+    return t
+
+
+def make_timesformer_clip_vit(nframes: int, model="ViT-B/32", clip_model: ClipParams = None, cfg: ClipConfig = None):
+    """model/timesformer_clip.py:441-467: the older TimeSformer variant (cls attends globally, patches attend
+    to cls + same frame / same position; no temporal_fc), initialised from the CLIP ViT weights."""
+    if cfg is None:
+        cfg = clip_model.cfg if clip_model is not None else CONFIGS[model]
+    t = VisionParams(cfg.image_resolution, cfg.vision_patch_size, cfg.vision_width, cfg.vision_layers,
+                     cfg.vision_width // 64, cfg.embed_dim, nframes=nframes, v1=True)
     if clip_model is None:
         clip_model = load(model, cfg=cfg)
     missing, unexpected = t.load_state_dict(clip_model.visual.state_dict(), strict=False)

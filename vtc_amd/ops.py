@@ -106,6 +106,16 @@ def mean_groups(x: torch.Tensor, group: int) -> torch.Tensor:
     return out
 
 
+def segment_mean(x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+    """Mean of rows [offsets[g], offsets[g+1]) per group g (int32 offsets on the GPU)."""
+    x = _gpu(x, torch.float32, "x")
+    offsets = _gpu(offsets, torch.int32, "offsets")
+    n = offsets.numel() - 1
+    out = torch.empty(n, x.shape[1], dtype=torch.float32, device=x.device)
+    L.check(L.lib().vtc_segment_mean(x.data_ptr(), offsets.data_ptr(), out.data_ptr(), n, x.shape[1], _stream()), "vtc_segment_mean")
+    return out
+
+
 def similarity(v: torch.Tensor, t: torch.Tensor, logit_scale: torch.Tensor) -> torch.Tensor:
     v, t = _gpu(v, torch.float32, "v"), _gpu(t, torch.float32, "t")
     ls = _gpu(logit_scale.detach().reshape(1), torch.float32, "logit_scale")

@@ -69,6 +69,10 @@ def _pack_blocks(sd: SD, p: str, layers: int, dtype, keep: _Keep, timesformer: b
             b.lnt_g, b.lnt_b = keep.f32(sd[f"{q}.ln_time.weight"]), keep.f32(sd[f"{q}.ln_time.bias"])
             b.tqkv_w, b.tqkv_b = keep.mat(sd[f"{q}.timeattn.in_proj_weight"], dtype), keep.f32(sd[f"{q}.timeattn.in_proj_bias"])
             wo, bo = sd[f"{q}.timeattn.out_proj.weight"], sd[f"{q}.timeattn.out_proj.bias"]
+            if f"{q}.temporal_fc.weight" not in sd:      # model/timesformer_clip.py: no temporal_fc
+                b.tout_w, b.tout_b = keep.mat(wo, dtype), keep.f32(bo)
+                b.tfc_w, b.tfc_b = None, None
+                continue
             wf, bf = sd[f"{q}.temporal_fc.weight"], sd[f"{q}.temporal_fc.bias"]
             if fuse_temporal:
                 # temporal_fc(out_proj(a)) = (Wf Wo) a + (Wf bo + bf): one GEMM instead of two
@@ -95,6 +99,8 @@ class PackedVision:
         w.grid = int(round(math.sqrt(sd["positional_embedding"].shape[0] - 1)))
         w.embed_dim = sd["proj"].shape[1]
         w.nframes = sd["temporal_embed"].shape[0] if "temporal_embed" in sd else 0
+        # variant 1 = model/timesformer_clip.py (frames-major tokens, cls attends globally, no temporal_fc)
+        w.variant = 1 if (w.nframes and not any("temporal_fc" in k for k in sd)) else 0
         w.conv_w = k.mat(conv.reshape(w.width, -1), dtype)
         w.class_embedding, w.pos = k.f32(sd["class_embedding"]), k.f32(sd["positional_embedding"])
         w.temporal = k.f32(sd["temporal_embed"]) if w.nframes else None

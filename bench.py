@@ -191,6 +191,25 @@ def main():
 
     extra = {}
     if not args.no_extra:
+        # ---- config 2 again with the ragged text tower (tokens after EOT are not computed; identical
+        # outputs -- tests/test_gpu_towers.py::test_ragged_text_tower_equals_dense).  Reported apart from
+        # `value`, which does exactly the reference's work (all 77 positions of every sequence).
+        from vtc_amd import towers as _tw
+        _tw.TEXT_RAGGED = True
+        for _ in range(2):
+            step2()
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        kr = max(2, args.steps // 2)
+        for _ in range(kr):
+            step2()
+        barrier_sync(world)
+        dtr = max_over_ranks(time.perf_counter() - t0, world, device)
+        _tw.TEXT_RAGGED = False
+        n_tok = int((torch.cat([title, comments.reshape(-1, 77)]).argmax(-1) + 1).sum().item())
+        extra["config2_ragged_text_pairs_per_s"] = round(world * B * kr / dtr, 1)
+        extra["config2_ragged_text_ms_per_step"] = round(1e3 * dtr / kr, 3)
+        extra["config2_ragged_text_tokens_computed_frac"] = round(n_tok / (6 * B * 77), 4)
         # ---- config 3: 8-frame TimeSformer video + title + 5 comments ------------------------
         del m2
         torch.cuda.empty_cache()

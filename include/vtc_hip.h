@@ -111,6 +111,13 @@ size_t vtc_text_workspace_bytes(const vtc_text_w *w, int n_seq, int dtype);
 int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_seq, float *out, void *ws, size_t ws_bytes,
                      int dtype, void *stream);
 
+/* Same tower on a RAGGED batch: only tokens 0..EOT of each sequence are computed.  seq_offsets: int32
+ * [n_seq+1] exclusive prefix sums of (argmax(ids[s]) + 1); total_rows = seq_offsets[n_seq] (host value).
+ * Outputs are identical to vtc_text_forward: under the causal mask nothing after EOT reaches the EOT row. */
+size_t vtc_text_ragged_workspace_bytes(const vtc_text_w *w, int n_seq, int total_rows, int dtype);
+int vtc_text_forward_ragged(const vtc_text_w *w, const int64_t *ids, int n_seq, const int *seq_offsets, int total_rows,
+                            float *out, void *ws, size_t ws_bytes, int dtype, void *stream);
+
 /* Replaces PretrainedCLIPBase._load_comment_features' masking + _adapt_feature
  * (model/model.py:207-214, 141-205), eval semantics.
  * main: [B,D] fp32; comm_feats: [B*nc, D] fp32 = encode_text(comments.reshape(B*nc, ctx));

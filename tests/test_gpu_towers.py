@@ -114,6 +114,29 @@ def test_vit_and_text_towers_vs_oracle(dtype):
             report(f"ViT bf16-pixels {a.vision_width}", np.abs(unit(out_vb) - unit(ref_v)).max(), 2 * tol_for(dtype, a.embed_dim))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ragged_text_tower_equals_dense(dtype):
+    """Tokens after EOT cannot reach the EOT feature through a causal tower: the ragged path (only tokens
+    0..EOT computed) must reproduce the dense path and the oracle, including 2-token empty strings, full-length
+    rows and rows without any EOT (argmax = position of the largest id)."""
+    from vtc_amd import towers
+    a = A.VIT_B32
+    sd = A.synth_text(a, 52, prefix="model.")
+    txt = A.synth_tokens(37, a, 54, empty_frac=0.25)
+    txt[3, 1:76] = torch.randint(1, A.SOT, (75,)); txt[3, 76] = A.EOT          # full length
+    txt[5] = torch.randint(1, 1000, (77,)); txt[5, 40] = 48000                 # no EOT: argmax picks position 40
+    pt = towers.PackedText(cuda_sd(sd), "model.", dtype, heads=a.transformer_heads)
+    dense = pt.forward(txt.cuda(), ragged=False).cpu().numpy()
+    ragged = pt.forward(txt.cuda(), ragged=True).cpu().numpy()
+    ref = CR.encode_text(txt, sd, a, "model.").numpy()
+    if dtype == torch.float32:
+        assert np.abs(ragged - dense).max() < 2e-5 * np.abs(dense).max()
+        assert np.abs(unit(ragged) - unit(ref)).max() < 1e-5
+    else:
+        report_text("ragged text bf16", unit(ragged), unit(ref), dtype, a.embed_dim)
+        assert np.abs(unit(ragged) - unit(dense)).max() < 1.5e-3
+
+
 def test_identity_at_init_timesformer_equals_vit_gpu():
     """SURVEY 4 known answer: temporal_fc = 0, temporal_embed = 0, identical frames => TimeSformer == ViT."""
     from vtc_amd import towers

@@ -56,6 +56,8 @@ SIGNATURES = {
     "vtc_vision_forward": (C.c_int, [C.POINTER(VisionW), vp, C.c_int, C.c_int, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
     "vtc_text_workspace_bytes": (C.c_size_t, [C.POINTER(TextW), C.c_int, C.c_int]),
     "vtc_text_forward": (C.c_int, [C.POINTER(TextW), ip, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
+    "vtc_text_ragged_workspace_bytes": (C.c_size_t, [C.POINTER(TextW), C.c_int, C.c_int, C.c_int]),
+    "vtc_text_forward_ragged": (C.c_int, [C.POINTER(TextW), ip, C.c_int, ip, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
     "vtc_cam_workspace_bytes": (C.c_size_t, [C.POINTER(CamW), C.c_int, C.c_int, C.c_int]),
     "vtc_cam_forward": (C.c_int, [C.POINTER(CamW), fp, fp, ip, C.c_int, C.c_int, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
     "vtc_normalize_rows": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),

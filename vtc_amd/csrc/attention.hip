@@ -29,6 +29,7 @@ struct AttnParams {
   float *cls_out;
   int n_seq, L, heads, causal;
   int s2, a0, a1, a2, a3, pstride;
+  const int *seq_offsets;   // ragged mode: sequence s = rows [seq_offsets[s], seq_offsets[s+1]) (overrides the affine map)
   int W;  // model width = heads * 64
 };
 
@@ -70,9 +71,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   if (!active) gw = total - 1;              // keep every wave alive for the barrier; stores are predicated
   const int s = gw / p.heads, h = gw - s * p.heads;
   const int s_hi = s / p.s2, s_lo = s - s_hi * p.s2;
-  const long base = (long)s_hi * p.a1 + (long)s_lo * p.a2 + p.a0;
+  const long base = p.seq_offsets ? (long)p.seq_offsets[s] : (long)s_hi * p.a1 + (long)s_lo * p.a2 + p.a0;
   const int first = 1 + s_lo * p.a3;
-  const int L = p.L;
+  const int L = p.seq_offsets ? p.seq_offsets[s + 1] - p.seq_offsets[s] : p.L;
   const size_t ld = (size_t)3 * p.W * SZ;   // qkv row bytes
   auto row_of = [&](int tok) -> long { return tok == 0 ? base : base + first + (long)(tok - 1) * p.pstride; };
 
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (p.causal && kt > qt) {            // every key of this tile is in the future of every query
+      if ((p.causal && kt > qt) || kt * 16 >= L) {   // tile entirely in the future of every query, or past the sequence end
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc[kt][r] = -INFINITY;
         continue;
@@ -281,8 +282,23 @@ int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int 
   p.qkv = (const char *)qkv; p.out = (char *)out; p.cls_out = cls_out;
   p.n_seq = n_seq; p.L = L; p.heads = heads; p.causal = causal;
   p.s2 = s2; p.a0 = a0; p.a1 = a1; p.a2 = a2; p.a3 = a3; p.pstride = pstride;
+  p.seq_offsets = nullptr;
   p.W = heads * 64;
   ProfScope prof(VTC_PROF_ATTN, 4.0 * L * L * 64 * (double)n_seq * heads, stream);
+  return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
+}
+
+// Ragged batch: sequence s occupies the packed rows [seq_offsets[s], seq_offsets[s+1]); max_L bounds the lengths.
+int launch_attention_ragged(const void *qkv, void *out, int n_seq, int max_L, int heads, int causal, const int *seq_offsets,
+                            double flops, int dtype, hipStream_t stream) {
+  VTC_CHECK(n_seq > 0 && max_L > 0 && heads > 0 && seq_offsets, "attention_ragged: bad arguments");
+  AttnParams p;
+  p.qkv = (const char *)qkv; p.out = (char *)out; p.cls_out = nullptr;
+  p.n_seq = n_seq; p.L = max_L; p.heads = heads; p.causal = causal;
+  p.s2 = 1; p.a0 = 0; p.a1 = 0; p.a2 = 0; p.a3 = 0; p.pstride = 1;
+  p.seq_offsets = seq_offsets;
+  p.W = heads * 64;
+  ProfScope prof(VTC_PROF_ATTN, flops, stream);
   return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
 }
 

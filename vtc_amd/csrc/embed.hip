@@ -67,6 +67,32 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t *__restri
   }
 }
 
+// Ragged text batch: only the tokens up to and including EOT are materialised (a causal tower never
+// lets a later position influence the EOT feature).  Row seq_offsets[s] + p <- token p of sequence s.
+__global__ __launch_bounds__(256) void text_embed_ragged_kernel(const int64_t *__restrict__ ids, const float *__restrict__ tok,
+                                                                const float *__restrict__ pos, const int *__restrict__ seq_offsets,
+                                                                float *__restrict__ x, int n_seq, int ctx, int W, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);          // dense (s, p) index
+  if (r >= n_seq * ctx) return;
+  const int s = r / ctx, p = r - s * ctx;
+  const int lo = seq_offsets[s], len = seq_offsets[s + 1] - lo;
+  if (p >= len) return;
+  long id = ids[r];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const float *tr = tok + (size_t)id * W, *pr = pos + (size_t)p * W;
+  float *xr = x + (size_t)(lo + p) * W;
+  for (int c = lane * 4; c < W; c += 256) {
+    const float4 a = *reinterpret_cast<const float4 *>(tr + c), b = *reinterpret_cast<const float4 *>(pr + c);
+    *reinterpret_cast<float4 *>(xr + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void last_row_kernel(const int *__restrict__ seq_offsets, int *__restrict__ rows, int n_seq) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < n_seq) rows[s] = seq_offsets[s + 1] - 1;            // the EOT row of sequence s
+}
+
 // eot_row[s] = s*ctx + argmax_p ids[s,p] (first maximum, as torch.argmax)
 __global__ __launch_bounds__(256) void eot_index_kernel(const int64_t *__restrict__ ids, int *__restrict__ eot_row, int n_seq, int ctx) {
   const int s = blockIdx.x * 256 + threadIdx.x;
@@ -226,6 +252,17 @@ int launch_text_embed(const int64_t *ids, const float *tok, const float *pos, fl
   hipLaunchKernelGGL(text_embed_kernel, dim3(cdiv(n_seq * ctx, 4)), dim3(256), 0, stream, ids, tok, pos, x, n_seq * ctx, ctx, W, vocab);
   hipLaunchKernelGGL(eot_index_kernel, dim3(cdiv(n_seq, 256)), dim3(256), 0, stream, ids, eot_row, n_seq, ctx);
   VTC_LAUNCH_CHECK("text_embed");
+  return 0;
+}
+
+int launch_text_embed_ragged(const int64_t *ids, const float *tok, const float *pos, const int *seq_offsets, float *x, int *eot_row,
+                             int n_seq, int ctx, int W, int vocab, int total_rows, hipStream_t stream) {
+  VTC_CHECK(W % 4 == 0, "text_embed: width %d", W);
+  ProfScope prof(VTC_PROF_EMBED, (double)total_rows * W * 12, stream);
+  hipLaunchKernelGGL(text_embed_ragged_kernel, dim3(cdiv(n_seq * ctx, 4)), dim3(256), 0, stream, ids, tok, pos, seq_offsets, x, n_seq,
+                     ctx, W, vocab);
+  hipLaunchKernelGGL(last_row_kernel, dim3(cdiv(n_seq, 256)), dim3(256), 0, stream, seq_offsets, eot_row, n_seq);
+  VTC_LAUNCH_CHECK("text_embed_ragged");
   return 0;
 }
 

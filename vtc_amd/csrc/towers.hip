@@ -37,6 +37,8 @@ int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_f
 int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, int T, int W, hipStream_t stream);
 int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int F, int T, int W, hipStream_t stream);
 int launch_text_embed(const int64_t *ids, const float *tok, const float *pos, float *x, int *eot_row, int n_seq, int ctx, int W, int vocab, hipStream_t stream);
+int launch_text_embed_ragged(const int64_t *ids, const float *tok, const float *pos, const int *seq_offsets, float *x, int *eot_row, int n_seq, int ctx, int W, int vocab, int total_rows, hipStream_t stream);
+int launch_attention_ragged(const void *qkv, void *out, int n_seq, int max_L, int heads, int causal, const int *seq_offsets, double flops, int dtype, hipStream_t stream);
 int launch_cam_tokens(const float *main_f, const float *comm, const int64_t *comments, const float *mask_emb, float *X, int B, int nc, int ctx, int D, hipStream_t stream);
 int launch_cls_global_attention(const void *qkv, void *out, int n_items, int Ttok, int heads, int dtype, hipStream_t stream);
 int launch_cam_finalize(const float *Y, const float *lin, const float *main_f, float *out, int B, int Lc, int D, int init_from_avg, int act, float scale, hipStream_t stream);
@@ -236,6 +238,39 @@ extern "C" int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_s
   }
   // ln_final on the EOT row only (LayerNorm is per-row, so gathering first is identical), then @ text_projection
   // (always fp32, as for the vision tower)
+  RUN(launch_layernorm(t.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, VTC_F32, t.eot, 1, false, s));
+  RUN(gemm(t.lnp, w->proj_t, nullptr, out, n_seq, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));
+  return 0;
+}
+
+// Ragged variant: only the rows [seq_offsets[s], seq_offsets[s+1]) = tokens 0..EOT of each sequence are
+// computed (total_rows of them, known to the host).  Identical outputs: under the causal mask no token
+// after EOT can influence the EOT feature, and every other op of the tower is per-row.
+extern "C" size_t vtc_text_ragged_workspace_bytes(const vtc_text_w *w, int n_seq, int total_rows, int dtype) {
+  return plan_text(total_rows, n_seq, w->width, dtype, nullptr).total;
+}
+
+extern "C" int vtc_text_forward_ragged(const vtc_text_w *w, const int64_t *ids, int n_seq, const int *seq_offsets, int total_rows,
+                                       float *out, void *ws, size_t ws_bytes, int dtype, void *stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  VTC_CHECK(w && ids && seq_offsets && out && ws, "text_forward_ragged: null argument");
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "text_forward_ragged: bad dtype %d", dtype);
+  VTC_CHECK(n_seq > 0 && total_rows >= n_seq && total_rows <= n_seq * w->ctx, "text_forward_ragged: n_seq=%d total_rows=%d", n_seq, total_rows);
+  VTC_CHECK(w->ctx <= 80 && w->width == w->heads * 64, "text_forward_ragged: unsupported shape");
+  const int W = w->width, rows = total_rows;
+  TextWs t = plan_text(rows, n_seq, W, dtype, ws);
+  VTC_CHECK(ws_bytes >= t.total, "text_forward_ragged: workspace too small (%zu < %zu)", ws_bytes, t.total);
+  RUN(launch_text_embed_ragged(ids, w->tok_emb, w->pos, seq_offsets, t.x, t.eot, n_seq, w->ctx, W, w->vocab, rows, s));
+  // attention work estimate for the profiler: mean-square length ~ (rows/n_seq)^2 is a lower bound; report rows*avg
+  const double avgL = (double)rows / n_seq;
+  for (int l = 0; l < w->layers; ++l) {
+    const vtc_block_w &b = w->blocks[l];
+    RUN(launch_layernorm(t.x, b.ln1_g, b.ln1_b, t.h, rows, W, dtype, nullptr, 1, false, s));
+    RUN(gemm(t.h, b.qkv_w, b.qkv_b, t.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+    RUN(launch_attention_ragged(t.big, t.h, n_seq, w->ctx, w->heads, 1, seq_offsets, 4.0 * avgL * rows * 64 * w->heads, dtype, s));
+    RUN(gemm(t.h, b.out_w, b.out_b, t.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+    RUN(mlp_part(b, t.x, t.h, t.big, rows, W, dtype, s));
+  }
   RUN(launch_layernorm(t.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, VTC_F32, t.eot, 1, false, s));
   RUN(gemm(t.lnp, w->proj_t, nullptr, out, n_seq, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));
   return 0;

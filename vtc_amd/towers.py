@@ -22,6 +22,9 @@ SD = Dict[str, torch.Tensor]
 
 # items per vision-tower launch; 0 = the whole batch in one pass
 VISION_CHUNK = 0
+# Text tower on ragged batches: compute only tokens 0..EOT of every sequence (identical outputs under the
+# causal mask).  Off by default: the dense path does exactly the work the reference does.
+TEXT_RAGGED = False
 _WS: Dict[torch.device, torch.Tensor] = {}
 
 
@@ -153,7 +156,7 @@ class PackedText:
         w.blocks = self.blocks
         self.w = w
 
-    def forward(self, ids: torch.Tensor) -> torch.Tensor:
+    def forward(self, ids: torch.Tensor, ragged: Optional[bool] = None) -> torch.Tensor:
         """ids [S, ctx] int64 -> [S, embed] fp32."""
         w = self.w
         ids = ops._gpu(ids, torch.int64, "token ids")
@@ -162,6 +165,17 @@ class PackedText:
         S = ids.shape[0]
         out = torch.empty(S, w.embed_dim, dtype=torch.float32, device=ids.device)
         lib = L.lib()
+        if TEXT_RAGGED if ragged is None else ragged:
+            # lengths = position of the first maximum id (EOT) + 1; the prefix sum and its total are host
+            # bookkeeping (one small D2H), the tower itself runs on the packed rows
+            lens = ids.argmax(dim=-1).to(torch.int32) + 1
+            offsets = torch.zeros(S + 1, dtype=torch.int32, device=ids.device)
+            offsets[1:] = torch.cumsum(lens, 0)
+            total = int(offsets[-1].item())
+            ws = _ws(lib.vtc_text_ragged_workspace_bytes(C.byref(w), S, total, self.code), ids.device)
+            L.check(lib.vtc_text_forward_ragged(C.byref(w), ids.data_ptr(), S, offsets.data_ptr(), total, out.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), self.code, ops._stream()), "vtc_text_forward_ragged")
+            return out
         ws = _ws(lib.vtc_text_workspace_bytes(C.byref(w), S, self.code), ids.device)
         L.check(lib.vtc_text_forward(C.byref(w), ids.data_ptr(), S, out.data_ptr(), ws.data_ptr(), ws.numel(), self.code,
                                      ops._stream()), "vtc_text_forward")

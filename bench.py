@@ -194,6 +194,34 @@ def main():
         # ---- config 2 again with the ragged text tower (tokens after EOT are not computed; identical
         # outputs -- tests/test_gpu_towers.py::test_ragged_text_tower_equals_dense).  Reported apart from
         # `value`, which does exactly the reference's work (all 77 positions of every sequence).
+        # the same dense step without the per-launch HIP events, eager and replayed from a HIP graph
+        kr = max(2, args.steps // 2)
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for _ in range(kr):
+            step2()
+        barrier_sync(world)
+        extra["config2_ms_per_step_no_events"] = round(1e3 * max_over_ranks(time.perf_counter() - t0, world, device) / kr, 3)
+        try:
+            gstream = torch.cuda.Stream()
+            gstream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(gstream):
+                step2()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=gstream):
+                    gout = step2()
+            torch.cuda.current_stream().wait_stream(gstream)
+            graph.replay()
+            barrier_sync(world)
+            t0 = time.perf_counter()
+            for _ in range(kr):
+                graph.replay()
+            barrier_sync(world)
+            extra["config2_ms_per_step_hipgraph"] = round(1e3 * max_over_ranks(time.perf_counter() - t0, world, device) / kr, 3)
+            extra["config2_hipgraph_matches_eager"] = bool(torch.equal(gout[2], out[2]))
+            del graph
+        except Exception as e:  # graph capture is an optimisation, never a requirement
+            extra["config2_hipgraph_error"] = repr(e)[:200]
         from vtc_amd import towers as _tw
         _tw.TEXT_RAGGED = True
         for _ in range(2):

@@ -39,9 +39,13 @@ using namespace vtcgemm;
 namespace {
 
 // WM x WN waves, each owning TM x TN MFMA tiles of 16x16.
-template <typename T, int MODE, typename OutT, int WM, int WN, int TM, int TN>
+// NSTAGE LDS buffers: 2 = wait for the next slab at the end of every K-step; 3 = the LDS-DMA of slab
+// t+2 is issued at step t and only slab t+1 is waited for (counted s_waitcnt vmcnt(G)), so two slabs are
+// always in flight and the DMA latency has two K-steps of matrix work to hide under.
+template <typename T, int MODE, typename OutT, int WM, int WN, int TM, int TN, int NSTAGE>
 __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p) {
   constexpr int NW = WM * WN, BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int G = BM / 8 / NW + BN / 8 / NW;          // LDS-DMA instructions per wave per slab
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
   constexpr int AG = BM / 8 / NW, WG = BN / 8 / NW;
   constexpr int SUPER = SUPER_ROWS / BM;
@@ -81,30 +85,35 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
   if (p.exp_arg > 0 && bid >= (nwg >> 1)) {   // diagnostic: phase-shift the second workgroup of each CU
     for (int i = 0; i < p.exp_arg; ++i) __builtin_amdgcn_s_sleep(16);
   }
-  stage_tile<AG>(p.A, m0, p.M, p.lda_bytes, 0, lds_base, wave_u, lane);
-  stage_tile<WG>(p.W, n0, p.N, p.ldw_bytes, 0, lds_base + A_BYTES, wave_u, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int cur = 0;                                   // LDS buffer of the slab being multiplied
+  int m0n = 0, n0n = 0;
+  bool has_next = li + nb_x < nt_x;
+  if (has_next) decode(start_x + li + nb_x, m0n, n0n);
+  // stage the slab that is `d` K-steps after step t of the current tile (it may belong to the next tile)
+  auto stage_ahead = [&](int t, int d) -> bool {
+    const unsigned dst = lds_base + ((cur + d) % NSTAGE) * STAGE;
+    const int k = t + d;
+    if (k < ksteps) {
+      stage_tile<AG>(p.A, m0, p.M, p.lda_bytes, k * ROWB, dst, wave_u, lane);
+      stage_tile<WG>(p.W, n0, p.N, p.ldw_bytes, k * ROWB, dst + A_BYTES, wave_u, lane);
+      return true;
+    }
+    if (has_next) {                              // rides under the last K-steps of this tile
+      stage_tile<AG>(p.A, m0n, p.M, p.lda_bytes, (k - ksteps) * ROWB, dst, wave_u, lane);
+      stage_tile<WG>(p.W, n0n, p.N, p.ldw_bytes, (k - ksteps) * ROWB, dst + A_BYTES, wave_u, lane);
+      return true;
+    }
+    return false;
+  };
+  stage_ahead(0, 0);
+  if (NSTAGE == 3 && stage_ahead(0, 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int cur = 0;
 
   while (true) {
-    const int li_next = li + nb_x;
-    const bool has_next = li_next < nt_x;
-    int m0n = 0, n0n = 0;
-    if (has_next) decode(start_x + li_next, m0n, n0n);
 
-    // Per-column addend of the epilogue (bias, or |g|^2 for the distance epilogue), fetched now so
-    // its latency hides under the K loop.  Interior tiles only; edge tiles use the generic path.
+    // Interior tiles (every tile of the towers) take the transposed fast epilogue; edge tiles the generic one.
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && vec_ok;
-    float4 pre4[TN];
-    {
-      const float *colv = MODE == EPI_L2DIST ? p.epi.coln : p.bias;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        pre4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (interior && colv) pre4[j] = *reinterpret_cast<const float4 *>(colv + n0 + (wc * TN + j) * 16 + g * 4);
-      }
-    }
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -113,32 +122,43 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
       for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int t = 0; t < ksteps; ++t) {
-      const unsigned nxt = lds_base + (cur ^ 1) * STAGE;
-      if (t + 1 < ksteps) {
-        stage_tile<AG>(p.A, m0, p.M, p.lda_bytes, (t + 1) * ROWB, nxt, wave_u, lane);
-        stage_tile<WG>(p.W, n0, p.N, p.ldw_bytes, (t + 1) * ROWB, nxt + A_BYTES, wave_u, lane);
-      } else if (has_next) {                   // first K-slab of the next tile rides under this step
-        stage_tile<AG>(p.A, m0n, p.M, p.lda_bytes, 0, nxt, wave_u, lane);
-        stage_tile<WG>(p.W, n0n, p.N, p.ldw_bytes, 0, nxt + A_BYTES, wave_u, lane);
-      }
-      const char *as = lds + cur * STAGE;
-      const char *ws = as + A_BYTES;
+      const bool issued = stage_ahead(t, NSTAGE - 1);
+      // Fragment reads are inline-asm ds_read_b128 with hand-counted lgkmcnt waits: hipcc, left to itself,
+      // keeps ONE A-fragment register in this loop (read -> lgkmcnt(0) -> 4 MFMA -> read ...), which parks
+      // every wave on an LDS round trip per 4 MFMAs (SQ_WAIT_ANY 42 %, MFMA busy 44 %).  Here the read of
+      // fragment i+1 is in flight while the MFMAs of fragment i issue (LDS returns in order, so
+      // lgkmcnt(1) == "everything but the youngest read has landed").
+      const unsigned a_addr = lds_base + cur * STAGE + arow;
+      const unsigned w_addr = lds_base + cur * STAGE + A_BYTES + wrow;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const int coff = ((4 * ks + g) ^ swz) << 4;
-        uint4 af[TM], wf[TN];
+        const unsigned coff = ((4 * ks + g) ^ swz) << 4;
+        u32x4 wf[TN], aE, aO;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const uint4 *>(ws + wrow + j * 16 * ROWB + coff);
+        for (int j = 0; j < TN; ++j) lds_read16(wf[j], w_addr + coff, j * 16 * ROWB);
+        lds_read16(aE, a_addr + coff, 0);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4 *>(as + arow + i * 16 * ROWB + coff);
+        for (int i = 0; i < TM; i += 2) {
+          lds_read16(aO, a_addr + coff, (i + 1) * 16 * ROWB);
+          if (i == 0) lgkm_wait_frags<1>(aE, wf);
+          else lgkm_wait<1>(aE);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int j = 0; j < TN; ++j) Mma<T>::run(wf[j], aE, acc[i][j]);
+          if (i + 2 < TM) {
+            lds_read16(aE, a_addr + coff, (i + 2) * 16 * ROWB);
+            lgkm_wait<1>(aO);
+          } else {
+            lgkm_wait<0>(aO);
+          }
 #pragma unroll
-          for (int j = 0; j < TN; ++j) Mma<T>::run(wf[j], af[i], acc[i][j]);
+          for (int j = 0; j < TN; ++j) Mma<T>::run(wf[j], aO, acc[i + 1][j]);
+        }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the next slab must have landed; with 3 stages the slab issued in this step may stay in flight
+      if (NSTAGE == 3 && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      cur ^= 1;
+      cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
 
     // ---- epilogue: lane holds out[m][n..n+3], m = m0 + 16 (wr TM + i) + (lane & 15),
@@ -153,14 +173,31 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
       // (the other stage already holds the next tile's first slab) and writes whole rows: every
       // store instruction covers 4 (fp32) or 8 (bf16) full 256 / 128-byte row segments.
       constexpr int TS = 68;                                   // padded row stride (floats): conflict-free b128 writes
-      float *tr = reinterpret_cast<float *>(lds + (cur ^ 1) * STAGE + wave * (STAGE / NW));   // 8 KiB per wave
+      float *tr = reinterpret_cast<float *>(lds + ((cur + NSTAGE - 1) % NSTAGE) * STAGE + wave * (STAGE / NW));   // >= 6 KiB per wave
       const int l15 = lane & 15;
       const int ncol0 = n0 + wc * TN * 16;
-      float rn[TM];
-      if (MODE == EPI_L2DIST) {
+      // column addend (bias, or |g|^2 of the distance epilogue) for the columns this lane writes back
+      const float *colv = MODE == EPI_L2DIST ? p.epi.coln : p.bias;
+      float cadd[8];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) rn[i] = p.epi.rown[m0 + (wr * TM + i) * 16 + l15];
+      for (int e = 0; e < 8; ++e) cadd[e] = 0.f;
+      if (colv) {
+        if constexpr (sizeof(OutT) == 4) {
+          const float4 c4 = *reinterpret_cast<const float4 *>(colv + ncol0 + l15 * 4);
+          cadd[0] = c4.x; cadd[1] = c4.y; cadd[2] = c4.z; cadd[3] = c4.w;
+        } else {
+          const float4 c0 = *reinterpret_cast<const float4 *>(colv + ncol0 + (lane & 7) * 8);
+          const float4 c1 = *reinterpret_cast<const float4 *>(colv + ncol0 + (lane & 7) * 8 + 4);
+          cadd[0] = c0.x; cadd[1] = c0.y; cadd[2] = c0.z; cadd[3] = c0.w;
+          cadd[4] = c1.x; cadd[5] = c1.y; cadd[6] = c1.z; cadd[7] = c1.w;
+        }
       }
+      auto fin = [&](float a, float add, float rnv) -> float {
+        float v = MODE == EPI_L2DIST ? rnv + add - 2.0f * a : a + add;
+        if (MODE == VTC_EPI_GELU) v = quick_gelu<sizeof(T) == 4>(v);
+        if (MODE == EPI_SCALE) v *= scale;
+        return v;
+      };
       // residual mode: the x rows of pass i+1 are fetched while pass i is transposed and stored
       auto x_ptr = [&](int i, int k) -> float * {
         const int m = m0 + (wr * TM + i) * 16 + (lane >> 4) + 4 * k;
@@ -180,16 +217,8 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
         // 1. registers -> LDS: final fp32 values in [16 rows][64 cols]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          const float a4[4] = {pre4[j].x, pre4[j].y, pre4[j].z, pre4[j].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (MODE == EPI_L2DIST) v[e] = rn[i] + a4[e] - 2.0f * v[e];
-            else v[e] += a4[e];
-            if (MODE == VTC_EPI_GELU) v[e] = quick_gelu<sizeof(T) == 4>(v[e]);
-            if (MODE == EPI_SCALE) v[e] *= scale;
-          }
-          *reinterpret_cast<float4 *>(tr + l15 * TS + 16 * j + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4 *>(tr + l15 * TS + 16 * j + 4 * g) =
+              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -202,6 +231,10 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
             const int r = (lane >> 4) + 4 * k, cc = l15 * 4;
             float4 v = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
             const int m = mrow0 + r;
+            {
+              const float rnv = MODE == EPI_L2DIST ? p.epi.rown[m] : 0.f;
+              v.x = fin(v.x, cadd[0], rnv); v.y = fin(v.y, cadd[1], rnv); v.z = fin(v.z, cadd[2], rnv); v.w = fin(v.w, cadd[3], rnv);
+            }
             size_t orow = (size_t)m;
             bool live = true;
             if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && (m % p.epi.skip_mod) == 0) live = false;
@@ -231,8 +264,10 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             const int r = (lane >> 3) + 8 * k, cc = (lane & 7) * 8;
-            const float4 v0 = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
-            const float4 v1 = *reinterpret_cast<const float4 *>(tr + r * TS + cc + 4);
+            float4 v0 = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
+            float4 v1 = *reinterpret_cast<const float4 *>(tr + r * TS + cc + 4);
+            v0.x = fin(v0.x, cadd[0], 0.f); v0.y = fin(v0.y, cadd[1], 0.f); v0.z = fin(v0.z, cadd[2], 0.f); v0.w = fin(v0.w, cadd[3], 0.f);
+            v1.x = fin(v1.x, cadd[4], 0.f); v1.y = fin(v1.y, cadd[5], 0.f); v1.z = fin(v1.z, cadd[6], 0.f); v1.w = fin(v1.w, cadd[7], 0.f);
             uint4 pk;
             pk.x = (unsigned)f2bf(v0.x) | ((unsigned)f2bf(v0.y) << 16);
             pk.y = (unsigned)f2bf(v0.z) | ((unsigned)f2bf(v0.w) << 16);
@@ -294,7 +329,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
     }
 
     if (!has_next) break;
-    li = li_next; m0 = m0n; n0 = n0n;
+    li += nb_x; m0 = m0n; n0 = n0n;
+    has_next = li + nb_x < nt_x;
+    if (has_next) decode(start_x + li + nb_x, m0n, n0n);
   }
 }
 
@@ -313,21 +350,21 @@ int num_cus() {
 }  // namespace vtcgemm
 namespace {
 
-template <typename T, int MODE, typename OutT, int WM, int WN, int TM, int TN>
+template <typename T, int MODE, typename OutT, int WM, int WN, int TM, int TN, int NSTAGE>
 int run(GemmParams p, hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT_ = WM * WN * 64;
   p.MT = cdiv(p.M, BM); p.NT = cdiv(p.N, BN);
   const int ntiles = p.MT * p.NT;
-  const size_t shmem = (size_t)2 * (BM + BN) * ROWB;
+  const size_t shmem = (size_t)NSTAGE * (BM + BN) * ROWB;
   const int wg_per_cu = shmem > 80 * 1024 ? 1 : 2;
   const int grid = min(ntiles, num_cus() * wg_per_cu);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<T, MODE, OutT, WM, WN, TM, TN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<T, MODE, OutT, WM, WN, TM, TN, NSTAGE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<T, MODE, OutT, WM, WN, TM, TN>), dim3(grid), dim3(NT_), shmem, stream, p);
+  hipLaunchKernelGGL((gemm_kernel<T, MODE, OutT, WM, WN, TM, TN, NSTAGE>), dim3(grid), dim3(NT_), shmem, stream, p);
   VTC_LAUNCH_CHECK("gemm");
   return 0;
 }
@@ -342,9 +379,11 @@ int run_cfg(const GemmParams &p, hipStream_t stream) {
     bool big = big_tiles * 2 >= (long)num_cus() * 3;
     if (g_force_tile == 1) big = false;
     if (g_force_tile == 2) big = true;
-    if (big) return run<T, MODE, OutT, 2, 4, 8, 4>(p, stream);
+    const int kst = p.K / Mma<T>::KPR;
+    if (g_force_tile == 3 && kst >= 2) return run<T, MODE, OutT, 4, 2, 4, 4, 3>(p, stream);   // 256x128, 3-stage ring
+    if (big) return run<T, MODE, OutT, 2, 4, 8, 4, 2>(p, stream);
   }
-  return run<T, MODE, OutT, 2, 2, 4, 4>(p, stream);
+  return run<T, MODE, OutT, 2, 2, 4, 4, 2>(p, stream);
 }
 
 template <typename T>

@@ -8,8 +8,12 @@ constexpr int ROWB = 128;          // bytes of K per LDS row
 constexpr int SUPER_ROWS = 1024;   // output rows per L2 super-row
 
 template <typename T> struct Mma;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 template <> struct Mma<bf16_t> {
   static constexpr int KPR = 64;  // K elements per 128-byte row
+  __device__ static __forceinline__ void run(const u32x4v &w, const u32x4v &a, f32x4 &acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+  }
   __device__ static __forceinline__ void run(const uint4 &w, const uint4 &a, f32x4 &acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), acc,
                                                   0, 0, 0);
@@ -17,6 +21,13 @@ template <> struct Mma<bf16_t> {
 };
 template <> struct Mma<float> {
   static constexpr int KPR = 32;
+  __device__ static __forceinline__ void run(const u32x4v &w, const u32x4v &a, f32x4 &acc) {
+    const f32x4 wv = __builtin_bit_cast(f32x4, w), av = __builtin_bit_cast(f32x4, a);   // whole-tuple casts
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], av[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], av[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], av[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], av[3], acc, 0, 0, 0);
+  }
   __device__ static __forceinline__ void run(const uint4 &w, const uint4 &a, f32x4 &acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.x), __builtin_bit_cast(float, a.x), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, w.y), __builtin_bit_cast(float, a.y), acc, 0, 0, 0);
@@ -58,6 +69,24 @@ __device__ __forceinline__ void glds16(const char *gsrc, unsigned lds_dst) {
       : "memory");
 }
 
+// 16-byte LDS read the compiler does not schedule or count: `addr` is the 32-bit LDS byte address,
+// OFF an immediate (< 65536).  The data is valid only after a matching lgkm_wait (LDS reads of one
+// wave return in order; every wait names the registers it guards so no consumer can move above it).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one 128-bit register tuple (asm "v" operand)
+__device__ __forceinline__ void lds_read16(u32x4 &dst, unsigned addr, int off) {
+  // "memory": keeps the read below the barrier that publishes the buffer and above the one that recycles it
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait(u32x4 &x) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N));
+}
+template <int N, int TN>
+__device__ __forceinline__ void lgkm_wait_frags(u32x4 &x, u32x4 (&w)[TN]) {
+  static_assert(TN == 4, "four weight fragments per wave");
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(x), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N));
+}
+
 // Stage GROUPS 8-row groups of a ROWS-row x 128-byte operand tile (this wave's share).
 template <int GROUPS>
 __device__ __forceinline__ void stage_tile(const char *base, int row0, int nrows, int ld_bytes, int kbyte, unsigned lds_tile,
@@ -71,7 +100,7 @@ __device__ __forceinline__ void stage_tile(const char *base, int row0, int nrows
     int gr = row0 + r;
     gr = gr < nrows ? gr : nrows - 1;         // clamp: tail rows re-read a valid row, never stored
     const char *src = base + (size_t)gr * ld_bytes + kbyte + c * 16;
-    glds16(src, lds_tile + group * 1024);
+    glds16(src, __builtin_amdgcn_readfirstlane(lds_tile + group * 1024));   // provably wave-uniform -> SGPR operand
   }
 }
 

@@ -22,6 +22,10 @@ SD = Dict[str, torch.Tensor]
 
 # items per vision-tower launch; 0 = the whole batch in one pass
 VISION_CHUNK = 0
+# sequences per text-tower launch; 0 = the whole batch in one pass.  A chunk whose activations
+# (x fp32 + h + qkv/hidden, ~8 KB per token at W = 512) stay inside the 256 MiB Infinity Cache turns the
+# HBM-bound stages (LayerNorm, attention, residual epilogues) into cache-bound ones.
+TEXT_CHUNK = int(__import__("os").environ.get("VTC_TEXT_CHUNK", "0"))
 # Text tower on ragged batches: compute only tokens 0..EOT of every sequence (identical outputs under the
 # causal mask).  Off by default: the dense path does exactly the work the reference does.
 TEXT_RAGGED = False
@@ -176,9 +180,12 @@ class PackedText:
             L.check(lib.vtc_text_forward_ragged(C.byref(w), ids.data_ptr(), S, offsets.data_ptr(), total, out.data_ptr(),
                                                 ws.data_ptr(), ws.numel(), self.code, ops._stream()), "vtc_text_forward_ragged")
             return out
-        ws = _ws(lib.vtc_text_workspace_bytes(C.byref(w), S, self.code), ids.device)
-        L.check(lib.vtc_text_forward(C.byref(w), ids.data_ptr(), S, out.data_ptr(), ws.data_ptr(), ws.numel(), self.code,
-                                     ops._stream()), "vtc_text_forward")
+        chunk = TEXT_CHUNK if TEXT_CHUNK > 0 else S
+        ws = _ws(lib.vtc_text_workspace_bytes(C.byref(w), min(chunk, S), self.code), ids.device)
+        for s0 in range(0, S, chunk):
+            n = min(chunk, S - s0)
+            L.check(lib.vtc_text_forward(C.byref(w), ids[s0:s0 + n].data_ptr(), n, out[s0:s0 + n].data_ptr(), ws.data_ptr(),
+                                         ws.numel(), self.code, ops._stream()), "vtc_text_forward")
         return out
 
 

@@ -52,60 +52,108 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict
   }
 }
 
-__global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__ dist, int ld, int n_rows, int n_cols, int depth,
-                                                       int64_t *__restrict__ ids, float *__restrict__ dists, size_t out_row0) {
-  const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n_rows) return;
-  const float *row = dist + (size_t)r * ld;
-  float bd = INFINITY;
-  int bi = 0x7fffffff;
-  float tau = INFINITY;
-  int tau_i = 0x7fffffff;
-  const bool vec = (ld & 3) == 0;
-  for (int base = 0; base < n_cols; base += 256) {
-    const int c = base + lane * 4;
-    float v[4];
-    if (vec && c + 3 < n_cols) {
-      const float4 t = *reinterpret_cast<const float4 *>(row + c);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = c + e < n_cols ? row[c + e] : INFINITY;
-    }
-    bool pass[4];
-    bool anyp = false;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = c + e;
-      pass[e] = idx < n_cols && (v[e] < tau || (v[e] == tau && idx < tau_i));
-      anyp |= pass[e];
-    }
-    if (__ballot(anyp) == 0ull) continue;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      unsigned long long mask = __ballot(pass[e]);
-      while (mask) {
-        const int l = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        const float cv = __shfl(v[e], l, 64);
-        const int ci = base + l * 4 + e;
-        if (cv < tau || (cv == tau && ci < tau_i)) {     // wave-uniform: the list may have tightened meanwhile
-          const bool less = (bd < cv) || (bd == cv && bi < ci);
-          const int pos = __popcll(__ballot(less));
-          const float ud = __shfl_up(bd, 1, 64);
-          const int ui = __shfl_up(bi, 1, 64);
-          if (lane > pos) { bd = ud; bi = ui; }
-          if (lane == pos) { bd = cv; bi = ci; }
-          tau = __shfl(bd, depth - 1, 64);
-          tau_i = __shfl(bi, depth - 1, 64);
-        }
+// Wave-wide sorted best list, one entry per lane (lane i = i-th best), order = (distance, index).
+struct WaveList {
+  float bd;
+  int bi;
+  float tau;     // distance of entry depth-1 (wave-uniform)
+  int tau_i;
+  __device__ __forceinline__ void init() { bd = INFINITY; bi = 0x7fffffff; tau = INFINITY; tau_i = 0x7fffffff; }
+  // offer one candidate per lane (pass = lane has a candidate that beats the current depth-th entry).
+  // Insertions are rare after warm-up but serial: broadcasts are v_readlane (the lane index is
+  // wave-uniform), the one-lane shift a ds_bpermute.
+  __device__ __forceinline__ void offer(float v, int idx, bool pass, int lane, int depth) {
+    unsigned long long mask = __ballot(pass);
+    while (mask) {
+      const int l = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+      const int ci = __builtin_amdgcn_readlane(idx, l);
+      if (cv < tau || (cv == tau && ci < tau_i)) {       // wave-uniform: the list may have tightened meanwhile
+        const bool less = (bd < cv) || (bd == cv && bi < ci);
+        const int pos = __popcll(__ballot(less));
+        const float ud = __shfl_up(bd, 1, 64);
+        const int ui = __shfl_up(bi, 1, 64);
+        if (lane > pos) { bd = ud; bi = ui; }
+        if (lane == pos) { bd = cv; bi = ci; }
+        tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bd), depth - 1));
+        tau_i = __builtin_amdgcn_readlane(bi, depth - 1);
       }
     }
   }
+  __device__ __forceinline__ bool beats(float v, int idx) const { return v < tau || (v == tau && idx < tau_i); }
+};
+
+// One wave per (row, column segment): streams its segment with 2 x 16-byte loads in flight per lane and
+// keeps the segment's best `depth`; segments exist only to put enough waves (bytes in flight) on the chip
+// when a block has few rows.  S == 1 writes the final ids/dists directly.
+__global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__ dist, int ld, int n_rows, int n_cols, int depth,
+                                                       int S, int seg_cols, int64_t *__restrict__ ids, float *__restrict__ dists,
+                                                       size_t out_row0, float *__restrict__ part_d, int *__restrict__ part_i) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n_rows * S) return;
+  const int r = w / S, seg = w - r * S;
+  const float *row = dist + (size_t)r * ld;
+  const int c_lo = seg * seg_cols, c_hi = min(n_cols, c_lo + seg_cols);
+  WaveList wl;
+  wl.init();
+  const bool vec = (ld & 3) == 0;
+  for (int base = c_lo; base < c_hi; base += 512) {
+    float v[8];
+    int cidx[2] = {base + lane * 4, base + 256 + lane * 4};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = cidx[h];
+      if (vec && c + 3 < c_hi) {
+        const float4 t = *reinterpret_cast<const float4 *>(row + c);
+        v[4 * h] = t.x; v[4 * h + 1] = t.y; v[4 * h + 2] = t.z; v[4 * h + 3] = t.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * h + e] = c + e < c_hi ? row[c + e] : INFINITY;
+      }
+    }
+    bool pass[8], anyp = false;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int idx = cidx[q >> 2] + (q & 3);
+      pass[q] = idx < c_hi && wl.beats(v[q], idx);
+      anyp |= pass[q];
+    }
+    if (__ballot(anyp) == 0ull) continue;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wl.offer(v[q], cidx[q >> 2] + (q & 3), pass[q], lane, depth);
+  }
   if (lane < depth) {
-    ids[(out_row0 + r) * depth + lane] = bi == 0x7fffffff ? -1 : (int64_t)bi;
-    if (dists) dists[(out_row0 + r) * depth + lane] = bd;
+    if (S == 1) {
+      ids[(out_row0 + r) * depth + lane] = wl.bi == 0x7fffffff ? -1 : (int64_t)wl.bi;
+      if (dists) dists[(out_row0 + r) * depth + lane] = wl.bd;
+    } else {
+      part_d[(size_t)w * depth + lane] = wl.bd;
+      part_i[(size_t)w * depth + lane] = wl.bi;
+    }
+  }
+}
+
+// One wave per row: merge the S partial lists of the row.
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ part_d, const int *__restrict__ part_i, int n_rows,
+                                                         int S, int depth, int64_t *__restrict__ ids, float *__restrict__ dists,
+                                                         size_t out_row0) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  WaveList wl;
+  wl.init();
+  const int total = S * depth;
+  for (int base = 0; base < total; base += 64) {
+    const int k = base + lane;
+    const float v = k < total ? part_d[(size_t)r * total + k] : INFINITY;
+    const int idx = k < total ? part_i[(size_t)r * total + k] : 0x7fffffff;
+    wl.offer(v, idx, k < total && idx != 0x7fffffff && wl.beats(v, idx), lane, depth);
+  }
+  if (lane < depth) {
+    ids[(out_row0 + r) * depth + lane] = wl.bi == 0x7fffffff ? -1 : (int64_t)wl.bi;
+    if (dists) dists[(out_row0 + r) * depth + lane] = wl.bd;
   }
 }
 
@@ -157,9 +205,12 @@ struct SweepWs {
   float *qn, *gn;
   bf16_t *qb, *gb;
   float *dist;
+  float *part_d;
+  int *part_i;
   int rows_per_block;
   size_t total;
 };
+constexpr int MAX_SEG = 16;
 
 SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block) {
   SweepWs s;
@@ -180,6 +231,8 @@ SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block)
   if (rpb > nq) rpb = nq;
   s.rows_per_block = rpb;
   s.dist = (float *)take((size_t)rpb * ng * 4);
+  s.part_d = (float *)take((size_t)rpb * MAX_SEG * 64 * 4);
+  s.part_i = (int *)take((size_t)rpb * MAX_SEG * 64 * 4);
   s.total = off;
   return s;
 }
@@ -218,8 +271,18 @@ extern "C" int vtc_l2_topk(const float *gallery, const float *queries, int ng, i
       rc = launch_gemm(s.qb + (size_t)r0 * d * parts, s.gb, nullptr, s.dist, rows, ng, d * parts, VTC_BF16, e, stream);
     if (rc) return rc;
     {
+      // enough (row, segment) waves to keep ~8k waves' worth of loads in flight
+      // (every segment pays its own warm-up insertions, so segments are used only when rows alone cannot fill the chip)
+      int S = cdiv(2048, rows);
+      S = S < 1 ? 1 : (S > MAX_SEG ? MAX_SEG : S);
+      int seg_cols = cdiv(cdiv(ng, S), 512) * 512;
+      S = cdiv(ng, seg_cols);
       ProfScope prof(VTC_PROF_TOPK, (double)rows * ng * 4, stream);
-      hipLaunchKernelGGL(row_topk_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, s.dist, ng, rows, ng, depth, ids, dists, (size_t)r0);
+      hipLaunchKernelGGL(row_topk_kernel, dim3(cdiv(rows * S, 4)), dim3(256), 0, stream, s.dist, ng, rows, ng, depth, S, seg_cols, ids,
+                         dists, (size_t)r0, s.part_d, s.part_i);
+      if (S > 1)
+        hipLaunchKernelGGL(topk_merge_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, s.part_d, s.part_i, rows, S, depth, ids, dists,
+                           (size_t)r0);
     }
     VTC_LAUNCH_CHECK("row_topk");
   }

@@ -68,6 +68,27 @@ class PretrainedCLIPBase(nn.Module):
             self._packed = p
         return self._packed
 
+    #: run the visual tower on a side HIP stream while the text tower runs on the caller's stream: both
+    #: towers are chains of persistent-grid kernels, and one tower's kernels fill the other's launch gaps and tails
+    overlap_towers = __import__("os").environ.get("VTC_OVERLAP", "1") != "0"
+    _video_tower = False      # True: model.visual takes [B,F,3,H,W] (TimeSformer wrappers)
+
+    def _encode_both(self, vis, title):
+        """(visual features, title features); the two towers are independent until the CAM / similarity."""
+        enc = self.encode_image if self._video_tower else self._encode_vis
+        if not self.overlap_towers or len(vis.shape) == 2:
+            return enc(vis), self.encode_text(title)
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            fv = enc(vis)
+        ft = self.encode_text(title)
+        cur.wait_stream(self._side)
+        fv.record_stream(cur)
+        return fv, ft
+
     def _check_mode(self, *tensors):
         if self.training:
             raise RuntimeError("vtc_amd implements the forward/eval path only: call .eval() "
@@ -165,8 +186,7 @@ class PretrainedCLIP(PretrainedCLIPBase):
 
     def forward(self, vis, title, comments=None):
         self._check_mode(vis, title, comments)
-        feats_vis = self._encode_vis(vis)
-        feats_title = self.encode_text(title)
+        feats_vis, feats_title = self._encode_both(vis, title)
         if comments is None or self.comment_fusion is None or self.comment_fusion == "None":
             feats_text = feats_title
         else:
@@ -200,13 +220,14 @@ class PretrainedCLIP_finaltf(PretrainedCLIPBase):
 
     def forward(self, vis, title, comments):
         self._check_mode(vis, title, comments)
-        feats_vis = self._encode_vis(vis)
-        feats_title = self.encode_text(title)
+        feats_vis, feats_title = self._encode_both(vis, title)
         feats_vis, feats_text = self._encode_with_comments(feats_vis, feats_title, comments)
         return feats_vis, feats_text, self._sim(feats_vis, feats_text)
 
 
 class PretrainedCLIP_TimeSformer(PretrainedCLIPBase):
+    _video_tower = True
+
     def __init__(self, model_type="ViT-B/32", freeze=False, residual_activation=None):
         super().__init__()
         self.model = clip_arch.load(model_type, device="cpu")
@@ -218,12 +239,14 @@ class PretrainedCLIP_TimeSformer(PretrainedCLIPBase):
 
     def forward(self, im, text, comments=None):
         self._check_mode(im, text)
-        feats_im = normalize(self.encode_image(im))              # model.visual(im), model/model.py:497
-        feats_text = normalize(self.encode_text(text))
+        feats_im, feats_text = self._encode_both(im, text)       # model.visual(im), model/model.py:497
+        feats_im, feats_text = normalize(feats_im), normalize(feats_text)
         return feats_im, feats_text, self._sim(feats_im, feats_text)
 
 
 class PretrainedCLIP_TimeSformer_finaltf(PretrainedCLIPBase):
+    _video_tower = True
+
     def __init__(self, model_type="ViT-B/32", freeze=False, branch_to_adapt="text", branch_to_adapt_val="text",
                  residual_activation=None, visual_device=None, n_layers=2, n_heads=8, init_from_avg=True,
                  random_comment_masking=False, random_skip_adapter=True):
@@ -244,7 +267,6 @@ class PretrainedCLIP_TimeSformer_finaltf(PretrainedCLIPBase):
 
     def forward(self, vis, title, comments):
         self._check_mode(vis, title, comments)
-        feats_vis = self.encode_image(vis)
-        feats_title = self.encode_text(title)
+        feats_vis, feats_title = self._encode_both(vis, title)
         feats_vis, feats_text = self._encode_with_comments(feats_vis, feats_title, comments)
         return feats_vis, feats_text, self._sim(feats_vis, feats_text)

@@ -29,14 +29,16 @@ TEXT_CHUNK = int(__import__("os").environ.get("VTC_TEXT_CHUNK", "0"))
 # Text tower on ragged batches: compute only tokens 0..EOT of every sequence (identical outputs under the
 # causal mask).  Off by default: the dense path does exactly the work the reference does.
 TEXT_RAGGED = False
-_WS: Dict[torch.device, torch.Tensor] = {}
+_WS: Dict[tuple, torch.Tensor] = {}
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
-    w = _WS.get(device)
+    """One growing workspace per (device, stream): towers running concurrently on two streams must not share scratch."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    w = _WS.get(key)
     if w is None or w.numel() < nbytes:
-        _WS[device] = w = None  # drop the old one before growing
-        _WS[device] = w = ops.workspace(nbytes, device)
+        _WS[key] = w = None  # drop the old one before growing
+        _WS[key] = w = ops.workspace(nbytes, device)
     return w
 
 

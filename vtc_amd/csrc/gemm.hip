@@ -46,6 +46,7 @@ template <typename T, int MODE, typename OutT, int WM, int WN, int TM, int TN, i
 __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p) {
   constexpr int NW = WM * WN, BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int G = BM / 8 / NW + BN / 8 / NW;          // LDS-DMA instructions per wave per slab
+  constexpr bool STAGGER = NW == 8;                     // two waves per SIMD inside one workgroup
   constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
   constexpr int AG = BM / 8 / NW, WG = BN / 8 / NW;
   constexpr int SUPER = SUPER_ROWS / BM;
@@ -86,6 +87,11 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
     for (int i = 0; i < p.exp_arg; ++i) __builtin_amdgcn_s_sleep(16);
   }
   int cur = 0;                                   // LDS buffer of the slab being multiplied
+  // both operands addressable with 32-bit byte offsets (true for every tower shape)?
+  const bool small32 = (size_t)p.M * p.lda_bytes < (1ull << 32) && (size_t)p.N * p.ldw_bytes < (1ull << 32);
+  unsigned a_off[AG], w_off[WG];
+  tile_offsets<AG>(a_off, m0, p.M, p.lda_bytes, wave_u, lane);
+  tile_offsets<WG>(w_off, n0, p.N, p.ldw_bytes, wave_u, lane);
   int m0n = 0, n0n = 0;
   bool has_next = li + nb_x < nt_x;
   if (has_next) decode(start_x + li + nb_x, m0n, n0n);
@@ -94,8 +100,13 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
     const unsigned dst = lds_base + ((cur + d) % NSTAGE) * STAGE;
     const int k = t + d;
     if (k < ksteps) {
-      stage_tile<AG>(p.A, m0, p.M, p.lda_bytes, k * ROWB, dst, wave_u, lane);
-      stage_tile<WG>(p.W, n0, p.N, p.ldw_bytes, k * ROWB, dst + A_BYTES, wave_u, lane);
+      if (small32) {                             // uniform base + precomputed 32-bit lane offsets
+        stage_tile_fast<AG>(a_off, p.A + (size_t)k * ROWB, dst, wave_u);
+        stage_tile_fast<WG>(w_off, p.W + (size_t)k * ROWB, dst + A_BYTES, wave_u);
+      } else {
+        stage_tile<AG>(p.A, m0, p.M, p.lda_bytes, k * ROWB, dst, wave_u, lane);
+        stage_tile<WG>(p.W, n0, p.N, p.ldw_bytes, k * ROWB, dst + A_BYTES, wave_u, lane);
+      }
       return true;
     }
     if (has_next) {                              // rides under the last K-steps of this tile
@@ -122,7 +133,14 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
       for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int t = 0; t < ksteps; ++t) {
-      const bool issued = stage_ahead(t, NSTAGE - 1);
+      // Stagger (MI355X_MICROARCH "two waves per SIMD", item 9): the two waves that share a SIMD run the
+      // same program between the same barriers, so left alone they issue their LDS-DMA pieces (~100
+      // cycles of issue each, no matrix work) at the same time and their MFMAs at the same time.  The
+      // second half of the workgroup issues its DMA after the first half-step instead, so one wave's
+      // address/DMA issue sits beside the other's MFMAs.
+      const bool late_dma = STAGGER && wave_u >= NW / 2;
+      bool issued = false;
+      if (!late_dma) issued = stage_ahead(t, NSTAGE - 1);
       // Fragment reads are inline-asm ds_read_b128 with hand-counted lgkmcnt waits: hipcc, left to itself,
       // keeps ONE A-fragment register in this loop (read -> lgkmcnt(0) -> 4 MFMA -> read ...), which parks
       // every wave on an LDS round trip per 4 MFMAs (SQ_WAIT_ANY 42 %, MFMA busy 44 %).  Here the read of
@@ -132,6 +150,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
       const unsigned w_addr = lds_base + cur * STAGE + A_BYTES + wrow;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        if (ks == 1 && late_dma) issued = stage_ahead(t, NSTAGE - 1);
         const unsigned coff = ((4 * ks + g) ^ swz) << 4;
         u32x4 wf[TN], aE, aO;
 #pragma unroll
@@ -330,6 +349,8 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
 
     if (!has_next) break;
     li += nb_x; m0 = m0n; n0 = n0n;
+    tile_offsets<AG>(a_off, m0, p.M, p.lda_bytes, wave_u, lane);
+    tile_offsets<WG>(w_off, n0, p.N, p.ldw_bytes, wave_u, lane);
     has_next = li + nb_x < nt_x;
     if (has_next) decode(start_x + li + nb_x, m0n, n0n);
   }

@@ -87,6 +87,41 @@ __device__ __forceinline__ void lgkm_wait_frags(u32x4 &x, u32x4 (&w)[TN]) {
   asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(x), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N));
 }
 
+// Same DMA with a wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: the per-lane part is
+// computed once per tile, the base advances by one scalar add per K-step -- no 64-bit VALU address
+// arithmetic in the K loop (each piece's issue cost is what the partner wave's MFMAs have to cover).
+__device__ __forceinline__ void glds16s(unsigned voff, const char *sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+
+// per-lane byte offsets of this wave's GROUPS pieces of a tile whose first row is row0 (rows clamped)
+template <int GROUPS>
+__device__ __forceinline__ void tile_offsets(unsigned (&off)[GROUPS], int row0, int nrows, int ld_bytes, int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < GROUPS; ++q) {
+    const int r = (wave * GROUPS + q) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int gr = row0 + r;
+    gr = gr < nrows ? gr : nrows - 1;
+    off[q] = (unsigned)gr * (unsigned)ld_bytes + c * 16;
+  }
+}
+template <int GROUPS>
+__device__ __forceinline__ void stage_tile_fast(const unsigned (&off)[GROUPS], const char *sbase, unsigned lds_tile, int wave) {
+#pragma unroll
+  for (int q = 0; q < GROUPS; ++q)
+    glds16s(off[q], sbase, __builtin_amdgcn_readfirstlane(lds_tile + (wave * GROUPS + q) * 1024));
+}
+
 // Stage GROUPS 8-row groups of a ROWS-row x 128-byte operand tile (this wave's share).
 template <int GROUPS>
 __device__ __forceinline__ void stage_tile(const char *base, int row0, int nrows, int ld_bytes, int kbyte, unsigned lds_tile,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-enum { VTC_F32 = 0, VTC_BF16 = 1 };
+enum { VTC_F32 = 0, VTC_BF16 = 1, VTC_U8 = 2 /* pixel_dtype only: raw 0..255 pixels */ };
 
 /* residual activations of the CAM, model/model.py:65-77 (stateless ones) */
 enum { VTC_ACT_NONE = 0, VTC_ACT_NORMALIZE = 1, VTC_ACT_SQUASH = 2, VTC_ACT_TANH = 3 };
@@ -61,6 +61,8 @@ typedef struct {
 typedef struct {
   int width, heads, layers, patch, grid, embed_dim, nframes;
   int variant;                    /* 0: timesformer_clip_alt.py (used by model.py); 1: timesformer_clip.py */
+  float pix_mean[3], pix_std[3];  /* pixel_dtype VTC_U8: x = (u8/255 - mean[c]) / std[c], i.e. ToTensor + Normalize of
+                                     CLIP_TRANSFORM (dataset_loaders/dataset_loaders.py:40-49) fused into the patch gather */
   const void  *conv_w;            /* conv1.weight flattened [W, 3*patch*patch]            */
   const float *class_embedding;   /* [W]                                                  */
   const float *pos;               /* positional_embedding [1+grid*grid, W]                */
@@ -99,7 +101,7 @@ int vtc_abi_version(void);
 /* Replaces clip_model.encode_image (model/model.py:332,464) when w->nframes == 0 and
  * VisualTransformer.forward (model/timesformer_clip_alt.py:252-286, called at
  * model/model.py:497,613) when w->nframes > 0.
- * pixels: [n_items, F, 3, H, W] (F = 1 for images), fp32 (pixel_dtype VTC_F32) or bf16.
+ * pixels: [n_items, F, 3, H, W] (F = 1 for images), fp32 (pixel_dtype VTC_F32), bf16, or raw uint8 (VTC_U8).
  * out:    [n_items, embed_dim] fp32 (not normalised). */
 size_t vtc_vision_workspace_bytes(const vtc_vision_w *w, int n_items, int frames, int dtype);
 int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int pixel_dtype, int n_items, int frames,

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvtc_hip.so")
 
-VTC_F32, VTC_BF16 = 0, 1
+VTC_F32, VTC_BF16, VTC_U8 = 0, 1, 2
 ACT_NONE, ACT_NORMALIZE, ACT_SQUASH, ACT_TANH = 0, 1, 2, 3
 SWEEP_F32, SWEEP_BF16X3, SWEEP_BF16 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RESID = 0, 1, 2
@@ -30,6 +30,7 @@ class BlockW(C.Structure):
 class VisionW(C.Structure):
     _fields_ = [("width", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("patch", C.c_int), ("grid", C.c_int),
                 ("embed_dim", C.c_int), ("nframes", C.c_int), ("variant", C.c_int),
+                ("pix_mean", C.c_float * 3), ("pix_std", C.c_float * 3),
                 ("conv_w", C.c_void_p), ("class_embedding", C.c_void_p), ("pos", C.c_void_p), ("temporal", C.c_void_p),
                 ("ln_pre_g", C.c_void_p), ("ln_pre_b", C.c_void_p), ("ln_post_g", C.c_void_p), ("ln_post_b", C.c_void_p),
                 ("proj_t", C.c_void_p), ("blocks", C.POINTER(BlockW))]

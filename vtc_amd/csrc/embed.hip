@@ -10,6 +10,30 @@
 
 namespace {
 
+// raw uint8 pixels: ToTensor (/255) + per-channel Normalize fused into the gather
+struct PixNorm { float mean[3], inv_std[3]; };
+template <typename T>
+__global__ __launch_bounds__(256) void im2row_u8_kernel(const unsigned char *__restrict__ px, T *__restrict__ out, int n_frames, int grid,
+                                                        int patch, int res, PixNorm nrm) {
+  const int K = 3 * patch * patch;
+  const size_t total = (size_t)n_frames * grid * grid * (K / 4);
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int kq = (int)(idx % (K / 4));
+  const size_t m = idx / (K / 4);
+  const int k = kq * 4;
+  const int c = k / (patch * patch), rem = k - c * patch * patch;
+  const int i = rem / patch, j = rem - i * patch;
+  const int P = grid * grid;
+  const int f = (int)(m / P), pp = (int)(m - (size_t)f * P);
+  const int py = pp / grid, pxx = pp - py * grid;
+  const unsigned char *src = px + (((size_t)f * 3 + c) * res + (size_t)py * patch + i) * res + (size_t)pxx * patch + j;
+  const uchar4 u = *reinterpret_cast<const uchar4 *>(src);
+  const float mu = nrm.mean[c], is = nrm.inv_std[c];
+  ElemOps<T>::store4(out + m * K + k, (u.x / 255.0f - mu) * is, (u.y / 255.0f - mu) * is, (u.z / 255.0f - mu) * is,
+                     (u.w / 255.0f - mu) * is);
+}
+
 template <typename PixT, typename T>
 __global__ __launch_bounds__(256) void im2row_kernel(const PixT *__restrict__ px, T *__restrict__ out, int n_frames, int grid,
                                                      int patch, int res) {
@@ -214,8 +238,25 @@ __global__ __launch_bounds__(256) void cam_finalize_kernel(const float *__restri
 }  // namespace
 
 int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res,
-                  hipStream_t stream) {
+                  const float *mean, const float *stdv, hipStream_t stream) {
   VTC_CHECK(patch % 4 == 0, "im2row: patch=%d must be a multiple of 4", patch);
+  if (pixel_dtype == VTC_U8) {
+    PixNorm nrm;
+    for (int c = 0; c < 3; ++c) {
+      VTC_CHECK(stdv[c] > 0.f, "im2row: pix_std[%d] must be positive for uint8 pixels", c);
+      nrm.mean[c] = mean[c]; nrm.inv_std[c] = 1.0f / stdv[c];
+    }
+    const size_t total8 = (size_t)n_frames * grid * grid * (3 * patch * patch / 4);
+    ProfScope prof8(VTC_PROF_EMBED, (double)total8 * 4 * (1 + (dtype == VTC_BF16 ? 2 : 4)), stream);
+    if (dtype == VTC_BF16)
+      hipLaunchKernelGGL((im2row_u8_kernel<bf16_t>), dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, stream,
+                         (const unsigned char *)px, (bf16_t *)out, n_frames, grid, patch, res, nrm);
+    else
+      hipLaunchKernelGGL((im2row_u8_kernel<float>), dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, stream,
+                         (const unsigned char *)px, (float *)out, n_frames, grid, patch, res, nrm);
+    VTC_LAUNCH_CHECK("im2row_u8");
+    return 0;
+  }
   const size_t total = (size_t)n_frames * grid * grid * (3 * patch * patch / 4);
   const dim3 g((unsigned)((total + 255) / 256)), b(256);
   ProfScope prof(VTC_PROF_EMBED, (double)total * 4 * ((pixel_dtype == VTC_BF16 ? 2 : 4) + (dtype == VTC_BF16 ? 2 : 4)), stream);

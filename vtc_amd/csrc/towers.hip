@@ -33,7 +33,7 @@ void vtc_set_error(const char *fmt, ...) {
 extern "C" const char *vtc_last_error(void) { return g_err; }
 extern "C" int vtc_abi_version(void) { return 1; }
 
-int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res, hipStream_t stream);
+int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res, const float *mean, const float *stdv, hipStream_t stream);
 int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, int T, int W, hipStream_t stream);
 int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int F, int T, int W, hipStream_t stream);
 int launch_text_embed(const int64_t *ids, const float *tok, const float *pos, float *x, int *eot_row, int n_seq, int ctx, int W, int vocab, hipStream_t stream);
@@ -157,7 +157,8 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
   VTC_CHECK(ws_bytes >= v.total, "vision_forward: workspace too small (%zu < %zu)", ws_bytes, v.total);
 
   // patch embedding (+pos, +temporal) scattered into the reference's token order, cls rows, ln_pre
-  RUN(launch_im2row(pixels, pixel_dtype, v.big, dtype, n_items * F, w->grid, w->patch, res, s));
+  VTC_CHECK(pixel_dtype == VTC_F32 || pixel_dtype == VTC_BF16 || pixel_dtype == VTC_U8, "vision_forward: bad pixel dtype %d", pixel_dtype);
+  RUN(launch_im2row(pixels, pixel_dtype, v.big, dtype, n_items * F, w->grid, w->patch, res, w->pix_mean, w->pix_std, s));
   {
     GemmEpi e;
     e.mode = EPI_PATCH; e.out_dtype = VTC_F32; e.pos = w->pos; e.temporal = tsf ? w->temporal : nullptr;

@@ -110,6 +110,9 @@ class PackedVision:
         w.nframes = sd["temporal_embed"].shape[0] if "temporal_embed" in sd else 0
         # variant 1 = model/timesformer_clip.py (frames-major tokens, cls attends globally, no temporal_fc)
         w.variant = 1 if (w.nframes and not any("temporal_fc" in k for k in sd)) else 0
+        # raw uint8 pixels: ToTensor + Normalize of CLIP_TRANSFORM (dataset_loaders/dataset_loaders.py:40-49)
+        w.pix_mean = (C.c_float * 3)(0.48145466, 0.4578275, 0.40821073)
+        w.pix_std = (C.c_float * 3)(0.26862954, 0.26130258, 0.27577711)
         w.conv_w = k.mat(conv.reshape(w.width, -1), dtype)
         w.class_embedding, w.pos = k.f32(sd["class_embedding"]), k.f32(sd["positional_embedding"])
         w.temporal = k.f32(sd["temporal_embed"]) if w.nframes else None
@@ -127,7 +130,7 @@ class PackedVision:
         if pixels.dim() == 4:
             pixels = pixels.unsqueeze(1)
         pixels = ops._gpu(pixels, name="pixels")
-        if pixels.dtype not in (torch.float32, torch.bfloat16):
+        if pixels.dtype not in (torch.float32, torch.bfloat16, torch.uint8):
             pixels = pixels.float()
         n, F = pixels.shape[0], pixels.shape[1]
         if tuple(pixels.shape[2:]) != (3, self.res, self.res):
@@ -138,7 +141,8 @@ class PackedVision:
         ws = _ws(lib.vtc_vision_workspace_bytes(C.byref(w), min(chunk, n), F, self.code), pixels.device)
         for i0 in range(0, n, chunk):
             m = min(chunk, n - i0)
-            L.check(lib.vtc_vision_forward(C.byref(w), pixels[i0:i0 + m].data_ptr(), ops.dtype_code(pixels.dtype), m, F,
+            pcode = L.VTC_U8 if pixels.dtype == torch.uint8 else ops.dtype_code(pixels.dtype)
+            L.check(lib.vtc_vision_forward(C.byref(w), pixels[i0:i0 + m].data_ptr(), pcode, m, F,
                                            out[i0:i0 + m].data_ptr(), ws.data_ptr(), ws.numel(), self.code, ops._stream()),
                     "vtc_vision_forward")
         return out

@@ -26,6 +26,9 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs: several ranks on ONE card (VTC_LOCAL_DEVICE=0) over gloo (VTC_DIST_BACKEND=gloo)
+    local = int(os.environ.get("VTC_LOCAL_DEVICE", local))
+    backend = os.environ.get("VTC_DIST_BACKEND", backend)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvtc_hip.so")
+# VTC_HIP_LIB: kernel-tuning experiments only (a differently compiled build of the same sources)
+LIB_PATH = os.environ.get("VTC_HIP_LIB") or os.path.join(_HERE, "lib", "libvtc_hip.so")
 
 VTC_F32, VTC_BF16, VTC_U8 = 0, 1, 2
 ACT_NONE, ACT_NORMALIZE, ACT_SQUASH, ACT_TANH = 0, 1, 2, 3

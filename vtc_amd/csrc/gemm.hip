@@ -38,6 +38,191 @@ using namespace vtcgemm;
 
 namespace {
 
+// ---- epilogue (shared by both kernels): the wave's TM x TN accumulator fragments -> out, through a scratch
+// area of the dynamic LDS (byte offset scratch_off, >= 6 KiB per wave) that no DMA targets and nobody reads until
+// the caller's next barrier.  (The area is named by OFFSET and re-based on the extern array here: handed over as
+// a generic pointer, hipcc guards every LDS read behind the preceding global stores -- vmcnt waits that
+// serialise the store stream; measured -20 % on the residual shapes.)
+template <typename T, int MODE, typename OutT, int WM, int WN, int TM, int TN, int SCRATCH_PER_WAVE>
+__device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmParams &p, int m0, int n0, unsigned scratch_off) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WN, wc = wave % WN;
+  const int g = lane >> 4;
+  const int ldo = p.ldo;
+  const bool vec_ok = (ldo & 3) == 0;
+  // Interior tiles (every tile of the towers) take the transposed fast epilogue; edge tiles the generic one.
+  const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && vec_ok;
+  // ---- epilogue: lane holds out[m][n..n+3], m = m0 + 16 (wr TM + i) + (lane & 15),
+  //                n = n0 + 16 (wc TN + j) + 4 g
+  float scale = 1.0f;
+  if (MODE == EPI_SCALE) scale = __expf(*p.epi.scale_log);
+  if (interior) {
+    // Fast path (every tile of the towers).  The write path of a CU retires roughly one distinct
+    // cache line per 5-8 cycles whatever its fill, so storing straight from the MFMA layout
+    // (16 rows x 32..64 B per instruction) made the epilogue cost as much as 5 K-steps.  Instead
+    // each wave transposes its outputs through the LDS stage that the last K-step has just freed
+    // (the other stage already holds the next tile's first slab) and writes whole rows: every
+    // store instruction covers 4 (fp32) or 8 (bf16) full 256 / 128-byte row segments.
+    constexpr int TS = 68;                                   // padded row stride (floats): conflict-free b128 writes
+    float *tr = reinterpret_cast<float *>(lds + scratch_off + wave * SCRATCH_PER_WAVE);
+    const int l15 = lane & 15;
+    const int ncol0 = n0 + wc * TN * 16;
+    // column addend (bias, or |g|^2 of the distance epilogue) for the columns this lane writes back
+    const float *colv = MODE == EPI_L2DIST ? p.epi.coln : p.bias;
+    float cadd[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cadd[e] = 0.f;
+    if (colv) {
+      if constexpr (sizeof(OutT) == 4) {
+        const float4 c4 = *reinterpret_cast<const float4 *>(colv + ncol0 + l15 * 4);
+        cadd[0] = c4.x; cadd[1] = c4.y; cadd[2] = c4.z; cadd[3] = c4.w;
+      } else {
+        const float4 c0 = *reinterpret_cast<const float4 *>(colv + ncol0 + (lane & 7) * 8);
+        const float4 c1 = *reinterpret_cast<const float4 *>(colv + ncol0 + (lane & 7) * 8 + 4);
+        cadd[0] = c0.x; cadd[1] = c0.y; cadd[2] = c0.z; cadd[3] = c0.w;
+        cadd[4] = c1.x; cadd[5] = c1.y; cadd[6] = c1.z; cadd[7] = c1.w;
+      }
+    }
+    auto fin = [&](float a, float add, float rnv) -> float {
+      float v = MODE == EPI_L2DIST ? rnv + add - 2.0f * a : a + add;
+      if (MODE == VTC_EPI_GELU) v = quick_gelu<sizeof(T) == 4>(v);
+      if (MODE == EPI_SCALE) v *= scale;
+      return v;
+    };
+    // residual mode: the x rows of pass i+1 are fetched while pass i is transposed and stored
+    auto x_ptr = [&](int i, int k) -> float * {
+      const int m = m0 + (wr * TM + i) * 16 + (lane >> 4) + 4 * k;
+      return reinterpret_cast<float *>(p.out) + (size_t)m * ldo + ncol0 + l15 * 4;
+    };
+    float4 xc[4], xn[4];
+    if (MODE == VTC_EPI_RESID) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xc[k] = *reinterpret_cast<const float4 *>(x_ptr(0, k));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (MODE == VTC_EPI_RESID && i + 1 < TM) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xn[k] = *reinterpret_cast<const float4 *>(x_ptr(i + 1, k));
+      }
+      // 1. registers -> LDS: final fp32 values in [16 rows][64 cols]
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        *reinterpret_cast<float4 *>(tr + l15 * TS + 16 * j + 4 * g) =
+            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // 2. LDS -> global, row-contiguous
+      const int mrow0 = m0 + (wr * TM + i) * 16;
+      if constexpr (sizeof(OutT) == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = (lane >> 4) + 4 * k, cc = l15 * 4;
+          float4 v = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
+          const int m = mrow0 + r;
+          {
+            const float rnv = MODE == EPI_L2DIST ? p.epi.rown[m] : 0.f;
+            v.x = fin(v.x, cadd[0], rnv); v.y = fin(v.y, cadd[1], rnv); v.z = fin(v.z, cadd[2], rnv); v.w = fin(v.w, cadd[3], rnv);
+          }
+          size_t orow = (size_t)m;
+          bool live = true;
+          if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && (m % p.epi.skip_mod) == 0) live = false;
+          if (MODE == EPI_PATCH) {
+            const int np = m % p.epi.P, ft = m / p.epi.P;
+            const int tt = ft % p.epi.F, item = ft / p.epi.F;
+            orow = p.epi.frames_major ? (size_t)item * p.epi.T + 1 + (size_t)tt * p.epi.P + np
+                                      : (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
+            const float4 p4 = *reinterpret_cast<const float4 *>(p.epi.pos + (size_t)(1 + np) * p.N + ncol0 + cc);
+            v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+            if (p.epi.temporal) {
+              const float4 t4 = *reinterpret_cast<const float4 *>(p.epi.temporal + (size_t)tt * p.N + ncol0 + cc);
+              v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
+            }
+          }
+          float *o = reinterpret_cast<float *>(p.out) + orow * ldo + ncol0 + cc;
+          if (MODE == VTC_EPI_RESID) {
+            // skipped rows are written back unchanged (a select, not a branch: an exec-masked store makes hipcc
+            // re-wait on the x prefetch after every store, which throttles the store stream)
+            const float4 x = xc[k];
+            *reinterpret_cast<float4 *>(o) = make_float4(live ? x.x + v.x : x.x, live ? x.y + v.y : x.y,
+                                                         live ? x.z + v.z : x.z, live ? x.w + v.w : x.w);
+          } else {
+            *reinterpret_cast<float4 *>(o) = v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int r = (lane >> 3) + 8 * k, cc = (lane & 7) * 8;
+          float4 v0 = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
+          float4 v1 = *reinterpret_cast<const float4 *>(tr + r * TS + cc + 4);
+          v0.x = fin(v0.x, cadd[0], 0.f); v0.y = fin(v0.y, cadd[1], 0.f); v0.z = fin(v0.z, cadd[2], 0.f); v0.w = fin(v0.w, cadd[3], 0.f);
+          v1.x = fin(v1.x, cadd[4], 0.f); v1.y = fin(v1.y, cadd[5], 0.f); v1.z = fin(v1.z, cadd[6], 0.f); v1.w = fin(v1.w, cadd[7], 0.f);
+          uint4 pk;
+          pk.x = (unsigned)f2bf(v0.x) | ((unsigned)f2bf(v0.y) << 16);
+          pk.y = (unsigned)f2bf(v0.z) | ((unsigned)f2bf(v0.w) << 16);
+          pk.z = (unsigned)f2bf(v1.x) | ((unsigned)f2bf(v1.y) << 16);
+          pk.w = (unsigned)f2bf(v1.z) | ((unsigned)f2bf(v1.w) << 16);
+          bf16_t *o = reinterpret_cast<bf16_t *>(p.out) + (size_t)(mrow0 + r) * ldo + ncol0 + cc;
+          *reinterpret_cast<uint4 *>(o) = pk;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (MODE == VTC_EPI_RESID) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xc[k] = xn[k];
+      }
+    }
+  } else {
+    // Generic path: edge tiles (M or N not a multiple of the tile, odd leading dimension).
+    // Fully unrolled: a runtime index into acc[][] would send the accumulators to scratch.
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wr * TM + i) * 16 + (lane & 15);
+      bool live = m < p.M;
+      if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && live && (m % p.epi.skip_mod) == 0) live = false;
+      if (live) {
+        size_t orow = (size_t)m;
+        const float *posrow = nullptr, *temprow = nullptr;
+        float rn = 0.f;
+        if (MODE == EPI_PATCH) {
+          const int np = m % p.epi.P, ft = m / p.epi.P;
+          const int tt = ft % p.epi.F, item = ft / p.epi.F;
+          orow = p.epi.frames_major ? (size_t)item * p.epi.T + 1 + (size_t)tt * p.epi.P + np
+                                    : (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
+          posrow = p.epi.pos + (size_t)(1 + np) * p.N;
+          if (p.epi.temporal) temprow = p.epi.temporal + (size_t)tt * p.N;
+        }
+        if (MODE == EPI_L2DIST) rn = p.epi.rown[m];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + (wc * TN + j) * 16 + g * 4;
+          OutT *o = reinterpret_cast<OutT *>(p.out) + orow * ldo + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e < p.N) {
+              float x = acc[i][j][e];
+              if (p.bias) x += p.bias[n + e];
+              if (MODE == VTC_EPI_GELU) x = quick_gelu<sizeof(T) == 4>(x);
+              if (MODE == EPI_PATCH) x += posrow[n + e] + (temprow ? temprow[n + e] : 0.f);
+              if (MODE == EPI_L2DIST) x = rn + p.epi.coln[n + e] - 2.0f * x;
+              if (MODE == EPI_SCALE) x *= scale;
+              if (MODE == VTC_EPI_RESID) reinterpret_cast<float *>(o)[e] += x;
+              else ElemOps<OutT>::store(o + e, x);
+            }
+          }
+        }
+      }
+    }
+  }
+
+}
+
 // WM x WN waves, each owning TM x TN MFMA tiles of 16x16.
 // NSTAGE LDS buffers: 2 = wait for the next slab at the end of every K-step; 3 = the LDS-DMA of slab
 // t+2 is issued at step t and only slab t+1 is waited for (counted s_waitcnt vmcnt(G)), so two slabs are
@@ -123,9 +308,6 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
 
   while (true) {
 
-    // Interior tiles (every tile of the towers) take the transposed fast epilogue; edge tiles the generic one.
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && vec_ok;
-
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -180,177 +362,224 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
       cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
 
-    // ---- epilogue: lane holds out[m][n..n+3], m = m0 + 16 (wr TM + i) + (lane & 15),
-    //                n = n0 + 16 (wc TN + j) + 4 g
-    float scale = 1.0f;
-    if (MODE == EPI_SCALE) scale = __expf(*p.epi.scale_log);
-    if (interior) {
-      // Fast path (every tile of the towers).  The write path of a CU retires roughly one distinct
-      // cache line per 5-8 cycles whatever its fill, so storing straight from the MFMA layout
-      // (16 rows x 32..64 B per instruction) made the epilogue cost as much as 5 K-steps.  Instead
-      // each wave transposes its outputs through the LDS stage that the last K-step has just freed
-      // (the other stage already holds the next tile's first slab) and writes whole rows: every
-      // store instruction covers 4 (fp32) or 8 (bf16) full 256 / 128-byte row segments.
-      constexpr int TS = 68;                                   // padded row stride (floats): conflict-free b128 writes
-      float *tr = reinterpret_cast<float *>(lds + ((cur + NSTAGE - 1) % NSTAGE) * STAGE + wave * (STAGE / NW));   // >= 6 KiB per wave
-      const int l15 = lane & 15;
-      const int ncol0 = n0 + wc * TN * 16;
-      // column addend (bias, or |g|^2 of the distance epilogue) for the columns this lane writes back
-      const float *colv = MODE == EPI_L2DIST ? p.epi.coln : p.bias;
-      float cadd[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) cadd[e] = 0.f;
-      if (colv) {
-        if constexpr (sizeof(OutT) == 4) {
-          const float4 c4 = *reinterpret_cast<const float4 *>(colv + ncol0 + l15 * 4);
-          cadd[0] = c4.x; cadd[1] = c4.y; cadd[2] = c4.z; cadd[3] = c4.w;
-        } else {
-          const float4 c0 = *reinterpret_cast<const float4 *>(colv + ncol0 + (lane & 7) * 8);
-          const float4 c1 = *reinterpret_cast<const float4 *>(colv + ncol0 + (lane & 7) * 8 + 4);
-          cadd[0] = c0.x; cadd[1] = c0.y; cadd[2] = c0.z; cadd[3] = c0.w;
-          cadd[4] = c1.x; cadd[5] = c1.y; cadd[6] = c1.z; cadd[7] = c1.w;
-        }
-      }
-      auto fin = [&](float a, float add, float rnv) -> float {
-        float v = MODE == EPI_L2DIST ? rnv + add - 2.0f * a : a + add;
-        if (MODE == VTC_EPI_GELU) v = quick_gelu<sizeof(T) == 4>(v);
-        if (MODE == EPI_SCALE) v *= scale;
-        return v;
-      };
-      // residual mode: the x rows of pass i+1 are fetched while pass i is transposed and stored
-      auto x_ptr = [&](int i, int k) -> float * {
-        const int m = m0 + (wr * TM + i) * 16 + (lane >> 4) + 4 * k;
-        return reinterpret_cast<float *>(p.out) + (size_t)m * ldo + ncol0 + l15 * 4;
-      };
-      float4 xc[4], xn[4];
-      if (MODE == VTC_EPI_RESID) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) xc[k] = *reinterpret_cast<const float4 *>(x_ptr(0, k));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (MODE == VTC_EPI_RESID && i + 1 < TM) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) xn[k] = *reinterpret_cast<const float4 *>(x_ptr(i + 1, k));
-        }
-        // 1. registers -> LDS: final fp32 values in [16 rows][64 cols]
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          *reinterpret_cast<float4 *>(tr + l15 * TS + 16 * j + 4 * g) =
-              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // 2. LDS -> global, row-contiguous
-        const int mrow0 = m0 + (wr * TM + i) * 16;
-        if constexpr (sizeof(OutT) == 4) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int r = (lane >> 4) + 4 * k, cc = l15 * 4;
-            float4 v = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
-            const int m = mrow0 + r;
-            {
-              const float rnv = MODE == EPI_L2DIST ? p.epi.rown[m] : 0.f;
-              v.x = fin(v.x, cadd[0], rnv); v.y = fin(v.y, cadd[1], rnv); v.z = fin(v.z, cadd[2], rnv); v.w = fin(v.w, cadd[3], rnv);
-            }
-            size_t orow = (size_t)m;
-            bool live = true;
-            if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && (m % p.epi.skip_mod) == 0) live = false;
-            if (MODE == EPI_PATCH) {
-              const int np = m % p.epi.P, ft = m / p.epi.P;
-              const int tt = ft % p.epi.F, item = ft / p.epi.F;
-              orow = p.epi.frames_major ? (size_t)item * p.epi.T + 1 + (size_t)tt * p.epi.P + np
-                                        : (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
-              const float4 p4 = *reinterpret_cast<const float4 *>(p.epi.pos + (size_t)(1 + np) * p.N + ncol0 + cc);
-              v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
-              if (p.epi.temporal) {
-                const float4 t4 = *reinterpret_cast<const float4 *>(p.epi.temporal + (size_t)tt * p.N + ncol0 + cc);
-                v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
-              }
-            }
-            float *o = reinterpret_cast<float *>(p.out) + orow * ldo + ncol0 + cc;
-            if (MODE == VTC_EPI_RESID) {
-              if (live) {
-                const float4 x = xc[k];
-                *reinterpret_cast<float4 *>(o) = make_float4(x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w);
-              }
-            } else {
-              *reinterpret_cast<float4 *>(o) = v;
-            }
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int r = (lane >> 3) + 8 * k, cc = (lane & 7) * 8;
-            float4 v0 = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
-            float4 v1 = *reinterpret_cast<const float4 *>(tr + r * TS + cc + 4);
-            v0.x = fin(v0.x, cadd[0], 0.f); v0.y = fin(v0.y, cadd[1], 0.f); v0.z = fin(v0.z, cadd[2], 0.f); v0.w = fin(v0.w, cadd[3], 0.f);
-            v1.x = fin(v1.x, cadd[4], 0.f); v1.y = fin(v1.y, cadd[5], 0.f); v1.z = fin(v1.z, cadd[6], 0.f); v1.w = fin(v1.w, cadd[7], 0.f);
-            uint4 pk;
-            pk.x = (unsigned)f2bf(v0.x) | ((unsigned)f2bf(v0.y) << 16);
-            pk.y = (unsigned)f2bf(v0.z) | ((unsigned)f2bf(v0.w) << 16);
-            pk.z = (unsigned)f2bf(v1.x) | ((unsigned)f2bf(v1.y) << 16);
-            pk.w = (unsigned)f2bf(v1.z) | ((unsigned)f2bf(v1.w) << 16);
-            bf16_t *o = reinterpret_cast<bf16_t *>(p.out) + (size_t)(mrow0 + r) * ldo + ncol0 + cc;
-            *reinterpret_cast<uint4 *>(o) = pk;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (MODE == VTC_EPI_RESID) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) xc[k] = xn[k];
-        }
-      }
-      if (has_next) __syncthreads();       // the transposition area becomes the next K-step's staging buffer
-    } else {
-      // Generic path: edge tiles (M or N not a multiple of the tile, odd leading dimension).
-      // Fully unrolled: a runtime index into acc[][] would send the accumulators to scratch.
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int m = m0 + (wr * TM + i) * 16 + (lane & 15);
-        bool live = m < p.M;
-        if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && live && (m % p.epi.skip_mod) == 0) live = false;
-        if (live) {
-          size_t orow = (size_t)m;
-          const float *posrow = nullptr, *temprow = nullptr;
-          float rn = 0.f;
-          if (MODE == EPI_PATCH) {
-            const int np = m % p.epi.P, ft = m / p.epi.P;
-            const int tt = ft % p.epi.F, item = ft / p.epi.F;
-            orow = p.epi.frames_major ? (size_t)item * p.epi.T + 1 + (size_t)tt * p.epi.P + np
-                                      : (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
-            posrow = p.epi.pos + (size_t)(1 + np) * p.N;
-            if (p.epi.temporal) temprow = p.epi.temporal + (size_t)tt * p.N;
-          }
-          if (MODE == EPI_L2DIST) rn = p.epi.rown[m];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wc * TN + j) * 16 + g * 4;
-            OutT *o = reinterpret_cast<OutT *>(p.out) + orow * ldo + n;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (n + e < p.N) {
-                float x = acc[i][j][e];
-                if (p.bias) x += p.bias[n + e];
-                if (MODE == VTC_EPI_GELU) x = quick_gelu<sizeof(T) == 4>(x);
-                if (MODE == EPI_PATCH) x += posrow[n + e] + (temprow ? temprow[n + e] : 0.f);
-                if (MODE == EPI_L2DIST) x = rn + p.epi.coln[n + e] - 2.0f * x;
-                if (MODE == EPI_SCALE) x *= scale;
-                if (MODE == VTC_EPI_RESID) reinterpret_cast<float *>(o)[e] += x;
-                else ElemOps<OutT>::store(o + e, x);
-              }
-            }
-          }
-        }
-      }
-    }
+    tile_epilogue<T, MODE, OutT, WM, WN, TM, TN, STAGE / NW>(acc, p, m0, n0, ((cur + NSTAGE - 1) % NSTAGE) * STAGE);
+    if (has_next) __syncthreads();         // the transposition area becomes the next K-step's staging buffer
 
     if (!has_next) break;
     li += nb_x; m0 = m0n; n0 = n0n;
     tile_offsets<AG>(a_off, m0, p.M, p.lda_bytes, wave_u, lane);
     tile_offsets<WG>(w_off, n0, p.N, p.ldw_bytes, wave_u, lane);
+    has_next = li + nb_x < nt_x;
+    if (has_next) decode(start_x + li + nb_x, m0n, n0n);
+  }
+}
+
+
+// =====================================================================================================
+// Phased 256x256 bf16 kernel -- the tower shapes (every problem that fills the chip with 256x256 tiles).
+//
+// Same tile, LDS image, swizzle, persistent XCD-aware walk and epilogue as gemm_kernel; what differs is the
+// K loop.  gemm_kernel's waves run free between one barrier per K-step: each issues its LDS reads, its MFMAs and
+// its share of the next slab's LDS-DMA whenever its own program gets there.  Measured on that loop (ablation
+// builds, 8192^3): 1120 TFLOP/s as is, 1449 without the DMA, 1242 without the LDS reads, 1852 with neither --
+// the matrix pipe idles half the time because LDS reads, DMA landing (LDS writes) and MFMA issue of eight
+// unsynchronised waves interfere, and moving the DMA issue around (top of step, interleaved, one loader wave per
+// SIMD) changes nothing.  Here a K-tile is FOUR phases, one 64x32 output quadrant x K=64 each:
+//     {issue the quadrant's new fragment reads; issue 2 LDS-DMA pieces (1/4 of the next K-tile);
+//      s_barrier; lgkmcnt(0); setprio 1; 16 MFMA; setprio 0; vmcnt(2); s_barrier}
+// with waves 4-7 running ONE BARRIER BEHIND waves 0-3: on every SIMD one wave is inside an uninterrupted MFMA
+// cluster while its partner reads LDS and issues DMA, and they swap at every barrier.  The next K-tile streams
+// in a quarter per phase with one quarter always in flight across the barriers (counted vmcnt, never 0).  Quadrant walk (0,0) (0,1) (1,1) (1,0): 12 / 4 / 8 / 4 fragment reads; a quarter is the
+// 128 activation rows or weight rows the next K-tile's phase needs first: A0, W0, W1, A1.
+// (structure after the 8-phase schedule of the CDNA HIP guide, section 5.)
+template <int MODE, typename OutT>
+__global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p) {
+  using T = bf16_t;
+  constexpr int WM = 2, WN = 4, TM = 8, TN = 4, NW = 8, BM = 256, BN = 256;
+  constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;
+  constexpr int SUPER = SUPER_ROWS / BM;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = lane >> 4;
+
+  // ---- persistent, XCD-aware tile walk (as gemm_kernel) ----
+  const int ntiles = p.MT * p.NT, nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int nb_x = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);
+  const int nt_x = (ntiles >> 3) + (xcd < (ntiles & 7) ? 1 : 0);
+  const int start_x = xcd * (ntiles >> 3) + min(xcd, ntiles & 7);
+  auto decode = [&](int logical, int &m0, int &n0) {
+    const int per_super = SUPER * p.NT;
+    const int sr = logical / per_super, rem = logical - sr * per_super;
+    const int gsz = min(SUPER, p.MT - sr * SUPER);
+    const int nt = rem / gsz;
+    m0 = (sr * SUPER + (rem - nt * gsz)) * BM;
+    n0 = nt * BN;
+  };
+  int li = slot;
+  if (li >= nt_x) return;                      // uniform for the whole workgroup
+  int m0, n0;
+  decode(start_x + li, m0, n0);
+  int m0n = 0, n0n = 0;
+  bool has_next = li + nb_x < nt_x;
+  if (has_next) decode(start_x + li + nb_x, m0n, n0n);
+
+  const int ksteps = p.K / 64;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)lds);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int swz = (lane >> 1) & 7;
+  // fragment read addresses inside a stage: activation fragment i = rows wr*128 + 16 i .., weight fragment j
+  const unsigned a_rd = (wr * 128 + (lane & 15)) * ROWB;
+  const unsigned w_rd = A_BYTES + (wc * 64 + (lane & 15)) * ROWB;
+  const unsigned coff0 = ((0 + g) ^ swz) << 4, coff1 = ((4 + g) ^ swz) << 4;
+
+  // ---- LDS-DMA quarters ----
+  // first 8-row group of this wave's two (consecutive) pieces of quarter A0 / W0; A1 = +8 groups, W1 = +4
+  const int ga0 = (wave_u >> 2) * 16 + (wave_u & 3) * 2;
+  const int gw0 = (wave_u >> 1) * 8 + (wave_u & 1) * 2;
+  // per-lane source offset of a piece whose group index is even; the odd one (second piece) uses ^ 64
+  const unsigned a_vo = (unsigned)(lane >> 3) * (unsigned)p.lda_bytes + (((lane & 7) ^ (lane >> 4)) << 4);
+  const unsigned w_vo = (unsigned)(lane >> 3) * (unsigned)p.ldw_bytes + (((lane & 7) ^ (lane >> 4)) << 4);
+  // Two pieces: 16 rows x 128 B of operand `base` starting at tile row (row0 + 8 grp), K byte kb, into
+  // lds_dst .. +2 KiB.  Interior tiles: wave-uniform 64-bit base + 32-bit lane offset, one M0 write (the
+  // instruction offset moves both the source and the LDS destination; the second base is pre-decremented).
+  auto stage2 = [&](const char *base, int row0, int nrows, int ld_bytes, unsigned vo, int grp, int kb, unsigned lds_dst,
+                    bool fast) __attribute__((always_inline)) {
+    if (fast) {
+      const char *sb0 = base + (size_t)(row0 + grp * 8) * ld_bytes + kb;
+      const char *sb1 = sb0 + (ptrdiff_t)8 * ld_bytes - 1024;
+#ifdef VTC_ABLATE_DMA_EXEC1   // timing experiment: same instruction stream, one lane's worth of data
+      asm volatile(
+          "s_mov_b32 m0, %4\n\t"
+          "s_mov_b64 exec, 1\n\t"
+          "global_load_lds_dwordx4 %0, %2\n\t"
+          "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+          "s_mov_b64 exec, -1"
+          :
+          : "v"(vo), "v"(vo ^ 64u), "s"(sb0), "s"(sb1), "s"(lds_dst)
+          : "memory");
+#else
+      asm volatile(
+          "s_mov_b32 m0, %4\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %0, %2\n\t"
+          "global_load_lds_dwordx4 %1, %3 offset:1024"
+          :
+          : "v"(vo), "v"(vo ^ 64u), "s"(sb0), "s"(sb1), "s"(lds_dst)
+          : "memory");
+#endif
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int r = (grp + q) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int gr = row0 + r;
+        gr = gr < nrows ? gr : nrows - 1;         // clamp: tail rows re-read a valid row, never stored
+        glds16(base + (size_t)gr * ld_bytes + kb + c * 16, __builtin_amdgcn_readfirstlane(lds_dst + q * 1024));
+      }
+    }
+  };
+  // quarter qi (0 = A0, 1 = W0, 2 = W1, 3 = A1) of K-tile kk of the tile at (sm, sn) into stage st
+  auto stage_quarter = [&](int qi, int sm, int sn, int kk, unsigned st, bool fastA, bool fastW) __attribute__((always_inline)) {
+    if (qi == 0 || qi == 3) {
+      const int grp = ga0 + (qi == 3 ? 8 : 0);
+      stage2(p.A, sm, p.M, p.lda_bytes, a_vo, grp, kk * ROWB, st + grp * 1024, fastA);
+    } else {
+      const int grp = gw0 + (qi == 2 ? 4 : 0);
+      stage2(p.W, sn, p.N, p.ldw_bytes, w_vo, grp, kk * ROWB, st + A_BYTES + grp * 1024, fastW);
+    }
+  };
+
+  int cur = 0;
+  {   // prologue: the whole first K-tile
+    const bool fa = m0 + BM <= p.M, fw = n0 + BN <= p.N;
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) stage_quarter(qi, m0, n0, 0, lds_base, fa, fw);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  u32x4 aS[4][2], wS[2][2];     // register subtile: 4 activation x 2 weight fragments x 2 K halves
+  while (true) {
+    // PING-PONG: waves 4-7 (the SIMD partners of waves 0-3) run one barrier behind, so that on every SIMD one
+    // wave is in its MFMA cluster while the other issues its fragment reads and DMA pieces.  (Re-joined before
+    // the epilogue: the transposition scratch is the stage the lagging half reads last.)
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < ksteps; ++t) {
+      const unsigned st_cur = lds_base + cur * STAGE, st_nxt = lds_base + (cur ^ 1) * STAGE;
+      // what streams in during this K-tile: K-tile t+1 of this tile, or K-tile 0 of the next tile (when this is
+      // the workgroup's last tile: K-tile 0 of this one again, into the stage nobody reads any more)
+      const int kn = t + 1;
+      const bool to_next = kn == ksteps && has_next;
+      const int sm = to_next ? m0n : m0, sn = to_next ? n0n : n0, kk = kn < ksteps ? kn : 0;
+      const bool fastA = sm + BM <= p.M, fastW = sn + BN <= p.N;
+      static_for<4>([&](auto ph_c) __attribute__((always_inline)) {
+        constexpr int ph = decltype(ph_c)::value;
+        constexpr int qm = ph >> 1, qn = (ph == 1 || ph == 2) ? 1 : 0;
+        // (a) this quadrant's new fragments (published by the wait + barrier that ended the previous phase)
+        if constexpr (ph != 2) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            lds_read16(wS[j][0], st_cur + w_rd + coff0, (qn * 2 + j) * 16 * ROWB);
+            lds_read16(wS[j][1], st_cur + w_rd + coff1, (qn * 2 + j) * 16 * ROWB);
+          }
+        }
+        if constexpr (ph == 0 || ph == 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            lds_read16(aS[i][0], st_cur + a_rd + coff0, (qm * 4 + i) * 16 * ROWB);
+            lds_read16(aS[i][1], st_cur + a_rd + coff1, (qm * 4 + i) * 16 * ROWB);
+          }
+        }
+        // (b) one quarter of the next K-tile
+#if defined(VTC_ABLATE_DMA)
+#elif defined(VTC_ABLATE_HALF_DMA)
+        if constexpr (ph == 0 || ph == 3) stage_quarter(ph, sm, sn, kk, st_nxt, fastA, fastW);
+#else
+        stage_quarter(ph, sm, sn, kk, st_nxt, fastA, fastW);
+#endif
+        // (c) everybody has issued; the reads land while we wait here
+#if defined(VTC_PHASED_WAIT_FIRST)
+        lgkm_wait_subtile(aS, wS);
+        __builtin_amdgcn_s_barrier();
+#elif defined(VTC_PHASED_ONE_BARRIER)
+        lgkm_wait_subtile(aS, wS);
+#else
+        __builtin_amdgcn_s_barrier();
+        lgkm_wait_subtile(aS, wS);
+#endif
+        // (d) the MFMA cluster
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) Mma<T>::run(wS[j][ks], aS[i][ks], acc[qm * 4 + i][qn * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        // (e) my pieces of every quarter but the newest have landed; the barrier makes that everybody's.  A
+        //     quarter is read three phases after its issue at the earliest, and the half of the workgroup that runs
+        //     one barrier ahead must not read what the other half has not waited for yet: hence one phase early.
+#ifndef VTC_ABLATE_VMWAIT
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#endif
+        __builtin_amdgcn_s_barrier();
+      });
+      cur ^= 1;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // re-join: waves 4-7 finish their last MFMA cluster
+
+    tile_epilogue<T, MODE, OutT, WM, WN, TM, TN, STAGE / NW>(acc, p, m0, n0, (cur ^ 1) * STAGE);
+    if (!has_next) break;
+    __builtin_amdgcn_s_barrier();          // the transposition area is the next K-tile's DMA target
+    li += nb_x; m0 = m0n; n0 = n0n;
     has_next = li + nb_x < nt_x;
     if (has_next) decode(start_x + li + nb_x, m0n, n0n);
   }
@@ -390,7 +619,24 @@ int run(GemmParams p, hipStream_t stream) {
   return 0;
 }
 
-int g_force_tile = 0;   // 0 = heuristic, 1 = small, 2 = big (diagnostics: VTC_GEMM_TILE)
+template <int MODE, typename OutT>
+int run_phased(GemmParams p, hipStream_t stream) {
+  p.MT = cdiv(p.M, 256); p.NT = cdiv(p.N, 256);
+  const int ntiles = p.MT * p.NT;
+  const size_t shmem = (size_t)2 * 512 * ROWB;          // 128 KiB: one workgroup per CU
+  const int grid = min(ntiles, num_cus());
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_phased_kernel<MODE, OutT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_phased_kernel<MODE, OutT>), dim3(grid), dim3(512), shmem, stream, p);
+  VTC_LAUNCH_CHECK("gemm_phased");
+  return 0;
+}
+
+int g_force_tile = 0;   // 0 = heuristic, 1 = small, 2 = big free-running, 4 = big phased (diagnostics: VTC_GEMM_TILE)
 
 template <typename T, int MODE, typename OutT>
 int run_cfg(const GemmParams &p, hipStream_t stream) {
@@ -402,6 +648,8 @@ int run_cfg(const GemmParams &p, hipStream_t stream) {
     if (g_force_tile == 2) big = true;
     const int kst = p.K / Mma<T>::KPR;
     if (g_force_tile == 3 && kst >= 2) return run<T, MODE, OutT, 4, 2, 4, 4, 3>(p, stream);   // 256x128, 3-stage ring
+    if (g_force_tile == 4) big = true;
+    if (big && g_force_tile != 2) return run_phased<MODE, OutT>(p, stream);
     if (big) return run<T, MODE, OutT, 2, 4, 8, 4, 2>(p, stream);
   }
   return run<T, MODE, OutT, 2, 2, 4, 4, 2>(p, stream);

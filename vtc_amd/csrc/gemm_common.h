@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+#include <type_traits>
+
 namespace vtcgemm {
 
 constexpr int ROWB = 128;          // bytes of K per LDS row
@@ -75,7 +77,11 @@ __device__ __forceinline__ void glds16(const char *gsrc, unsigned lds_dst) {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one 128-bit register tuple (asm "v" operand)
 __device__ __forceinline__ void lds_read16(u32x4 &dst, unsigned addr, int off) {
   // "memory": keeps the read below the barrier that publishes the buffer and above the one that recycles it
+#ifdef VTC_ABLATE_LDSREAD
+  asm volatile("; no read %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory");
+#else
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory");
+#endif
 }
 template <int N>
 __device__ __forceinline__ void lgkm_wait(u32x4 &x) {
@@ -85,6 +91,22 @@ template <int N, int TN>
 __device__ __forceinline__ void lgkm_wait_frags(u32x4 &x, u32x4 (&w)[TN]) {
   static_assert(TN == 4, "four weight fragments per wave");
   asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(x), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N));
+}
+
+// all twelve fragments of the phased kernel's register subtile (whatever subset was just re-read) have landed
+__device__ __forceinline__ void lgkm_wait_subtile(u32x4 (&a)[4][2], u32x4 (&w)[2][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]),
+                 "+v"(a[3][1]), "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
 }
 
 // Same DMA with a wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: the per-lane part is

@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip config 3 and the sweep")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--sweep-n", type=int, default=10000)
+    ap.add_argument("--stress-n", type=int, default=50000, help="second sweep size (0 = skip)")
     ap.add_argument("--hipgraph", action="store_true", help="also time the step replayed from a captured HIP graph (last, opt-in)")
     args = ap.parse_args()
 
@@ -256,26 +257,31 @@ def main():
         torch.cuda.empty_cache()
 
         # ---- sweep: N x N sim + R@1/5/10 both directions, sharded by query rows ---------------
-        N = args.sweep_n
-        lo, hi = vdist.shard_bounds(N, rank, world)
-        g2 = torch.Generator().manual_seed(123)
-        va = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
-        noise = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
-        tb = torch.nn.functional.normalize(va + 4.0 * noise * torch.rand(N, 1, generator=g2), dim=-1)   # planted positives, R@K < 1
-        va_l, tb_l = va[lo:hi].to(device), tb[lo:hi].to(device)
-        for prec_name, prec in (("f32", L.SWEEP_F32), ("bf16x3", L.SWEEP_BF16X3)):
-            vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec)      # warm-up
-            barrier_sync(world)
-            t0 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                r_ab, r_ba = vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec)
-            barrier_sync(world)
-            dts = max_over_ranks(time.perf_counter() - t0, world, device) / reps
-            extra[f"sweep_{N}_{prec_name}_ms"] = round(1e3 * dts, 3)
-            extra[f"sweep_{N}_{prec_name}_recall"] = {"t_from_v": r_ab, "v_from_t": r_ba}
-            # algorithmic HBM bytes, materialised fp32 matrix: 8 N^2 per direction
-            extra[f"sweep_{N}_{prec_name}_algorithmic_GBps"] = round(2 * 8.0 * N * N / dts / 1e9, 1)
+        # N = 10k (BASELINE configs[3]) and the 50k stress size (configs[4]); embeddings drawn directly
+        # (SURVEY 8d), planted positives so that R@K < 1.
+        for N in [n for n in (args.sweep_n, args.stress_n) if n > 0]:
+            lo, hi = vdist.shard_bounds(N, rank, world)
+            g2 = torch.Generator().manual_seed(123)
+            va = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
+            noise = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
+            tb = torch.nn.functional.normalize(va + 4.0 * noise * torch.rand(N, 1, generator=g2), dim=-1)
+            va_l, tb_l = va[lo:hi].to(device), tb[lo:hi].to(device)
+            precs = [("f32", L.SWEEP_F32), ("bf16x3", L.SWEEP_BF16X3)] + ([("bf16", L.SWEEP_BF16)] if N == args.stress_n else [])
+            for prec_name, prec in precs:
+                vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec)      # warm-up
+                barrier_sync(world)
+                t0 = time.perf_counter()
+                reps = 3
+                for _ in range(reps):
+                    r_ab, r_ba = vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec)
+                barrier_sync(world)
+                dts = max_over_ranks(time.perf_counter() - t0, world, device) / reps
+                extra[f"sweep_{N}_{prec_name}_ms"] = round(1e3 * dts, 3)
+                extra[f"sweep_{N}_{prec_name}_recall"] = {"t_from_v": r_ab, "v_from_t": r_ba}
+                # algorithmic HBM bytes, materialised fp32 matrix: 8 N^2 per direction, whole job
+                extra[f"sweep_{N}_{prec_name}_algorithmic_GBps"] = round(2 * 8.0 * N * N / dts / 1e9, 1)
+            del va, noise, tb, va_l, tb_l
+            torch.cuda.empty_cache()
         if args.hipgraph:
             # opt-in and last: in this ROCm build everything that ran after a capture was 1.5-6x slower
             try:

@@ -18,7 +18,7 @@ for N in [int(a) for a in sys.argv[1:]] or [10000, 50000]:
     a = torch.nn.functional.normalize(torch.randn(N, 512, generator=g), dim=-1).cuda()
     b = torch.nn.functional.normalize(a.cpu() + 0.5 * torch.randn(N, 512, generator=g) / 22.6, dim=-1).cuda()
     for name, prec in (("f32", L.SWEEP_F32), ("bf16x3", L.SWEEP_BF16X3), ("bf16", L.SWEEP_BF16)):
-        for rpb in (0,):
+        for rpb in [int(x) for x in os.environ.get('RPB', '0').split(',')]:
             ops.l2_topk(a, b, 11, precision=prec, rows_per_block=rpb, return_dists=False)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -32,5 +32,5 @@ for N in [int(a) for a in sys.argv[1:]] or [10000, 50000]:
             lib.vtc_prof_end(stream, ms, cnt, work)
             d = {L.PROF_CLASSES[i]: (round(ms[i], 3), cnt[i]) for i in range(n) if cnt[i]}
             gemm_ms = ms[0] + ms[1]
-            print(f"N={N} {name:7s} one direction: wall {wall*1e3:8.3f} ms | {d} | gemm {2.0*N*N*512/gemm_ms/1e9:7.1f} TFLOP/s (x3 K for bf16x3) | "
+            print(f"N={N} {name:7s} rpb={rpb} one direction: wall {wall*1e3:8.3f} ms | {d} | gemm {2.0*N*N*512/gemm_ms/1e9:7.1f} TFLOP/s (x3 K for bf16x3) | "
                   f"topk {4.0*N*N/ms[5]/1e6:7.1f} GB/s | matrix traffic 8N^2/wall = {8.0*N*N/wall/1e9:7.1f} GB/s", flush=True)

@@ -6,7 +6,7 @@
 //   vtc_clip_loss   0.5 (CE(sim, arange) + CE(sim^T, arange)) (model/loss.py:18-22)
 //
 // Sweep pipeline (per block of query rows, the fp32 distance matrix "tiled in HBM" as
-// BASELINE.json prescribes; blocks are sized to stay resident in the 256 MiB Infinity Cache):
+// BASELINE.json prescribes; blocks of up to 2 GiB):
 //   1. row norms |q|^2, |g|^2 in fp32 (once);
 //   2. distance GEMM with the L2 epilogue  d = |q|^2 + |g|^2 - 2 q.g  (gemm.hip, EPI_L2DIST):
 //        F32     fp32 MFMA, exact;
@@ -20,6 +20,8 @@
 //      insertion is a ballot/popcount rank + one shuffle.  Order is (distance, index)
 //      lexicographic => ties resolve to the lowest gallery index, independent of scan order.
 #include "common.h"
+
+#include <algorithm>
 
 namespace {
 
@@ -72,8 +74,9 @@ struct WaveList {
       if (cv < tau || (cv == tau && ci < tau_i)) {       // wave-uniform: the list may have tightened meanwhile
         const bool less = (bd < cv) || (bd == cv && bi < ci);
         const int pos = __popcll(__ballot(less));
-        const float ud = __shfl_up(bd, 1, 64);
-        const int ui = __shfl_up(bi, 1, 64);
+        // shift by one lane: DPP wave_shr:1 (a VALU move, no LDS round trip as __shfl_up's ds_bpermute)
+        const float ud = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, bd), 0x138, 0xf, 0xf, false));
+        const int ui = __builtin_amdgcn_update_dpp(0, bi, 0x138, 0xf, 0xf, false);
         if (lane > pos) { bd = ud; bi = ui; }
         if (lane == pos) { bd = cv; bi = ci; }
         tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bd), depth - 1));
@@ -84,9 +87,12 @@ struct WaveList {
   __device__ __forceinline__ bool beats(float v, int idx) const { return v < tau || (v == tau && idx < tau_i); }
 };
 
-// One wave per (row, column segment): streams its segment with 2 x 16-byte loads in flight per lane and
-// keeps the segment's best `depth`; segments exist only to put enough waves (bytes in flight) on the chip
-// when a block has few rows.  S == 1 writes the final ids/dists directly.
+// One wave per (row, column segment): streams its segment 1024 columns per step -- four 16-byte loads per lane,
+// the next TWO steps' loads already in flight while this step is screened (8 KiB per wave outstanding; with the ~2 us
+// loaded latency of this path two 16-byte loads per wave and 13 waves per CU left the kernel latency-bound at
+// 0.8-1.2 TB/s).  Screening is one min over the lane's 16 values against the wave-uniform k-th best: after
+// warm-up almost every step is 4 loads + 15 v_min + 1 ballot.  Segments exist only to put enough waves on the
+// chip when a block has few rows; S == 1 writes the final ids/dists directly.
 __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__ dist, int ld, int n_rows, int n_cols, int depth,
                                                        int S, int seg_cols, int64_t *__restrict__ ids, float *__restrict__ dists,
                                                        size_t out_row0, float *__restrict__ part_d, int *__restrict__ part_i) {
@@ -99,12 +105,11 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__
   WaveList wl;
   wl.init();
   const bool vec = (ld & 3) == 0;
-  for (int base = c_lo; base < c_hi; base += 512) {
-    float v[8];
-    int cidx[2] = {base + lane * 4, base + 256 + lane * 4};
+  // lane's 4 x 4 columns of the step starting at `base`: base + 256 h + 4 lane + e
+  auto load_step = [&](int base, float (&v)[16]) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = cidx[h];
+    for (int h = 0; h < 4; ++h) {
+      const int c = base + 256 * h + lane * 4;
       if (vec && c + 3 < c_hi) {
         const float4 t = *reinterpret_cast<const float4 *>(row + c);
         v[4 * h] = t.x; v[4 * h + 1] = t.y; v[4 * h + 2] = t.z; v[4 * h + 3] = t.w;
@@ -113,16 +118,44 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__
         for (int e = 0; e < 4; ++e) v[4 * h + e] = c + e < c_hi ? row[c + e] : INFINITY;
       }
     }
-    bool pass[8], anyp = false;
+  };
+  float cur[16], nxt[16], nx2[16];
+  load_step(c_lo, cur);
+  if (c_lo + 1024 < c_hi) load_step(c_lo + 1024, nxt);
+  for (int base = c_lo; base < c_hi; base += 1024) {
+    if (base + 2048 < c_hi) load_step(base + 2048, nx2);     // two steps (8 KiB per wave) in flight behind this one
+    float m = cur[0];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int idx = cidx[q >> 2] + (q & 3);
-      pass[q] = idx < c_hi && wl.beats(v[q], idx);
-      anyp |= pass[q];
+    for (int q = 1; q < 16; ++q) m = fminf(m, cur[q]);
+    // m <= tau is necessary for any of the 16 to beat (tau, tau_i); columns past c_hi hold +inf and never insert
+    if (__ballot(m <= wl.tau) != 0ull) {
+      if (base == c_lo) {
+        // Warm-up: with an empty list every value "beats" it and 1024 candidates would be offered one by one.
+        // Offer each lane's smallest first (64 candidates): the list's k-th best is then already within a few
+        // ranks of the step's true k-th best and the remaining 960 are screened against it.
+        int qm = 0;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) qm = cur[q] < cur[qm] ? q : qm;     // first minimum = lowest column
+        float vm = cur[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) vm = q == qm ? cur[q] : vm;
+        const int im = base + 256 * (qm >> 2) + lane * 4 + (qm & 3);
+        wl.offer(vm, im, im < c_hi, lane, depth);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int idx = base + 256 * (q >> 2) + lane * 4 + (q & 3);
+          wl.offer(cur[q], idx, q != qm && idx < c_hi && wl.beats(cur[q], idx), lane, depth);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int idx = base + 256 * (q >> 2) + lane * 4 + (q & 3);
+          wl.offer(cur[q], idx, idx < c_hi && wl.beats(cur[q], idx), lane, depth);
+        }
+      }
     }
-    if (__ballot(anyp) == 0ull) continue;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) wl.offer(v[q], cidx[q >> 2] + (q & 3), pass[q], lane, depth);
+    for (int q = 0; q < 16; ++q) { cur[q] = nxt[q]; nxt[q] = nx2[q]; }
   }
   if (lane < depth) {
     if (S == 1) {
@@ -223,10 +256,13 @@ SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block)
   s.gb = (bf16_t *)take((size_t)ng * d * parts * 2);
   int rpb = rows_per_block;
   if (rpb <= 0) {
-    const size_t budget = (size_t)128 << 20;                 // keep the live block inside the Infinity Cache
-    rpb = (int)(budget / ((size_t)ng * 4));
-    rpb = rpb / 128 * 128;
-    if (rpb < 128) rpb = 128;
+    // Big blocks: a block's top-k pass costs one list warm-up per (row, segment) wave, and the GEMM a fill/drain
+    // per launch, so FEWER, LARGER blocks win over Infinity-Cache residency (measured at 50k x 50k, F32 /
+    // BF16X3, one direction: 128 MiB blocks 27.5 / 19.6 ms, 2 GiB blocks 21.4 / 10.4 ms; top-k 1.5 -> 5.0 TB/s).
+    const size_t budget = (size_t)2 << 30;
+    rpb = (int)std::min<size_t>(budget / ((size_t)ng * 4), (size_t)1 << 20);
+    rpb = rpb / 256 * 256;
+    if (rpb < 256) rpb = 256;
   }
   if (rpb > nq) rpb = nq;
   s.rows_per_block = rpb;
@@ -271,11 +307,11 @@ extern "C" int vtc_l2_topk(const float *gallery, const float *queries, int ng, i
       rc = launch_gemm(s.qb + (size_t)r0 * d * parts, s.gb, nullptr, s.dist, rows, ng, d * parts, VTC_BF16, e, stream);
     if (rc) return rc;
     {
-      // enough (row, segment) waves to keep ~8k waves' worth of loads in flight
+      // enough (row, segment) waves to fill the chip (32 waves per CU)
       // (every segment pays its own warm-up insertions, so segments are used only when rows alone cannot fill the chip)
-      int S = cdiv(2048, rows);
+      int S = cdiv(8192, rows);
       S = S < 1 ? 1 : (S > MAX_SEG ? MAX_SEG : S);
-      int seg_cols = cdiv(cdiv(ng, S), 512) * 512;
+      int seg_cols = cdiv(cdiv(ng, S), 1024) * 1024;
       S = cdiv(ng, seg_cols);
       ProfScope prof(VTC_PROF_TOPK, (double)rows * ng * 4, stream);
       hipLaunchKernelGGL(row_topk_kernel, dim3(cdiv(rows * S, 4)), dim3(256), 0, stream, s.dist, ng, rows, ng, depth, S, seg_cols, ids,

@@ -10,13 +10,14 @@ synthetic random pixels and tokens, random-init weights of the real architecture
 `value` = pairs encoded per second over the whole job (all ranks; weak scaling: B per GPU fixed).
 
 Extra objects on the same JSON line:
-  roofline      the dominant kernel (the bf16 MFMA GEMM, every instantiation of gemm_kernel<bf16>):
+  roofline      the dominant kernel class (the bf16 MFMA GEMM: gemm_phased_kernel and gemm_kernel<bf16>):
                 achieved = sum(2MNK) / sum(kernel time), both measured live with HIP events on the
-                launch stream inside the timed region (vtc_prof_*); peak = 2.5 PFLOP/s dense bf16.
+                launch stream inside the timed region (vtc_prof_*); peak = 2.5 PFLOP/s dense bf16;
+                traffic = HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json).
   cpu_baseline  the oracle (plain PyTorch fp32 restatement of the reference) timed on this box's host
                 cores on a bounded sample of the same workload (rank 0, N = 1 only).
   extra         secondary measurements of the same path: config 3 (8-frame TimeSformer + CAM)
-                pairs/s, and the N x N sweep (sim + R@1/5/10 both directions) in ms at N = 10k,
+                pairs/s, and the N x N sweep (sim + R@1/5/10 both directions) in ms at N = 10k and 50k,
                 sharded over the ranks with one RCCL all-gather + one all-reduce when N > 1.
 """
 from __future__ import annotations
@@ -102,6 +103,20 @@ def cpu_baseline(kind_pairs=96):
                 sample=f"oracle fp32 forward of config 2 at B={B} (1 title + 5 comments per pair), best of 2, {best:.2f} s")
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel class, from the committed rocprofv3 PMC passes of this
+    same command (profiles/*_traffic.json, written by tools/summarize_profile.py; collected in separate
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs with the gfx950 correction).  None when no such file exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    try:
+        return round(float(json.load(open(files[-1]))["traffic_bytes_per_launch"]), 1)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,7 +200,7 @@ def main():
     achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
     roofline = dict(bound="mfma", achieved=round(achieved, 1), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
-                    traffic=None, kernel=f"gemm_kernel<{args.dtype}> (all epilogues)",
+                    traffic=pmc_traffic(), kernel=f"{args.dtype} GEMM: gemm_phased_kernel + gemm_kernel<{args.dtype}> (all epilogues)",
                     launches_per_step=g["launches"] // args.steps, avg_launch_us=round(1e3 * g["ms"] / max(1, g["launches"]), 2),
                     flop_per_launch=round(g["work"] / max(1, g["launches"]) / 1e9, 3))
     breakdown = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}

@@ -134,3 +134,50 @@ def test_attention_time_and_space_row_maps(dtype, F):
     got = out[:, 1:].reshape(B, P, F, W).permute(0, 2, 1, 3)
     assert (got - ref_s[:, :, 1:]).abs().max() < tol
     assert (cls_out.cpu().reshape(B, F, W) - ref_s[:, :, 0]).abs().max() < tol
+
+
+# ---- the phased 256x256 bf16 kernel (chosen when the problem has >= 384 tiles of 256x256) -------------------
+@pytest.mark.parametrize("M,N,K", [(8192, 3072, 512), (8200, 3000, 768), (12800, 2304, 64), (16384, 1536, 1024)])
+def test_gemm_phased_store_bias(M, N, K):
+    """Interior and edge tiles (M, N not multiples of 256), one K-tile and many, fp32 and bf16 outputs."""
+    L, ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    # integer-valued: exact, catches any quarter / fragment / lane-map mistake; W rows and A rows all distinct
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float() + (torch.arange(N).float()[:, None] % 3)
+    bias = torch.randint(-5, 6, (N,), generator=g).float()
+    ref = (a @ w.t() + bias)                      # |values| < 2^24: exact in fp32
+    out = ops.gemm(a.cuda().bfloat16(), w.cuda().bfloat16(), bias.cuda(), out_dtype=torch.float32).cpu()
+    assert torch.equal(out, ref), (out - ref).abs().max()
+    # random data, bf16 output
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    ad, wd = a.cuda().bfloat16(), w.cuda().bfloat16()
+    ref = ad.float() @ wd.float().t() + bias.cuda()
+    out = ops.gemm(ad, wd, bias.cuda(), out_dtype=torch.bfloat16).float()
+    assert (out - ref).abs().max() < 2e-2 * max(1.0, float(ref.abs().max()))
+    out = ops.gemm(ad, wd, bias.cuda(), out_dtype=torch.float32)
+    assert (out - ref).abs().max() < 2e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_gemm_phased_epilogues():
+    L, ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 393 * 24, 3072, 256          # 37 x 12 tiles, last M tile partial
+    a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g)
+    ad, wd = a.cuda().bfloat16(), w.cuda().bfloat16()
+    lin = ad.float() @ wd.float().t() + b.cuda()
+    out = ops.gemm(ad, wd, b.cuda(), epilogue=L.EPI_GELU).float()
+    assert (out - quick_gelu(lin)).abs().max() < 2e-2
+    x0 = torch.randn(M, N, generator=g).cuda()
+    x = x0.clone()
+    ops.gemm(ad, wd, b.cuda(), epilogue=L.EPI_RESID, out=x, skip_mod=393)
+    ref = x0 + lin
+    ref[0::393] = x0[0::393]
+    assert (x - ref).abs().max() < 2e-4
+    assert torch.equal(x[0::393], x0[0::393])
+    # many tiles per workgroup (persistent walk + cross-tile prefetch), result independent of the walk
+    M2 = 256 * 40
+    a2 = torch.randint(-2, 3, (M2, 128), generator=g).float()
+    w2 = torch.randint(-2, 3, (4096, 128), generator=g).float()
+    out = ops.gemm(a2.cuda().bfloat16(), w2.cuda().bfloat16(), None, out_dtype=torch.float32).cpu()
+    assert torch.equal(out, a2 @ w2.t())

@@ -26,6 +26,13 @@ def short(name):
     return name.replace("unsigned short", "bf16")
 
 
+BF16 = "bf16 GEMM (gemm_phased_kernel + gemm_kernel<bf16,...>)"
+
+
+def is_bf16_gemm(n):
+    return n.startswith("gemm_phased_kernel") or n.startswith("gemm_kernel<bf16")
+
+
 def main():
     stats_dir, fetch_dir, write_dir, out = sys.argv[1:5]
     steps = int(sys.argv[5]) if len(sys.argv) > 5 else 1
@@ -39,7 +46,7 @@ def main():
         n = short(r["Name"])
         if float(r["Percentage"]) >= 0.05:
             lines.append(f"| `{n}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |")
-        cls = "gemm_kernel<bf16,...>" if n.startswith("gemm_kernel<bf16") else ("gemm_kernel<float,...>" if n.startswith("gemm_kernel<float") else None)
+        cls = BF16 if is_bf16_gemm(n) else ("gemm_kernel<float,...>" if n.startswith("gemm_kernel<float") else None)
         if cls:
             agg[cls][0] += int(r["Calls"]); agg[cls][1] += int(r["TotalDurationNs"])
     lines += ["", "## aggregated over template instantiations", "", "| kernel | calls | total ms | avg us |", "|---|---|---|---|"]
@@ -66,11 +73,18 @@ def main():
         wt = wr[n][1] * 1024 / max(1, wr[n][0]) / 1e6
         if rd + wt > 1.0:
             lines.append(f"| `{n}` | {c} | {rd:.1f} | {wt:.1f} |")
-        if n.startswith("gemm_kernel<bf16"):
-            tot["gemm_kernel<bf16,...>"][0] += c; tot["gemm_kernel<bf16,...>"][1] += 2 * fe[n][1] * 1024; tot["gemm_kernel<bf16,...>"][2] += wr[n][1] * 1024
+        if is_bf16_gemm(n):
+            tot[BF16][0] += c; tot[BF16][1] += 2 * fe[n][1] * 1024; tot[BF16][2] += wr[n][1] * 1024
     for k, (c, rd, wt) in tot.items():
         lines.append(f"| **{k} (all)** | {c} | {rd/c/1e6:.1f} | {wt/c/1e6:.1f} |")
         lines += ["", f"traffic per launch of `{k}`: {(rd+wt)/c/1e6:.1f} MB"]
+        # bench.py reads this file for roofline.traffic (bytes per launch of the dominant kernel class)
+        import json
+        json.dump({"kernel": k, "launches": c, "read_bytes_per_launch": rd / c, "write_bytes_per_launch": wt / c,
+                   "traffic_bytes_per_launch": (rd + wt) / c,
+                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --no-extra --no-cpu`; "
+                             "reads = 2 x FETCH_SIZE KiB (gfx950 correction), writes = WRITE_SIZE KiB"},
+                  open(out + "_traffic.json", "w"), indent=1)
     open(out + ".md", "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 

@@ -248,7 +248,7 @@ def main():
             torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
         m3 = m3.eval().to(device)
         m3.compute_dtype = cdt
-        B3 = 64
+        B3 = min(B, 256)      # SURVEY 8d C3 at B = 256 (the config's own batch_size of 50 under-fills the chip)
         vid = torch.randn(B3, 8, 3, 224, 224, generator=gen).to(device).to(cdt)
         t3, c3 = title[:B3].contiguous(), comments[:B3].contiguous()
         for _ in range(2):

@@ -641,9 +641,12 @@ int g_force_tile = 0;   // 0 = heuristic, 1 = small, 2 = big free-running, 4 = b
 template <typename T, int MODE, typename OutT>
 int run_cfg(const GemmParams &p, hipStream_t stream) {
   if constexpr (sizeof(T) == 2) {
-    // big tiles when they still fill the chip ~1.5 times over
-    const long big_tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 256);
-    bool big = big_tiles * 2 >= (long)num_cus() * 3;
+    // Tile choice by estimated rounds: a round of 256x256 tiles (one per CU) costs ~1.0, a round of 128x128 tiles
+    // (two per CU) ~0.65 of that (calibrated on the vision-tower shapes, tools/gemm_tile_choice.py: 150 big tiles
+    // -> big, 297 -> small, 75 -> small, 256 -> big, 450 and more -> big).
+    const long tb = (long)cdiv(p.M, 256) * cdiv(p.N, 256), ts = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
+    const long rb = (tb + num_cus() - 1) / num_cus(), rs = (ts + 2 * num_cus() - 1) / (2 * num_cus());
+    bool big = rb * 100 <= rs * 65;
     if (g_force_tile == 1) big = false;
     if (g_force_tile == 2) big = true;
     const int kst = p.K / Mma<T>::KPR;

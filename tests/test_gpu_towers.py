@@ -240,3 +240,40 @@ def test_product_fails_loudly_off_gpu_and_in_train_mode():
     m = m.cuda().train()
     with pytest.raises(RuntimeError):
         m(img.cuda(), txt.cuda())
+
+
+def test_full_size_batch_independence_and_oracle_spot_check():
+    """BASELINE sizes (config 2: 256 images + 1536 texts; config 3: 64 eight-frame videos), bf16: the towers run
+    on the phased 256x256 GEMM there, which the small cases above never reach.  Size-independent properties:
+    (i) an item's embedding does not depend on the batch it is in (first items re-encoded in a small batch, which
+    runs on the 128x128 kernel) and (ii) a few items agree with the fp32 oracle within the bf16 tolerance."""
+    from vtc_amd import towers
+    a = A.VIT_B32
+    sd = {}
+    sd.update(A.synth_visual(a, 61, prefix="model.visual."))
+    sd.update(A.synth_text(a, 62, prefix="model."))
+    pv = towers.PackedVision(cuda_sd(sd), "model.visual.", torch.bfloat16)
+    pt = towers.PackedText(cuda_sd(sd), "model.", torch.bfloat16, heads=a.transformer_heads)
+    img = A.synth_pixels((256, 3, 224, 224), 63)
+    txt = A.synth_tokens(1536, a, 64, empty_frac=0.1)
+    big_v = pv.forward(img.cuda()).cpu().numpy()
+    big_t = pt.forward(txt.cuda()).cpu().numpy()
+    assert np.isfinite(big_v).all() and np.isfinite(big_t).all()
+    small_v = pv.forward(img[:8].cuda()).cpu().numpy()
+    small_t = pt.forward(txt[:24].cuda()).cpu().numpy()
+    report("ViT batch independence (256 vs 8)", np.abs(unit(big_v[:8]) - unit(small_v)).max(), 1e-3)
+    report("text batch independence (1536 vs 24)", np.abs(unit(big_t[:24]) - unit(small_t)).max(), 1.5e-3)
+    ref_v = CR.encode_image(img[:3], sd, a, "model.visual.").numpy()
+    ref_t = CR.encode_text(txt[:6], sd, a, "model.").numpy()
+    report("ViT @B=256 vs oracle", np.abs(unit(big_v[:3]) - unit(ref_v)).max(), 1e-3)
+    report_text("text @S=1536 vs oracle", unit(big_t[:6]), unit(ref_t), torch.bfloat16, a.embed_dim)
+    # config 3: TimeSformer (alt) video tower, 64 videos x 8 frames
+    sdv = A.synth_visual(a, 65, nframes=8, prefix="model.visual.")
+    pvt = towers.PackedVision(cuda_sd(sdv), "model.visual.", torch.bfloat16)
+    vid = A.synth_pixels((64, 8, 3, 224, 224), 66)
+    big = pvt.forward(vid.cuda()).cpu().numpy()
+    small = pvt.forward(vid[:2].cuda()).cpu().numpy()
+    assert np.isfinite(big).all()
+    report("TimeSformer batch independence (64 vs 2)", np.abs(unit(big[:2]) - unit(small)).max(), 1e-3)
+    ref = T.timesformer_alt(vid[:1], sdv, a, "model.visual.").numpy()
+    report("TimeSformer @B=64 vs oracle", np.abs(unit(big[:1]) - unit(ref)).max(), 1e-3)

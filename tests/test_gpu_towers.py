@@ -277,3 +277,20 @@ def test_full_size_batch_independence_and_oracle_spot_check():
     report("TimeSformer batch independence (64 vs 2)", np.abs(unit(big[:2]) - unit(small)).max(), 1e-3)
     ref = T.timesformer_alt(vid[:1], sdv, a, "model.visual.").numpy()
     report("TimeSformer @B=64 vs oracle", np.abs(unit(big[:1]) - unit(ref)).max(), 1e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_timesformer_16_frames_vs_oracle(dtype):
+    """BASELINE configs[4]: 16-frame TimeSformer (VisualTransformer(nframes=16), timesformer_clip_alt.py:214-250);
+    time attention over 16 tokens, 1 + 49*16 tokens per video -- checked against the live oracle."""
+    from vtc_amd import towers
+    for a, B in ((A.TINY, 3), (A.VIT_B32, 2)):
+        sd = A.synth_visual(a, 71, nframes=16, prefix="v.")
+        for k in list(sd):                                   # trained temporal_fc is not zero
+            if k.endswith("temporal_fc.weight"):
+                sd[k] = torch.randn(sd[k].shape, generator=torch.Generator().manual_seed(72)) * 0.02
+        x = A.synth_pixels((B, 16, 3, a.image_resolution, a.image_resolution), 73)
+        ref = T.timesformer_alt(x, sd, a, "v.").numpy()
+        pv = towers.PackedVision(cuda_sd(sd), "v.", dtype)
+        out = pv.forward(x.cuda()).cpu().numpy()
+        report(f"TimeSformer F=16 {a.vision_width} {dtype}", np.abs(unit(out) - unit(ref)).max(), tol_for(dtype, a.embed_dim))

@@ -281,7 +281,7 @@ def main():
             noise = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
             tb = torch.nn.functional.normalize(va + 4.0 * noise * torch.rand(N, 1, generator=g2), dim=-1)
             va_l, tb_l = va[lo:hi].to(device), tb[lo:hi].to(device)
-            precs = [("f32", L.SWEEP_F32), ("bf16x3", L.SWEEP_BF16X3)] + ([("bf16", L.SWEEP_BF16)] if N == args.stress_n else [])
+            precs = [("exact", L.SWEEP_EXACT), ("f32", L.SWEEP_F32), ("bf16x3", L.SWEEP_BF16X3)] + ([("bf16", L.SWEEP_BF16)] if N == args.stress_n else [])
             for prec_name, prec in precs:
                 vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec)      # warm-up
                 barrier_sync(world)

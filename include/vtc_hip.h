@@ -37,7 +37,11 @@ enum { VTC_ACT_NONE = 0, VTC_ACT_NORMALIZE = 1, VTC_ACT_SQUASH = 2, VTC_ACT_TANH
 /* sweep precision: how q.g is formed from fp32 embeddings */
 enum { VTC_SWEEP_F32 = 0,      /* fp32 MFMA, bitwise a k-ordered fmaf chain            */
        VTC_SWEEP_BF16X3 = 1,   /* hi/lo bf16 split, 3 products: |err| ~ 5e-7           */
-       VTC_SWEEP_BF16 = 2 };   /* plain bf16 operands: |err| ~ 1e-3, ranks may differ  */
+       VTC_SWEEP_BF16 = 2,     /* plain bf16 operands: |err| ~ 1e-3, ranks may differ  */
+       VTC_SWEEP_EXACT = 3 };  /* BF16X3 candidate lists (depth + 21, at least 32) re-ranked with
+                                  fp64 distances sum_k (q_k - g_k)^2; a row whose candidate list is
+                                  not provably a superset of its true top-`depth` is recomputed by
+                                  fp64 brute force: ranks are those of exact fp64 arithmetic        */
 
 /* One residual attention block.
  * upstream clip/model.py ResidualAttentionBlock; TimeSformer extras

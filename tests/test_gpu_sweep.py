@@ -84,18 +84,21 @@ def test_similarity_and_clip_loss():
     assert abs(float(ops.clip_loss(s.cuda())) - float(M.clip_loss(s))) < 1e-5
 
 
-def test_full_size_properties_10k():
+@pytest.mark.parametrize("prec", ["exact", "f32"])
+def test_full_size_properties_10k(prec):
     """BASELINE size (10k x 10k): size-independent properties instead of a full oracle run:
     self-search finds itself at rank 1 with distance ~0, dists ascending, ids a valid set,
     and a row sample agrees with the fp64 oracle."""
+    from vtc_amd import _lib as L
     from vtc_amd import ops
+    p = L.SWEEP_EXACT if prec == "exact" else L.SWEEP_F32
     n, d = 10000, 512
     a, b = planted(n, d, seed=1)
     ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
-    ids, dists = ops.l2_topk(ta, ta, 11)
+    ids, dists = ops.l2_topk(ta, ta, 11, precision=p)
     assert torch.equal(ids[:, 0].cpu(), torch.arange(n))
     assert dists[:, 0].abs().max() < 1e-5
-    ids, dists = ops.l2_topk(ta, tb, 11)
+    ids, dists = ops.l2_topk(ta, tb, 11, precision=p)
     dn = dists.cpu().numpy()
     assert (np.diff(dn, axis=1) >= 0).all()
     idn = ids.cpu().numpy()
@@ -104,3 +107,40 @@ def test_full_size_properties_10k():
     i64, d64 = E.l2_topk(a, b[rows], 11, np.float64)
     assert np.abs(dn[rows] - d64).max() < 4e-6
     assert (idn[rows] == i64).mean() > 0.999
+    if prec == "exact":
+        assert np.array_equal(idn[rows], i64)
+
+
+@pytest.mark.parametrize("n,d", [(300, 64), (1000, 512), (4099, 512)])
+def test_l2_topk_exact_mode_has_fp64_ranks(n, d):
+    """VTC_SWEEP_EXACT: BF16X3 candidate lists re-ranked in fp64 -> the ids are those of exact fp64 arithmetic on
+    EVERY row (no near-tie exemption), the distances are the fp64 distances rounded to fp32."""
+    from vtc_amd import _lib as L
+    from vtc_amd import ops
+    a, b = planted(n, d, seed=n + 1)
+    for depth in (1, 11, 40):
+        ids, dists = ops.l2_topk(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), depth, precision=L.SWEEP_EXACT)
+        ids64, d64 = E.l2_topk(a, b, depth, np.float64)
+        direct = ((b[:, None, :].astype(np.float64) - a[ids64].astype(np.float64)) ** 2).sum(-1)   # sum (q - g)^2
+        assert np.array_equal(ids.cpu().numpy(), ids64)
+        assert np.abs(dists.cpu().numpy() - direct).max() < 3e-7
+
+
+def test_l2_topk_exact_mode_dense_near_ties_take_the_fp64_brute_force():
+    """A cluster of near-duplicates spaced far below the split-bf16 resolution, exact duplicates, and a gallery
+    smaller than the candidate list: rows that cannot be certified are recomputed by fp64 brute force."""
+    from vtc_amd import _lib as L
+    from vtc_amd import ops
+    rng = np.random.default_rng(9)
+    a = unit(rng.standard_normal((2000, 512))).astype(np.float32)
+    base = a[7].copy()
+    for j in range(60):                                      # 60 near-duplicates of row 7, 1e-7-scale differences
+        a[100 + j] = base
+        a[100 + j, j % 512] += np.float32(1e-7 * (j + 1))
+    a[500:530] = a[499]                                      # 30 exact duplicates: ties resolve to the lowest index
+    q = np.stack([base, a[499], unit(rng.standard_normal(512)).astype(np.float32)])
+    ids, _ = ops.l2_topk(torch.from_numpy(a).cuda(), torch.from_numpy(q).cuda(), 11, precision=L.SWEEP_EXACT)
+    assert np.array_equal(ids.cpu().numpy(), E.l2_topk(a, q, 11, np.float64)[0])
+    small = a[:20]                                           # gallery smaller than the candidate depth
+    ids, _ = ops.l2_topk(torch.from_numpy(small).cuda(), torch.from_numpy(q).cuda(), 11, precision=L.SWEEP_EXACT)
+    assert np.array_equal(ids.cpu().numpy(), E.l2_topk(small, q, 11, np.float64)[0])

@@ -17,7 +17,7 @@ for N in [int(a) for a in sys.argv[1:]] or [10000, 50000]:
     g = torch.Generator().manual_seed(123)
     a = torch.nn.functional.normalize(torch.randn(N, 512, generator=g), dim=-1).cuda()
     b = torch.nn.functional.normalize(a.cpu() + 0.5 * torch.randn(N, 512, generator=g) / 22.6, dim=-1).cuda()
-    for name, prec in (("f32", L.SWEEP_F32), ("bf16x3", L.SWEEP_BF16X3), ("bf16", L.SWEEP_BF16)):
+    for name, prec in (("f32", L.SWEEP_F32), ("bf16x3", L.SWEEP_BF16X3), ("bf16", L.SWEEP_BF16), ("exact", L.SWEEP_EXACT)):
         for rpb in [int(x) for x in os.environ.get('RPB', '0').split(',')]:
             ops.l2_topk(a, b, 11, precision=prec, rows_per_block=rpb, return_dists=False)
             torch.cuda.synchronize()

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("VTC_HIP_LIB") or os.path.join(_HERE, "lib", "libvtc_h
 
 VTC_F32, VTC_BF16, VTC_U8 = 0, 1, 2
 ACT_NONE, ACT_NORMALIZE, ACT_SQUASH, ACT_TANH = 0, 1, 2, 3
-SWEEP_F32, SWEEP_BF16X3, SWEEP_BF16 = 0, 1, 2
+SWEEP_F32, SWEEP_BF16X3, SWEEP_BF16, SWEEP_EXACT = 0, 1, 2, 3
 EPI_STORE, EPI_GELU, EPI_RESID = 0, 1, 2
 PROF_CLASSES = ("gemm_bf16", "gemm_f32", "attention", "norm", "embed", "topk")
 

@@ -501,6 +501,16 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
   }
 
   u32x4 aS[4][2], wS[2][2];     // register subtile: 4 activation x 2 weight fragments x 2 K halves
+#ifdef VTC_GEMM_STAMPS
+  // diagnostic build: s_memtime at the tile-level phase boundaries; sums leave through p.dbg only
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tsp = 0;
+  auto stamp = [&]() -> unsigned long long {
+    unsigned long long tsv;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tsv)::"memory");
+    return tsv;
+  };
+  tsp = stamp();
+#endif
   while (true) {
     // PING-PONG: waves 4-7 (the SIMD partners of waves 0-3) run one barrier behind, so that on every SIMD one
     // wave is in its MFMA cluster while the other issues its fragment reads and DMA pieces.  (Re-joined before
@@ -574,11 +584,26 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
       });
       cur ^= 1;
     }
+#ifdef VTC_GEMM_STAMPS
+    { const unsigned long long t = stamp(); ph[0] += t - tsp; tsp = t; }       // K loop (incl. the stagger barrier)
+#endif
     if (wr == 0) __builtin_amdgcn_s_barrier();   // re-join: waves 4-7 finish their last MFMA cluster
+#ifdef VTC_GEMM_STAMPS
+    { const unsigned long long t = stamp(); ph[1] += t - tsp; tsp = t; }       // re-join wait
+#endif
 
     tile_epilogue<T, MODE, OutT, WM, WN, TM, TN, STAGE / NW>(acc, p, m0, n0, (cur ^ 1) * STAGE);
+#ifdef VTC_GEMM_STAMPS
+    { const unsigned long long t = stamp(); ph[2] += t - tsp; tsp = t; ph[5] += 1; }   // epilogue issue
+    if (!has_next && lane == 0 && p.dbg) {
+      for (int i = 0; i < 6; ++i) p.dbg[((size_t)bid * NW + wave) * 8 + i] = ph[i];
+    }
+#endif
     if (!has_next) break;
     __builtin_amdgcn_s_barrier();          // the transposition area is the next K-tile's DMA target
+#ifdef VTC_GEMM_STAMPS
+    { const unsigned long long t = stamp(); ph[3] += t - tsp; tsp = t; }       // post-epilogue barrier
+#endif
     li += nb_x; m0 = m0n; n0 = n0n;
     has_next = li + nb_x < nt_x;
     if (has_next) decode(start_x + li + nb_x, m0n, n0n);
@@ -631,7 +656,27 @@ int run_phased(GemmParams p, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_done = true;
   }
+#ifdef VTC_GEMM_STAMPS
+  static unsigned long long *dbg = nullptr;
+  if (!dbg) (void)hipMalloc(&dbg, (size_t)256 * 8 * 8 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(dbg, 0, (size_t)256 * 8 * 8 * sizeof(unsigned long long), stream);
+  p.dbg = dbg;
+#endif
   hipLaunchKernelGGL((gemm_phased_kernel<MODE, OutT>), dim3(grid), dim3(512), shmem, stream, p);
+#ifdef VTC_GEMM_STAMPS
+  {
+    static unsigned long long host[256 * 8 * 8];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(host, dbg, sizeof(host), hipMemcpyDeviceToHost);
+    double sum[6] = {0, 0, 0, 0, 0, 0};
+    const int nw = grid * 8;
+    for (int w = 0; w < nw; ++w)
+      for (int i = 0; i < 6; ++i) sum[i] += (double)host[(size_t)w * 8 + i];
+    if (sum[5] > 0)
+      fprintf(stderr, "[phased stamps] M=%d N=%d K=%d mode %d: per tile cycles: k-loop %.0f | re-join %.0f | epilogue %.0f | barrier %.0f (tiles/wave %.1f)\n",
+              p.M, p.N, p.K, MODE, sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5], sum[5] / nw);
+  }
+#endif
   VTC_LAUNCH_CHECK("gemm_phased");
   return 0;
 }

@@ -47,6 +47,9 @@ struct GemmParams {
   int lda_bytes, ldw_bytes, ldo;
   int MT, NT;
   int exp_arg;   // diagnostics only (env VTC_GEMM_EXP), 0 in production
+#ifdef VTC_GEMM_STAMPS
+  unsigned long long *dbg;   // diagnostic build: per-wave phase cycle sums
+#endif
   GemmEpi epi;
 };
 

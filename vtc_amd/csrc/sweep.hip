@@ -190,6 +190,113 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
   }
 }
 
+// ---- VTC_SWEEP_EXACT ------------------------------------------------------------------------------------
+// fp64 squared distance sum_k (q_k - g_k)^2 of one (query, gallery) pair by the whole wave (lanes stride over k)
+__device__ __forceinline__ double wave_dist64(const float *__restrict__ q, const float *__restrict__ g, int d, int lane) {
+  double s = 0.0;
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 a = *reinterpret_cast<const float4 *>(q + c), b = *reinterpret_cast<const float4 *>(g + c);
+    const double e0 = (double)a.x - (double)b.x, e1 = (double)a.y - (double)b.y, e2 = (double)a.z - (double)b.z,
+                 e3 = (double)a.w - (double)b.w;
+    s += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);   // xor butterfly: every lane ends with the same bits
+  return s;
+}
+
+// One wave per query row: fp64 distances of the row's `cdepth` BF16X3 candidates, sorted by (distance, index); the
+// first `depth` are the answer IF the candidate list provably contains the true top-`depth`: every true member j
+// has approx(j) <= approx_(depth) + 2 eps, so it is on the list when approx_(cdepth) > approx_(depth) + 2 eps, with
+// eps = kappa (|q|^2 + max|g|^2) a worst-case bound of the split-bf16 distance error (dropped lo.lo products, the
+// two bf16 roundings of each operand, fp32 accumulation of 3 D products).  Otherwise the row is flagged.
+__global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restrict__ queries, const float *__restrict__ gallery, int nq,
+                                                           int ng, int d, const int64_t *__restrict__ cand, const float *__restrict__ cand_d,
+                                                           int cdepth, int depth, const float *__restrict__ qn, const float *__restrict__ gmax,
+                                                           float kappa, int64_t *__restrict__ ids, float *__restrict__ dists,
+                                                           int *__restrict__ flags) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nq) return;
+  const float *q = queries + (size_t)r * d;
+  const int64_t my = lane < cdepth ? cand[(size_t)r * cdepth + lane] : -1;
+  double md = INFINITY;
+  for (int c = 0; c < cdepth; ++c) {
+    const long long j = __shfl((long long)my, c, 64);
+    if (j < 0) continue;                                  // wave-uniform
+    const double dj = wave_dist64(q, gallery + (size_t)j * d, d, lane);
+    if (lane == c) md = dj;
+  }
+  // rank among the candidates by (fp64 distance, index); absent slots sort last
+  int rank = 0;
+  for (int c = 0; c < cdepth; ++c) {
+    const double od = __shfl(md, c, 64);
+    const long long oi = __shfl((long long)my, c, 64);
+    if (oi >= 0 && (od < md || (od == md && oi < (long long)my))) ++rank;
+  }
+  if (lane < cdepth && my >= 0 && rank < depth) {
+    ids[(size_t)r * depth + rank] = my;
+    if (dists) dists[(size_t)r * depth + rank] = (float)md;
+  }
+  if (lane == 0) {
+    bool sure = ng <= cdepth;                             // the list IS the gallery
+    if (!sure) {
+      const float eps = kappa * (qn[r] + *gmax);
+      sure = cand_d[(size_t)r * cdepth + cdepth - 1] > cand_d[(size_t)r * cdepth + depth - 1] + 2.0f * eps;
+    }
+    flags[r] = sure ? 0 : 1;
+  }
+}
+
+// Flagged rows only (dense near-ties: duplicates in the gallery): fp64 brute force over the whole gallery, one
+// workgroup per row, a sorted (distance, index) list per wave (one entry per lane), merged by wave 0.
+__global__ __launch_bounds__(256) void exact_fallback_kernel(const float *__restrict__ queries, const float *__restrict__ gallery, int ng,
+                                                             int d, int depth, const int *__restrict__ flags, int64_t *__restrict__ ids,
+                                                             float *__restrict__ dists) {
+  const int r = blockIdx.x;
+  if (!flags[r]) return;                                  // uniform for the workgroup
+  __shared__ double sd[4][64];
+  __shared__ int si[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float *q = queries + (size_t)r * d;
+  double bd = INFINITY;
+  int bi = 0x7fffffff;
+  auto offer = [&](double cv, int ci) {                   // wave-uniform candidate
+    const double tau = __shfl(bd, depth - 1, 64);
+    const int tau_i = __shfl(bi, depth - 1, 64);
+    if (!(cv < tau || (cv == tau && ci < tau_i))) return;
+    const bool less = bd < cv || (bd == cv && bi < ci);
+    const int pos = __popcll(__ballot(less));
+    const double ud = __shfl_up(bd, 1, 64);
+    const int ui = __shfl_up(bi, 1, 64);
+    if (lane > pos) { bd = ud; bi = ui; }
+    if (lane == pos) { bd = cv; bi = ci; }
+  };
+  for (int j = wave; j < ng; j += 4) offer(wave_dist64(q, gallery + (size_t)j * d, d, lane), j);
+  sd[wave][lane] = bd;
+  si[wave][lane] = bi;
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 1; w < 4; ++w)
+      for (int e = 0; e < depth; ++e)
+        if (si[w][e] != 0x7fffffff) offer(sd[w][e], si[w][e]);
+    if (lane < depth) {
+      ids[(size_t)r * depth + lane] = bi == 0x7fffffff ? -1 : (int64_t)bi;
+      if (dists) dists[(size_t)r * depth + lane] = (float)bd;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void max_reduce_kernel(const float *__restrict__ x, int n, float *__restrict__ out) {
+  __shared__ float part[4];
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, x[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+}
+
 __global__ __launch_bounds__(256) void recall_hits_kernel(const int64_t *__restrict__ ids, int n, int depth, int64_t target_offset,
                                                           int k0, int k1, int k2, int k3, int nk, unsigned long long *hits) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -241,12 +348,22 @@ struct SweepWs {
   float *part_d;
   int *part_i;
   int rows_per_block;
+  // VTC_SWEEP_EXACT only
+  int64_t *cand;
+  float *cand_d, *gmax;
+  int *flags;
+  int cdepth;
   size_t total;
 };
 constexpr int MAX_SEG = 16;
 
-SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block) {
+// candidate list depth of the EXACT mode: 21 spare ranks behind the requested ones, at least 32, at most 64 / n_gallery
+int exact_cdepth(int depth, int ng) { return std::min(std::min(64, ng), std::max(32, depth + 21)); }
+
+SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block, int depth = 0) {
   SweepWs s;
+  const bool exact = precision == VTC_SWEEP_EXACT;
+  if (exact) precision = VTC_SWEEP_BF16X3;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return ws ? ws + o : (char *)nullptr; };
   s.qn = (float *)take((size_t)nq * 4);
@@ -269,6 +386,14 @@ SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block)
   s.dist = (float *)take((size_t)rpb * ng * 4);
   s.part_d = (float *)take((size_t)rpb * MAX_SEG * 64 * 4);
   s.part_i = (int *)take((size_t)rpb * MAX_SEG * 64 * 4);
+  s.cand = nullptr; s.cand_d = nullptr; s.gmax = nullptr; s.flags = nullptr; s.cdepth = 0;
+  if (exact) {
+    s.cdepth = 64;                                          // sized for the deepest list (depth is not known to the size query)
+    s.cand = (int64_t *)take((size_t)nq * 64 * 8);
+    s.cand_d = (float *)take((size_t)nq * 64 * 4);
+    s.flags = (int *)take((size_t)nq * 4);
+    s.gmax = (float *)take(256);
+  }
   s.total = off;
   return s;
 }
@@ -279,15 +404,8 @@ extern "C" size_t vtc_l2_topk_workspace_bytes(int n_gallery, int n_queries, int 
   return plan(nullptr, n_gallery, n_queries, d, precision, rows_per_block).total;
 }
 
-extern "C" int vtc_l2_topk(const float *gallery, const float *queries, int ng, int nq, int d, int depth, int precision,
-                           int rows_per_block, int64_t *ids, float *dists, void *ws, size_t ws_bytes, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  VTC_CHECK(ng > 0 && nq > 0 && d > 0, "l2_topk: empty problem");
-  VTC_CHECK(depth >= 1 && depth <= 64 && depth <= ng, "l2_topk: depth=%d must be in [1, min(64, n_gallery)]", depth);
-  VTC_CHECK(precision >= VTC_SWEEP_F32 && precision <= VTC_SWEEP_BF16, "l2_topk: bad precision %d", precision);
-  VTC_CHECK(d % 64 == 0, "l2_topk: d=%d must be a multiple of 64", d);
-  SweepWs s = plan((char *)ws, ng, nq, d, precision, rows_per_block);
-  VTC_CHECK(ws && ws_bytes >= s.total, "l2_topk: workspace too small (%zu < %zu)", ws_bytes, s.total);
+static int l2_topk_impl(const float *gallery, const float *queries, int ng, int nq, int d, int depth, int precision,
+                        int64_t *ids, float *dists, const SweepWs &s, hipStream_t stream) {
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, queries, s.qn, nq, d);
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(ng, 4)), dim3(256), 0, stream, gallery, s.gn, ng, d);
   const int parts = precision == VTC_SWEEP_BF16X3 ? 3 : 1;
@@ -322,6 +440,31 @@ extern "C" int vtc_l2_topk(const float *gallery, const float *queries, int ng, i
     }
     VTC_LAUNCH_CHECK("row_topk");
   }
+  return 0;
+}
+
+extern "C" int vtc_l2_topk(const float *gallery, const float *queries, int ng, int nq, int d, int depth, int precision,
+                           int rows_per_block, int64_t *ids, float *dists, void *ws, size_t ws_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VTC_CHECK(ng > 0 && nq > 0 && d > 0, "l2_topk: empty problem");
+  VTC_CHECK(depth >= 1 && depth <= 64 && depth <= ng, "l2_topk: depth=%d must be in [1, min(64, n_gallery)]", depth);
+  VTC_CHECK(precision >= VTC_SWEEP_F32 && precision <= VTC_SWEEP_EXACT, "l2_topk: bad precision %d", precision);
+  VTC_CHECK(d % 64 == 0, "l2_topk: d=%d must be a multiple of 64", d);
+  SweepWs s = plan((char *)ws, ng, nq, d, precision, rows_per_block);
+  VTC_CHECK(ws && ws_bytes >= s.total, "l2_topk: workspace too small (%zu < %zu)", ws_bytes, s.total);
+  if (precision != VTC_SWEEP_EXACT) return l2_topk_impl(gallery, queries, ng, nq, d, depth, precision, ids, dists, s, stream);
+  // EXACT: BF16X3 candidate lists, fp64 re-rank, verified superset property, fp64 brute force for the rest
+  const int cdepth = exact_cdepth(depth, ng);
+  if (int rc = l2_topk_impl(gallery, queries, ng, nq, d, cdepth, VTC_SWEEP_BF16X3, s.cand, s.cand_d, s, stream)) return rc;
+  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, s.gn, ng, s.gmax);
+  // worst-case error of a split-bf16 distance, relative to |q|^2 + max|g|^2: dropped lo.lo products and the second
+  // bf16 rounding of both operands (3 * 2^-18), fp32 accumulation of 3 d products (3 d * 2^-24), fp32 row norms
+  // (d * 2^-24), the epilogue's three roundings
+  const float kappa = 3.0f / 262144.0f + 4.0f * d / 16777216.0f + 1e-6f;
+  hipLaunchKernelGGL(exact_rerank_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, queries, gallery, nq, ng, d, s.cand, s.cand_d, cdepth,
+                     depth, s.qn, s.gmax, kappa, ids, dists, s.flags);
+  hipLaunchKernelGGL(exact_fallback_kernel, dim3(nq), dim3(256), 0, stream, queries, gallery, ng, d, depth, s.flags, ids, dists);
+  VTC_LAUNCH_CHECK("l2_topk exact");
   return 0;
 }
 

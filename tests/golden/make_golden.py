@@ -150,6 +150,43 @@ def gen_loss():
          sim0=sims[0], sim1=sims[1], sim2=sims[2], loss=np.array(vals, dtype=np.float64))
 
 
+def gen_train_step():
+    """One (and a second) adapter-only training step of the reference: PretrainedCLIP_finaltf(freeze="all") in
+    train mode, clip_loss, torch.optim.Adam(lr=1e-3, amsgrad=True) over the parameters train.py:107 calls
+    final_adapter_layers (configs/pretrained_clip_comments_attn_frozen.jsonc).  The random_skip_adapter draw
+    (model.py:199-201) is made reproducible by seeding torch's generator right before each forward."""
+    m, a = build_wrapper("clip_finaltf", "TINY", seed=41, freeze="all", branch_to_adapt="text", branch_to_adapt_val="text",
+                         n_heads=2)
+    m.train()
+    torch.set_grad_enabled(True)
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert all(n.startswith(("final_transformer.", "final_linear.")) or n == "mask_embedding" for n in names), names
+    opt = torch.optim.Adam([p for _, p in m.named_parameters() if p.requires_grad], lr=1e-3, weight_decay=0, amsgrad=True)
+    B = 8
+    vis = A.synth_pixels((B, 3, a.image_resolution, a.image_resolution), 42)
+    title = A.synth_tokens(B, a, 43)
+    comments = A.synth_tokens(B * 5, a, 44, empty_frac=0.3).reshape(B, 5, -1)
+    out = {}
+    for step in range(2):
+        torch.manual_seed(100 + step)                  # consumed by :163 torch.rand([]) then :200 torch.rand(B)
+        opt.zero_grad()
+        res = m(vis, title, comments)
+        loss = ref_loss.clip_loss(res, None)
+        loss.backward()
+        out[f"loss{step}"] = float(loss)
+        if step == 0:
+            for n, p in m.named_parameters():
+                if p.requires_grad and p.grad is not None:
+                    out["grad0:" + n] = p.grad.detach().numpy().copy()
+        opt.step()
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            out["after2:" + n] = p.detach().numpy().copy()
+    torch.set_grad_enabled(False)
+    save("train_step_tiny", dict(kind="train_step", arch="TINY", B=B, wseed=41, xseed=42, tseed=43, cseed=44, empty_frac=0.3,
+                                 rng_seeds=[100, 101], n_heads=2, lr=1e-3), **out)
+
+
 if __name__ == "__main__":
     if os.environ.get("GOLDEN_ONLY"):
         globals()[os.environ["GOLDEN_ONLY"]]()
@@ -158,3 +195,4 @@ if __name__ == "__main__":
     gen_towers()
     gen_cam_at_init()
     gen_wrappers()
+    gen_train_step()

@@ -110,3 +110,43 @@ def test_identity_at_init_timesformer_equals_vit():
     tf = T.timesformer_alt(vid, sd, a, p="")
     vit = encode_image(img[:, 0], sd, a, p="")
     np.testing.assert_allclose(tf.numpy(), vit.numpy(), atol=5e-6)
+
+
+def test_train_step_oracle_vs_reference_golden():
+    """Adapter-only training step: the oracle's restated train-mode forward + autograd + restated
+    Adam(amsgrad) reproduce the reference's loss, every adapter gradient and the parameters after two steps."""
+    from dataclasses import asdict  # noqa: F401
+    from oracle import clip_ref as CR
+    from oracle import train_ref as TR
+    case, g = load_golden("train_step_tiny.npz")
+    a = A.TINY
+    sd = A.synth_model(a, case["wseed"], "clip_finaltf")
+    B = case["B"]
+    vis = A.synth_pixels((B, 3, a.image_resolution, a.image_resolution), case["xseed"])
+    title = A.synth_tokens(B, a, case["tseed"])
+    comments = A.synth_tokens(B * 5, a, case["cseed"], empty_frac=case["empty_frac"]).reshape(B, 5, -1)
+    with torch.no_grad():                                   # frozen towers: constants of the step
+        fv = CR.encode_image(vis, sd, a, "model.visual.").float()
+        ft = CR.encode_text(title, sd, a, "model.").float()
+        fc = CR.encode_text(comments.reshape(B * 5, -1), sd, a, "model.").float().reshape(B, 5, -1).permute(1, 0, 2)
+    empty = comments[..., 1] == A.EOT
+    params = {k: sd[k].clone() for k in TR.adapter_param_names(sd)}
+    sd = dict(sd); sd.update(params)
+    opt = TR.AdamAmsgrad({k: v for k, v in params.items()}, lr=case["lr"])
+    for step, seed in enumerate(case["rng_seeds"]):
+        torch.manual_seed(seed)
+        torch.rand([])                                       # model/model.py:163 consumes one draw first
+        skip = torch.rand(B) > 0.5                           # :200
+        loss, grads = TR.train_step(fv, ft, fc, empty, skip, sd, opt, n_heads=case["n_heads"])
+        assert abs(loss - float(g[f"loss{step}"])) < 2e-6 * max(1.0, abs(loss)), (step, loss, float(g[f"loss{step}"]))
+        if step == 0:
+            for k, v in grads.items():
+                ref = g["grad0:" + k]
+                assert np.abs(v.numpy() - ref).max() < 2e-6 * max(1e-3, np.abs(ref).max()) + 1e-8, k
+    for k in params:
+        d = np.abs(sd[k].numpy() - g["after2:" + k])
+        # Adam's step is lr * m / (sqrt(v) + 1e-8): where |grad| ~ 1e-8 its direction is decided by rounding noise, so
+        # elements with a vanishing gradient are only bounded by the two steps' maximum travel (2 lr)
+        big = np.abs(g["grad0:" + k]) > 1e-5 if ("grad0:" + k) in g else np.zeros(d.shape, bool)
+        assert d[big].max(initial=0.0) < 5e-6, k
+        assert d.max() <= 2.001 * case["lr"], k

@@ -179,6 +179,30 @@ int vtc_layernorm(const float *x, const float *g, const float *b, void *y, int r
 int vtc_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2, int a0,
                   int a1, int a2, int a3, int pstride, int dtype, void *stream);
 
+/* ---- adapter-only training step: backward + optimizer primitives, fp32 -------------------
+ * Replace, for PretrainedCLIP_finaltf with frozen towers (configs/pretrained_clip_comments_attn_frozen.jsonc), what
+ * torch.autograd does behind `loss.backward()` (trainer/trainer.py) for clip_loss (model/loss.py:18-22), normalize
+ * (model/model.py:26-27) and the CAM transformer (clip.model.Transformer, model/model.py:396-398), and
+ * torch.optim.Adam(amsgrad=True).step().  Orchestrated by vtc_amd/host/adapter_train.py; dgrad / wgrad matrix
+ * products are vtc_gemm calls on transposed operands. */
+int vtc_transpose_f32(const float *x, float *y, int rows, int cols, void *stream);            /* y[c][r] = x[r][c] */
+int vtc_colsum_f32(const float *x, float *out, int rows, int cols, void *stream);             /* bias gradients     */
+/* dx (+)= LN'(x; gamma)(dy), dgamma = sum_r dy xhat, dbeta = sum_r dy (eps 1e-5, biased variance) */
+int vtc_layernorm_bwd(const float *x, const float *gamma, const float *dy, float *dx, float *dgamma, float *dbeta, int rows,
+                      int width, int accumulate_dx, void *stream);
+/* unmasked attention backward, L <= 16, head_dim 64, sequences contiguous: qkv [n_seq*L, 3W], dout [n_seq*L, W] */
+int vtc_attention_small_bwd(const float *qkv, const float *dout, float *dqkv, int n_seq, int L, int heads, void *stream);
+/* QuickGELU: dy == NULL -> out = x sigmoid(1.702 x); else out = dy * d/dx */
+int vtc_quickgelu(const float *x, const float *dy, float *out, size_t n, void *stream);
+int vtc_normalize_rows_bwd(const float *x, const float *dy, float *dx, int n, int d, void *stream);
+/* dsim = d clip_loss / d sim; ws >= 4 n floats */
+int vtc_clip_loss_bwd(const float *sim, int n, float *dsim, void *ws, size_t ws_bytes, void *stream);
+/* torch.optim.Adam single-tensor step (weight_decay 0); step counts from 1; vmax only when amsgrad */
+int vtc_adam_step(float *p, const float *g, float *m, float *v, float *vmax, size_t n, float lr, float beta1, float beta2,
+                  float eps, int step, int amsgrad, void *stream);
+int vtc_axpby(float *out, const float *x, const float *y, float a, float b, size_t n, void *stream);   /* out = a x + b y  */
+int vtc_scale_rows(float *x, const float *s, int rows, int d, int group, void *stream);               /* x[r] *= s[r/group] */
+
 /* ---- optional per-launch timing (HIP events on the launch stream; bench/diagnostics) ----
  * Between vtc_prof_begin() and vtc_prof_end() every kernel launch of the library is bracketed by
  * two events.  vtc_prof_end synchronises `stream` and returns, per class, the summed kernel time,

@@ -77,6 +77,17 @@ SIGNATURES = {
     "vtc_prof_end": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "vtc_attention": (C.c_int, [vp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, vp]),
+    # adapter-only training step (backward + optimizer primitives)
+    "vtc_transpose_f32": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),
+    "vtc_colsum_f32": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),
+    "vtc_layernorm_bwd": (C.c_int, [fp, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]),
+    "vtc_attention_small_bwd": (C.c_int, [fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]),
+    "vtc_quickgelu": (C.c_int, [fp, fp, fp, C.c_size_t, vp]),
+    "vtc_normalize_rows_bwd": (C.c_int, [fp, fp, fp, C.c_int, C.c_int, vp]),
+    "vtc_clip_loss_bwd": (C.c_int, [fp, C.c_int, fp, vp, C.c_size_t, vp]),
+    "vtc_adam_step": (C.c_int, [fp, fp, fp, fp, fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp]),
+    "vtc_axpby": (C.c_int, [fp, fp, fp, C.c_float, C.c_float, C.c_size_t, vp]),
+    "vtc_scale_rows": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp]),
 }
 
 _lib = None

@@ -268,8 +268,34 @@ def main():
         g3 = p3[gk]
         extra["config3_gemm_tflops"] = round(g3["work"] / (g3["ms"] * 1e-3) / 1e12, 1)
         extra["config3_kernel_ms"] = {k: round(v["ms"], 3) for k, v in p3.items() if v["launches"]}
+        adapter_sd = {k: v.detach().clone() for k, v in m3.state_dict().items()
+                      if k.startswith("final_transformer.") or k in ("mask_embedding", "model.logit_scale")}
         del m3, vid
         torch.cuda.empty_cache()
+
+        # ---- adapter-only training step (configs/pretrained_clip_comments_attn_frozen.jsonc:
+        # batch 128, frozen towers, clip_loss, Adam amsgrad): forward + backward + update of the CAM on the HIP path
+        from vtc_amd.host.adapter_train import AdapterTrainer
+        trn = AdapterTrainer(adapter_sd)
+        Bt = 128
+        gt = torch.Generator().manual_seed(7)
+        tfv, tft = torch.randn(Bt, 512, generator=gt).to(device), torch.randn(Bt, 512, generator=gt).to(device)
+        tfc = torch.randn(5, Bt, 512, generator=gt).to(device)
+        temp = (torch.rand(Bt, 5, generator=gt) < 0.1).to(device)
+        tskip = (torch.rand(Bt, generator=gt) > 0.5).to(device)
+        for _ in range(3):
+            trn.step(tfv, tft, tfc, temp, tskip)
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        kt = 20
+        for _ in range(kt):
+            tl = trn.step(tfv, tft, tfc, temp, tskip)
+        barrier_sync(world)
+        dtt = max_over_ranks(time.perf_counter() - t0, world, device)
+        extra["adapter_train_step_ms"] = round(1e3 * dtt / kt, 3)
+        extra["adapter_train_batch"] = Bt
+        extra["adapter_train_loss_after"] = round(float(tl), 4)
+        del trn
 
         # ---- sweep: N x N sim + R@1/5/10 both directions, sharded by query rows ---------------
         # N = 10k (BASELINE configs[3]) and the 50k stress size (configs[4]); embeddings drawn directly

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
                                                            int ng, int d, const int64_t *__restrict__ cand, const float *__restrict__ cand_d,
                                                            int cdepth, int depth, const float *__restrict__ qn, const float *__restrict__ gmax,
                                                            float kappa, int64_t *__restrict__ ids, float *__restrict__ dists,
-                                                           int *__restrict__ flags) {
+                                                           int *__restrict__ flags) {   // flags[0] = count, flags[1..] = rows
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= nq) return;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
       const float eps = kappa * (qn[r] + *gmax);
       sure = cand_d[(size_t)r * cdepth + cdepth - 1] > cand_d[(size_t)r * cdepth + depth - 1] + 2.0f * eps;
     }
-    flags[r] = sure ? 0 : 1;
+    if (!sure) flags[1 + atomicAdd(flags, 1)] = r;
   }
 }
 
@@ -253,11 +253,12 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
 __global__ __launch_bounds__(256) void exact_fallback_kernel(const float *__restrict__ queries, const float *__restrict__ gallery, int ng,
                                                              int d, int depth, const int *__restrict__ flags, int64_t *__restrict__ ids,
                                                              float *__restrict__ dists) {
-  const int r = blockIdx.x;
-  if (!flags[r]) return;                                  // uniform for the workgroup
   __shared__ double sd[4][64];
   __shared__ int si[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_flagged = flags[0];
+  for (int f = blockIdx.x; f < n_flagged; f += gridDim.x) {   // uniform for the workgroup; normally zero trips
+  const int r = flags[1 + f];
   const float *q = queries + (size_t)r * d;
   double bd = INFINITY;
   int bi = 0x7fffffff;
@@ -284,6 +285,8 @@ __global__ __launch_bounds__(256) void exact_fallback_kernel(const float *__rest
       ids[(size_t)r * depth + lane] = bi == 0x7fffffff ? -1 : (int64_t)bi;
       if (dists) dists[(size_t)r * depth + lane] = (float)bd;
     }
+  }
+  __syncthreads();                                         // sd / si are reused by the next flagged row
   }
 }
 
@@ -391,7 +394,7 @@ SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block,
     s.cdepth = 64;                                          // sized for the deepest list (depth is not known to the size query)
     s.cand = (int64_t *)take((size_t)nq * 64 * 8);
     s.cand_d = (float *)take((size_t)nq * 64 * 4);
-    s.flags = (int *)take((size_t)nq * 4);
+    s.flags = (int *)take((size_t)(nq + 1) * 4);              // [0] = number of flagged rows, then their indices
     s.gmax = (float *)take(256);
   }
   s.total = off;
@@ -461,9 +464,11 @@ extern "C" int vtc_l2_topk(const float *gallery, const float *queries, int ng, i
   // bf16 rounding of both operands (3 * 2^-18), fp32 accumulation of 3 d products (3 d * 2^-24), fp32 row norms
   // (d * 2^-24), the epilogue's three roundings
   const float kappa = 3.0f / 262144.0f + 4.0f * d / 16777216.0f + 1e-6f;
+  (void)hipMemsetAsync(s.flags, 0, sizeof(int), stream);
   hipLaunchKernelGGL(exact_rerank_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, queries, gallery, nq, ng, d, s.cand, s.cand_d, cdepth,
                      depth, s.qn, s.gmax, kappa, ids, dists, s.flags);
-  hipLaunchKernelGGL(exact_fallback_kernel, dim3(nq), dim3(256), 0, stream, queries, gallery, ng, d, depth, s.flags, ids, dists);
+  hipLaunchKernelGGL(exact_fallback_kernel, dim3(std::min(nq, 2048)), dim3(256), 0, stream, queries, gallery, ng, d, depth, s.flags, ids,
+                     dists);
   VTC_LAUNCH_CHECK("l2_topk exact");
   return 0;
 }

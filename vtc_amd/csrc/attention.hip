@@ -107,15 +107,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   __syncthreads();  // Vt visible to every lane of the wave (waves do not share LDS regions)
 
   const char *qbase = p.qkv + (size_t)(h * 64) * SZ;
+  // query fragments are fetched one tile ahead: the loads of tile qt + 1 are in flight while tile qt is multiplied,
+  // soft-maxed and stored (the compiler cannot hoist them itself across the stores to p.out)
+  auto load_q = [&](int qt, uint4 (&q)[KS]) {
+    const char *r = qbase + (size_t)row_of(min(qt * 16 + c16, L - 1)) * ld;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) q[ks] = *reinterpret_cast<const uint4 *>(r + (4 * ks + g) * 16);
+  };
+  uint4 qf[KS], qn[KS];
+  load_q(0, qf);
   for (int qt = 0; qt < NT; ++qt) {
     if (qt * 16 >= L) break;
     const int qtok = qt * 16 + c16;
-    uint4 qf[KS];
-    {
-      const char *r = qbase + (size_t)row_of(min(qtok, L - 1)) * ld;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4 *>(r + (4 * ks + g) * 16);
-    }
+    if (qt + 1 < NT && (qt + 1) * 16 < L) load_q(qt + 1, qn);
     f32x4 sc[NT];
     float mx = -INFINITY;
 #pragma unroll
@@ -204,6 +208,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
           ElemOps<T>::store4(dst + dt * 16, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
       }
     }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
   }
 }
 

@@ -181,3 +181,35 @@ def test_gemm_phased_epilogues():
     w2 = torch.randint(-2, 3, (4096, 128), generator=g).float()
     out = ops.gemm(a2.cuda().bfloat16(), w2.cuda().bfloat16(), None, out_dtype=torch.float32).cpu()
     assert torch.equal(out, a2 @ w2.t())
+
+
+def test_gemm_random_shapes_all_kernels():
+    """Randomised shapes over every kernel configuration (64x64, 128x128, 256x256 phased; forced through
+    VTC_GEMM_TILE-independent heuristics by size), ragged edges in M and N, K from one K-tile up, every epilogue --
+    integer-valued operands make the fp32 result exact, so any indexing mistake shows as a mismatch."""
+    L, ops = _ops()
+    rng = np.random.default_rng(2024)
+    cases = []
+    for _ in range(10):      # small / medium: 64x64 and 128x128 kernels
+        cases.append((int(rng.integers(1, 700)), int(rng.integers(1, 700)), 64 * int(rng.integers(1, 6))))
+    for _ in range(6):       # large: phased kernel, ragged edges
+        cases.append((int(rng.integers(6000, 9000)), int(rng.integers(2500, 3400)), 64 * int(rng.integers(1, 5))))
+    for (M, N, K) in cases:
+        g = torch.Generator().manual_seed(M * 31 + N)
+        a = torch.randint(-2, 3, (M, K), generator=g).float()
+        w = torch.randint(-2, 3, (N, K), generator=g).float()
+        bias = torch.randint(-4, 5, (N,), generator=g).float()
+        ad, wd = a.cuda().bfloat16(), w.cuda().bfloat16()
+        ref = (a.cuda() @ w.cuda().t()) + bias.cuda()            # exact in fp32 (|values| small integers)
+        out = ops.gemm(ad, wd, bias.cuda(), out_dtype=torch.float32)
+        assert torch.equal(out, ref), (M, N, K, "store f32", float((out - ref).abs().max()))
+        out = ops.gemm(ad, wd, bias.cuda(), out_dtype=torch.bfloat16)
+        assert torch.equal(out.float(), ref.bfloat16().float()), (M, N, K, "store bf16")
+        x0 = torch.randint(-8, 9, (M, N), generator=g).float().cuda()
+        x = x0.clone()
+        ops.gemm(ad, wd, bias.cuda(), epilogue=L.EPI_RESID, out=x, skip_mod=7)
+        want = x0 + ref
+        want[0::7] = x0[0::7]
+        assert torch.equal(x, want), (M, N, K, "resid")
+        out = ops.gemm(ad, wd, bias.cuda(), epilogue=L.EPI_GELU, out_dtype=torch.float32)
+        assert (out - quick_gelu(ref)).abs().max() < 2e-2 * max(1.0, float(ref.abs().max())), (M, N, K, "gelu")

@@ -32,7 +32,8 @@ extern "C" {
 enum { VTC_F32 = 0, VTC_BF16 = 1, VTC_U8 = 2 /* pixel_dtype only: raw 0..255 pixels */ };
 
 /* residual activations of the CAM, model/model.py:65-77 (stateless ones) */
-enum { VTC_ACT_NONE = 0, VTC_ACT_NORMALIZE = 1, VTC_ACT_SQUASH = 2, VTC_ACT_TANH = 3 };
+enum { VTC_ACT_NONE = 0, VTC_ACT_NORMALIZE = 1, VTC_ACT_SQUASH = 2, VTC_ACT_TANH = 3,
+       VTC_ACT_SUB_MEAN = 4, VTC_ACT_BN = 5 };   /* eval-mode BatchNorm1d statistics, model/model.py:42-61 */
 
 /* sweep precision: how q.g is formed from fp32 embeddings */
 enum { VTC_SWEEP_F32 = 0,      /* fp32 MFMA, bitwise a k-ordered fmaf chain            */
@@ -95,6 +96,7 @@ typedef struct {
   const void  *final_linear;      /* [D,D] compute dtype (used when !init_from_avg)       */
   const float *mask_embedding;    /* [D]                                                  */
   const vtc_block_w *blocks;      /* HOST array                                           */
+  const float *bn_mean, *bn_var;  /* mean_center_bn.running_mean / running_var [D]; SUB_MEAN, BN only (else NULL) */
 } vtc_cam_w;
 
 const char *vtc_last_error(void);          /* thread-local message of the last failure   */

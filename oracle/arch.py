@@ -164,8 +164,17 @@ def synth_cam(arch: ClipArch, seed: int, n_layers: int = 2, init_from_avg_zero: 
     return {prefix + k: v for k, v in sd.items()}
 
 
+def synth_bn_stats(arch: ClipArch, seed: int) -> Dict[str, torch.Tensor]:
+    """Buffers of ``mean_center_bn = nn.BatchNorm1d(D, affine=False, momentum=0.2)`` (model/model.py:134-139), as a
+    checkpoint trained with residual_activation in {"sub_mean", "bn"} carries them."""
+    g = _Gen(seed)
+    D = arch.embed_dim
+    return {"mean_center_bn.running_mean": g.normal((D,), 0.05), "mean_center_bn.running_var": g.normal((D,), 0.02).abs() + 0.01,
+            "mean_center_bn.num_batches_tracked": torch.tensor(7, dtype=torch.long)}
+
+
 def synth_model(arch: ClipArch, seed: int, kind: str, nframes: int = 8, cam_layers: int = 2,
-                cam_at_init: bool = False) -> Dict[str, torch.Tensor]:
+                cam_at_init: bool = False, bn_stats: bool = False) -> Dict[str, torch.Tensor]:
     """Full state dict for one of the four wrappers (model/model.py:308,374,483,539).
 
     kind in {"clip", "clip_finaltf", "timesformer", "timesformer_finaltf"}."""
@@ -175,6 +184,8 @@ def synth_model(arch: ClipArch, seed: int, kind: str, nframes: int = 8, cam_laye
     sd.update(synth_text(arch, seed * 7 + 2, prefix="model."))
     if kind.endswith("finaltf"):
         sd.update(synth_cam(arch, seed * 7 + 3, n_layers=cam_layers, init_from_avg_zero=cam_at_init))
+    if bn_stats:
+        sd.update(synth_bn_stats(arch, seed * 7 + 4))
     return sd
 
 

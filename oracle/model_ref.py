@@ -30,8 +30,8 @@ def squash(s: torch.Tensor) -> torch.Tensor:
     return (mag_sq / (1.0 + mag_sq)) * (s / mag)
 
 
-# model/model.py:65-77 (stateless entries; "sub_mean"/"bn" need BatchNorm running stats
-# that no BASELINE config uses -- out of scope)
+# model/model.py:65-77; the two stateful entries ("sub_mean" :42-51, "bn" :54-61) are applied in adapt_feature from
+# the mean_center_bn running statistics (eval semantics)
 RESIDUAL_ACTIVATIONS = {
     "normalize": lambda x: normalize(x + 1e-9),
     "squash": squash,
@@ -68,7 +68,12 @@ def adapt_feature(main: torch.Tensor, aux: torch.Tensor, sd: SD, n_heads: int = 
         r = normalize(torch.mean(normalize(y), dim=0))              # :157-159
     else:
         r = y[0] @ sd["final_linear.weight"].t()                    # :161
-    r = RESIDUAL_ACTIVATIONS[residual_activation](r)               # :168-171
+    if residual_activation == "sub_mean":                          # :50  s - running_mean
+        r = r - sd["mean_center_bn.running_mean"]
+    elif residual_activation == "bn":                              # :60  BatchNorm1d(affine=False) in eval mode
+        r = (r - sd["mean_center_bn.running_mean"]) / torch.sqrt(sd["mean_center_bn.running_var"] + 1e-5)
+    else:
+        r = RESIDUAL_ACTIVATIONS[residual_activation](r)           # :168-171
     return normalize(normalize(main) + r)                           # :203
 
 

@@ -79,7 +79,7 @@ def build_wrapper(kind, arch_name, seed, **kw):
            "timesformer": ref_model.PretrainedCLIP_TimeSformer,
            "timesformer_finaltf": ref_model.PretrainedCLIP_TimeSformer_finaltf}[kind]
     m = cls(**kw).eval()
-    sd = A.synth_model(a, seed, kind, nframes=8)
+    sd = A.synth_model(a, seed, kind, nframes=8, bn_stats=kw.get("residual_activation") in ("sub_mean", "bn"))
     missing, unexpected = m.load_state_dict(sd, strict=False)
     # the double's causal mask etc. are not parameters; every parameter must be covered
     assert not unexpected, unexpected
@@ -106,6 +106,10 @@ def gen_wrappers():
         ("timesformer", "VIT_B32", 2, 5, {}),
         ("timesformer_finaltf", "VIT_B32", 2, 5, {"branch_to_adapt_val": "text"}),
         ("timesformer_finaltf", "VIT_B32", 2, 5, {"branch_to_adapt_val": "image"}),
+        # stateful residual activations (model.py:42-61), eval semantics = the mean_center_bn running statistics;
+        # "bn" reads state.branch_to_freeze with `in`, so the reference needs a string there (freeze="none")
+        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "text", "residual_activation": "sub_mean", "n_heads": 2}),
+        ("clip_finaltf", "TINY", 4, 4, {"branch_to_adapt_val": "text", "residual_activation": "bn", "freeze": "none", "n_heads": 2}),
     ]
     for i, (kind, arch_name, B, nd, kw) in enumerate(cases):
         m, a = build_wrapper(kind, arch_name, seed=21, **kw)

@@ -160,7 +160,8 @@ def build_wrapper(case, dtype):
     cls = {"clip": HM.PretrainedCLIP, "clip_finaltf": HM.PretrainedCLIP_finaltf,
            "timesformer": HM.PretrainedCLIP_TimeSformer, "timesformer_finaltf": HM.PretrainedCLIP_TimeSformer_finaltf}[case["model"]]
     m = cls(model_type=ClipConfig(**asdict(a)), **case["ctor"])
-    m.load_state_dict(A.synth_model(a, case["wseed"], case["model"], nframes=8), strict=True)   # eval.py:90-91
+    bn_stats = case["ctor"].get("residual_activation") in ("sub_mean", "bn")
+    m.load_state_dict(A.synth_model(a, case["wseed"], case["model"], nframes=8, bn_stats=bn_stats), strict=True)   # eval.py:90-91
     m = m.eval().cuda()
     m.compute_dtype = dtype
     return m, a

@@ -30,11 +30,12 @@ def test_visual_tower(fname):
 def run_wrapper(case):
     a = ARCH[case["arch"]]
     kind = case["model"]
-    sd = A.synth_model(a, case["wseed"], kind, nframes=8)
+    sd = A.synth_model(a, case["wseed"], kind, nframes=8, bn_stats=case["ctor"].get("residual_activation") in ("sub_mean", "bn"))
     vis = A.synth_pixels(case["vis_shape"], case["xseed"])
     title = A.synth_tokens(case["B"], a, case["tseed"])
     comments = A.synth_tokens(case["B"] * 5, a, case["cseed"], empty_frac=case["empty_frac"]).reshape(case["B"], 5, -1)
     kw = dict(case["ctor"])
+    kw.pop("freeze", None)
     branch = kw.pop("branch_to_adapt_val", "text")
     cam = {}
     if "init_from_avg" in kw:

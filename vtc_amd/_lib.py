@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VTC_HIP_LIB") or os.path.join(_HERE, "lib", "libvtc_hip.so")
 
 VTC_F32, VTC_BF16, VTC_U8 = 0, 1, 2
-ACT_NONE, ACT_NORMALIZE, ACT_SQUASH, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_NORMALIZE, ACT_SQUASH, ACT_TANH, ACT_SUB_MEAN, ACT_BN = 0, 1, 2, 3, 4, 5
 SWEEP_F32, SWEEP_BF16X3, SWEEP_BF16, SWEEP_EXACT = 0, 1, 2, 3
 EPI_STORE, EPI_GELU, EPI_RESID = 0, 1, 2
 PROF_CLASSES = ("gemm_bf16", "gemm_f32", "attention", "norm", "embed", "topk")
@@ -47,7 +47,8 @@ class TextW(C.Structure):
 class CamW(C.Structure):
     _fields_ = [("width", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("init_from_avg", C.c_int),
                 ("residual_activation", C.c_int), ("squash_scale", C.c_float),
-                ("final_linear", C.c_void_p), ("mask_embedding", C.c_void_p), ("blocks", C.POINTER(BlockW))]
+                ("final_linear", C.c_void_p), ("mask_embedding", C.c_void_p), ("blocks", C.POINTER(BlockW)),
+                ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol include/vtc_hip.h declares

@@ -167,7 +167,8 @@ __device__ __forceinline__ float act_apply(int act, float v, float msq, float sc
 template <int MAXD64>
 __global__ __launch_bounds__(256) void cam_finalize_kernel(const float *__restrict__ Y, const float *__restrict__ lin,
                                                            const float *__restrict__ main_f, float *__restrict__ out, int B, int Lc,
-                                                           int D, int init_from_avg, int act, float scale) {
+                                                           int D, int init_from_avg, int act, float scale,
+                                                           const float *__restrict__ bn_mean, const float *__restrict__ bn_var) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -201,7 +202,17 @@ __global__ __launch_bounds__(256) void cam_finalize_kernel(const float *__restri
       r[k] = c < D ? lin[(size_t)b * D + c] : 0.f;
     }
   }
-  if (act != VTC_ACT_NONE) {
+  if (act == VTC_ACT_SUB_MEAN || act == VTC_ACT_BN) {
+    // eval-mode BatchNorm1d(affine=False): model/model.py:42-61 (running statistics, eps 1e-5)
+#pragma unroll
+    for (int k = 0; k < MAXD64; ++k) {
+      const int c = lane + 64 * k;
+      if (c < D) {
+        const float d = r[k] - bn_mean[c];
+        r[k] = act == VTC_ACT_BN ? d / sqrtf(bn_var[c] + 1e-5f) : d;
+      }
+    }
+  } else if (act != VTC_ACT_NONE) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXD64; ++k) {
@@ -316,10 +327,13 @@ int launch_cam_tokens(const float *main_f, const float *comm, const int64_t *com
 }
 
 int launch_cam_finalize(const float *Y, const float *lin, const float *main_f, float *out, int B, int Lc, int D, int init_from_avg,
-                        int act, float scale, hipStream_t stream) {
+                        int act, float scale, const float *bn_mean, const float *bn_var, hipStream_t stream) {
   VTC_CHECK(D <= 1024, "cam: width %d > 1024", D);
+  VTC_CHECK(act >= VTC_ACT_NONE && act <= VTC_ACT_BN, "cam: unknown residual activation %d", act);
+  VTC_CHECK((act != VTC_ACT_SUB_MEAN && act != VTC_ACT_BN) || (bn_mean && bn_var),
+            "cam: residual activation %d needs bn_mean / bn_var", act);
   hipLaunchKernelGGL((cam_finalize_kernel<16>), dim3(cdiv(B, 4)), dim3(256), 0, stream, Y, lin, main_f, out, B, Lc, D, init_from_avg,
-                     act, scale);
+                     act, scale, bn_mean, bn_var);
   VTC_LAUNCH_CHECK("cam_finalize");
   return 0;
 }

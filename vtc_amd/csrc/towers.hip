@@ -31,7 +31,7 @@ void vtc_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 extern "C" const char *vtc_last_error(void) { return g_err; }
-extern "C" int vtc_abi_version(void) { return 1; }
+extern "C" int vtc_abi_version(void) { return 2; }
 
 int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res, const float *mean, const float *stdv, hipStream_t stream);
 int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, int T, int W, hipStream_t stream);
@@ -41,7 +41,7 @@ int launch_text_embed_ragged(const int64_t *ids, const float *tok, const float *
 int launch_attention_ragged(const void *qkv, void *out, int n_seq, int max_L, int heads, int causal, const int *seq_offsets, double flops, int dtype, hipStream_t stream);
 int launch_cam_tokens(const float *main_f, const float *comm, const int64_t *comments, const float *mask_emb, float *X, int B, int nc, int ctx, int D, hipStream_t stream);
 int launch_cls_global_attention(const void *qkv, void *out, int n_items, int Ttok, int heads, int dtype, hipStream_t stream);
-int launch_cam_finalize(const float *Y, const float *lin, const float *main_f, float *out, int B, int Lc, int D, int init_from_avg, int act, float scale, hipStream_t stream);
+int launch_cam_finalize(const float *Y, const float *lin, const float *main_f, float *out, int B, int Lc, int D, int init_from_avg, int act, float scale, const float *bn_mean, const float *bn_var, hipStream_t stream);
 
 namespace {
 
@@ -304,6 +304,6 @@ extern "C" int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, cons
     RUN(launch_layernorm(t.x, nullptr, nullptr, t.lnp, B, D, dtype, nullptr, Lc, true, s));
     RUN(gemm(t.lnp, w->final_linear, nullptr, lin, B, D, D, dtype, VTC_EPI_STORE, VTC_F32, 0, s));
   }
-  RUN(launch_cam_finalize(t.x, lin, main_feats, adapted, B, Lc, D, w->init_from_avg, w->residual_activation, w->squash_scale, s));
+  RUN(launch_cam_finalize(t.x, lin, main_feats, adapted, B, Lc, D, w->init_from_avg, w->residual_activation, w->squash_scale, w->bn_mean, w->bn_var, s));
   return 0;
 }

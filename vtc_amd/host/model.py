@@ -14,7 +14,7 @@ The forward pass is forward/eval only and runs entirely in libvtc_hip.so: inputs
 a ROCm GPU and the module in ``eval()`` mode, anything else raises (there is deliberately no
 CPU or PyTorch fallback -- the CPU restatement lives in ``oracle/`` and is test-only).
 Out of scope (raise): training-mode branches (random comment masking / skip adapter),
-``residual_activation`` in {"sub_mean","bn"}, the audio branch, feature-MLP baselines.
+the audio branch, feature-MLP baselines.
 """
 from __future__ import annotations
 
@@ -43,12 +43,14 @@ class PretrainedCLIPBase(nn.Module):
 
     def _common_init(self):
         if getattr(self, "residual_activation", None) in ["sub_mean", "bn"]:
-            raise NotImplementedError("residual_activation 'sub_mean'/'bn' (model/model.py:42-61) is not on the HIP path")
+            # model/model.py:134-139: running statistics only (forward is eval-mode here, see _check_eval)
+            self.mean_center_bn = nn.BatchNorm1d(self.feature_dim, affine=False, momentum=0.2)
         self._packed = {}
 
     # ---- packed-weight cache ---------------------------------------------------------------
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.compute_dtype, self.fuse_temporal)
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers())) + \
+            (self.compute_dtype, self.fuse_temporal)
 
     def _pack(self):
         sig = self._signature()

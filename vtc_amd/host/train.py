@@ -43,6 +43,9 @@ def main(config: ConfigParser, args=None, device="cuda"):
     model = config.init_obj("arch", module_arch).eval().to(device)   # towers: forward path; adapter train-mode semantics live in AdapterTrainer
     if getattr(model, "random_comment_masking", False):
         raise NotImplementedError("random_comment_masking=True (model/model.py:236-246) is not part of the slice")
+    if getattr(model, "residual_activation", None) is not None:
+        raise NotImplementedError(f"train: residual_activation {model.residual_activation!r} has no backward on the HIP path "
+                                  "(the adapter-only step covers residual_activation=None, the shipped config)")
     dataset = config.init_obj("dataset", module_data, train=True, test=False)
     loader = DataLoader(dataset, batch_size=config["batch_size"], shuffle=True, drop_last=True, num_workers=0,
                         generator=torch.Generator().manual_seed(1023))

@@ -197,14 +197,15 @@ class PackedText:
 
 _ACTS = {None: (L.ACT_NONE, 1.0), "none": (L.ACT_NONE, 1.0), "normalize": (L.ACT_NORMALIZE, 1.0),
          "squash": (L.ACT_SQUASH, 1.0), "squash10": (L.ACT_SQUASH, 10.0), "squash1p2": (L.ACT_SQUASH, 1.2),
-         "squash1p5": (L.ACT_SQUASH, 1.5), "squash1p8": (L.ACT_SQUASH, 1.8), "tanh": (L.ACT_TANH, 1.0)}
+         "squash1p5": (L.ACT_SQUASH, 1.5), "squash1p8": (L.ACT_SQUASH, 1.8), "tanh": (L.ACT_TANH, 1.0),
+         # eval-mode statistics of mean_center_bn = BatchNorm1d(D, affine=False) (model/model.py:42-61)
+         "sub_mean": (L.ACT_SUB_MEAN, 1.0), "bn": (L.ACT_BN, 1.0)}
 
 
 class PackedCam:
     def __init__(self, sd: SD, dtype, heads: int, init_from_avg: bool, residual_activation):
         if residual_activation not in _ACTS:
-            raise NotImplementedError(f"residual_activation={residual_activation!r} needs BatchNorm running statistics "
-                                      "(model/model.py:42-61); not implemented on the HIP path")
+            raise ValueError(f"unknown residual_activation {residual_activation!r} (model/model.py:30-80)")
         self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep()
         k = self.keep
         w = L.CamW()
@@ -219,6 +220,12 @@ class PackedCam:
         w.mask_embedding = k.f32(sd["mask_embedding"].reshape(-1))
         self.blocks = _pack_blocks(sd, "final_transformer", w.layers, dtype, k, False, False)
         w.blocks = self.blocks
+        if residual_activation in ("sub_mean", "bn"):
+            if "mean_center_bn.running_mean" not in sd:
+                raise KeyError("residual_activation %r needs mean_center_bn.running_mean / running_var in the state dict "
+                               "(model/model.py:42-61)" % residual_activation)
+            w.bn_mean = k.f32(sd["mean_center_bn.running_mean"].reshape(-1))
+            w.bn_var = k.f32(sd["mean_center_bn.running_var"].reshape(-1))
         self.w = w
 
     def forward(self, main: torch.Tensor, comm_feats: torch.Tensor, comments: torch.Tensor) -> torch.Tensor:

@@ -161,6 +161,15 @@ size_t vtc_l2_topk_workspace_bytes(int n_gallery, int n_queries, int d, int prec
 int vtc_l2_topk(const float *gallery, const float *queries, int n_gallery, int n_queries, int d, int depth,
                 int precision, int rows_per_block, int64_t *ids, float *dists, void *ws, size_t ws_bytes,
                 void *stream);
+
+/* Both retrieval directions from ONE distance matrix D[i][j] = |b_i - a_j|^2 (the reference runs two searches,
+ * evaluation/eval.py:117-127 -> model/metric.py:137-146): ids_b2a [n_b, depth] = vtc_l2_topk(gallery = a, queries = b),
+ * ids_a2b [n_a, depth] = vtc_l2_topk(gallery = b, queries = a); the second direction is read off the columns of the
+ * blocks the first direction's GEMM has written (no second GEMM).  dists_* may be NULL.  depth <= min(64, n_a, n_b). */
+size_t vtc_l2_topk_bidir_workspace_bytes(int n_a, int n_b, int d, int precision, int rows_per_block);
+int vtc_l2_topk_bidir(const float *a, const float *b, int n_a, int n_b, int d, int depth, int precision, int rows_per_block,
+                      int64_t *ids_b2a, float *dists_b2a, int64_t *ids_a2b, float *dists_a2b, void *ws, size_t ws_bytes,
+                      void *stream);
 /* hits[j] += #{ i : (target_offset + i) in ids[i, :k_vals[j]] }   (hits: int64 device) */
 int vtc_recall_hits(const int64_t *ids, int n_queries, int depth, int64_t target_offset, const int *k_vals_host,
                     int nk, long long *hits, void *stream);

@@ -144,3 +144,66 @@ def test_l2_topk_exact_mode_dense_near_ties_take_the_fp64_brute_force():
     small = a[:20]                                           # gallery smaller than the candidate depth
     ids, _ = ops.l2_topk(torch.from_numpy(small).cuda(), torch.from_numpy(q).cuda(), 11, precision=L.SWEEP_EXACT)
     assert np.array_equal(ids.cpu().numpy(), E.l2_topk(small, q, 11, np.float64)[0])
+
+
+@pytest.mark.parametrize("na,nb,d", [(300, 300, 64), (1000, 777, 512), (4099, 4099, 512), (40, 3000, 128), (3000, 40, 128)])
+@pytest.mark.parametrize("prec", ["exact", "f32", "bf16x3"])
+def test_l2_topk_bidir_equals_two_searches(na, nb, d, prec):
+    """vtc_l2_topk_bidir reads the second direction off the columns of the first direction's distance blocks: it
+    must return what two vtc_l2_topk calls return (EXACT: the fp64 ids on every row of both directions)."""
+    from vtc_amd import _lib as L
+    from vtc_amd import ops
+    p = {"exact": L.SWEEP_EXACT, "f32": L.SWEEP_F32, "bf16x3": L.SWEEP_BF16X3}[prec]
+    rng = np.random.default_rng(na + nb)
+    a = unit(rng.standard_normal((na, d))).astype(np.float32)
+    b = unit(rng.standard_normal((nb, d))).astype(np.float32)
+    m = min(na, nb)
+    b[:m] = unit(a[:m] + 0.5 * unit(rng.standard_normal((m, d)))).astype(np.float32)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    for depth in (1, 11):
+        for rpb in (0, 256):                                   # one block / several blocks (partial column lists merged)
+            i1, d1, i2, d2 = ops.l2_topk_bidir(ta, tb, depth, precision=p, rows_per_block=rpb)
+            r1, e1 = E.l2_topk(a, b, depth, np.float64)           # gallery a, queries b
+            r2, e2 = E.l2_topk(b, a, depth, np.float64)           # gallery b, queries a
+            tol = 4e-6 if prec != "bf16x3" else 2e-5 * (64 / d) ** 0.5
+            assert np.abs(d1.cpu().numpy() - e1).max() < tol and np.abs(d2.cpu().numpy() - e2).max() < tol
+            if prec == "exact":
+                assert np.array_equal(i1.cpu().numpy(), r1) and np.array_equal(i2.cpu().numpy(), r2)
+            else:
+                for got, ref, g, q in ((i1, r1, a, b), (i2, r2, b, a)):
+                    gaps = np.diff(E.l2_topk(g, q, depth + 1, np.float64)[1], axis=1)
+                    safe = (gaps > 4 * tol).all(axis=1)
+                    assert safe.mean() > 0.9 and np.array_equal(got.cpu().numpy()[safe], ref[safe])
+
+
+def test_l2_topk_bidir_ties_and_duplicates():
+    """Exact duplicates on both sides: (distance, index) order in both directions, lowest index first."""
+    from vtc_amd import _lib as L
+    from vtc_amd import ops
+    rng = np.random.default_rng(3)
+    a = unit(rng.standard_normal((500, 128))).astype(np.float32)
+    b = unit(rng.standard_normal((400, 128))).astype(np.float32)
+    a[100:130] = a[99]
+    b[200:240] = b[7]
+    for p in (L.SWEEP_EXACT, L.SWEEP_F32):
+        i1, _, i2, _ = ops.l2_topk_bidir(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 11, precision=p, rows_per_block=128)
+        j1, _ = ops.l2_topk(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 11, precision=p)
+        j2, _ = ops.l2_topk(torch.from_numpy(b).cuda(), torch.from_numpy(a).cuda(), 11, precision=p)
+        if p == L.SWEEP_EXACT:
+            assert torch.equal(i1, j1) and torch.equal(i2, j2)
+            assert np.array_equal(i2.cpu().numpy(), E.l2_topk(b, a, 11, np.float64)[0])
+        else:
+            assert torch.equal(i1, j1)
+            # fp32: the transposed direction rounds |b|^2 - 2 a.b + |a|^2 in another order; duplicates still tie exactly
+            assert (i2 == j2).float().mean() > 0.99
+
+
+def test_recall_compute_both_matches_two_computes_and_oracle():
+    """RecallAtK.compute_both on the one-matrix path (threshold lowered) == the reference's two compute() calls."""
+    from vtc_amd.host.metric import RecallAtK
+    a, b = planted(1500, 128, seed=11)
+    m = RecallAtK("videos", "titles", [1, 5, 10])
+    two = (m.compute(a, b), m.compute(b, a))
+    m.bidir_min_rows = 0
+    assert m.compute_both(a, b) == two
+    assert two[0] == E.recall_at_k(a, b, [1, 5, 10]) and two[1] == E.recall_at_k(b, a, [1, 5, 10])

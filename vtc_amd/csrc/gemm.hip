@@ -38,6 +38,21 @@ using namespace vtcgemm;
 
 namespace {
 
+// 16-byte global store, optionally non-temporal (streamed past L2: the store is acknowledged sooner, and the
+// in-order vmcnt queue of the next tile's first K-tiles drains sooner behind it)
+template <bool NT>
+__device__ __forceinline__ void store16(void *o, uint4 v) {
+  typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+  v4u_t vv = {v.x, v.y, v.z, v.w};
+  // (a run-time flag does not work: the two stores are merged and the hint is dropped)
+  if constexpr (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v4u_t *>(o));
+  else *reinterpret_cast<v4u_t *>(o) = vv;
+}
+template <bool NT>
+__device__ __forceinline__ void store16(void *o, float4 v) {
+  store16<NT>(o, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
+}
+
 // ---- epilogue (shared by both kernels): the wave's TM x TN accumulator fragments -> out, through a scratch
 // area of the dynamic LDS (byte offset scratch_off, >= 6 KiB per wave) that no DMA targets and nobody reads until
 // the caller's next barrier.  (The area is named by OFFSET and re-based on the extern array here: handed over as
@@ -52,6 +67,15 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
   const int g = lane >> 4;
   const int ldo = p.ldo;
   const bool vec_ok = (ldo & 3) == 0;
+  // Streaming (nt) stores.  A tile's stores sit in front of the next tile's first LDS-DMA waits in the wave's
+  // in-order vmcnt queue, so the K loop restarts only once they are acknowledged.  The distance matrix (256 KiB of
+  // fp32 per tile, read back once by the top-k pass): -27 % on the 50k x 50k distance GEMM; the towers' bf16
+  // outputs: -1.6 % per config-2 step; the fp32 residual stream (re-read by the LayerNorm that follows): neutral,
+  // kept on the default policy.  Mask bits: 0 distance, 1 bf16 outputs, 2 residual, 3 other fp32 (A/B builds).
+#ifndef VTC_NT_MASK
+#define VTC_NT_MASK 3
+#endif
+  constexpr bool nt_out = (VTC_NT_MASK >> (MODE == EPI_L2DIST ? 0 : MODE == VTC_EPI_RESID ? 2 : sizeof(OutT) == 2 ? 1 : 3)) & 1;
   // Interior tiles (every tile of the towers) take the transposed fast epilogue; edge tiles the generic one.
   const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && vec_ok;
   // ---- epilogue: lane holds out[m][n..n+3], m = m0 + 16 (wr TM + i) + (lane & 15),
@@ -111,7 +135,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
         for (int k = 0; k < 2; ++k) {
           const int r = (lane >> 3) + 8 * k, c = lane & 7;
           bf16_t *o = reinterpret_cast<bf16_t *>(p.out) + (size_t)(mrow0 + r) * ldo + ncol0 + c * 8;
-          *reinterpret_cast<uint4 *>(o) = make_uint4(lo[k].x, lo[k].y, hi[k].x, hi[k].y);
+          store16<nt_out>(o, make_uint4(lo[k].x, lo[k].y, hi[k].x, hi[k].y));
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -146,8 +170,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
         cadd[4] = c1.x; cadd[5] = c1.y; cadd[6] = c1.z; cadd[7] = c1.w;
       }
     }
-    auto fin = [&](float a, float add, float rnv) -> float {
-      float v = MODE == EPI_L2DIST ? rnv + add - 2.0f * a : a + add;
+    auto fin = [&](float a, float add) -> float {
+      float v = a + add;
       if (MODE == VTC_EPI_GELU) v = quick_gelu<sizeof(T) == 4>(v);
       if (MODE == EPI_SCALE) v *= scale;
       return v;
@@ -162,6 +186,14 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
 #pragma unroll
       for (int k = 0; k < 4; ++k) xc[k] = *reinterpret_cast<const float4 *>(x_ptr(0, k));
     }
+    // distance mode: |q|^2 of the lane's rows and |g|^2 of its columns are fetched once, in the MFMA layout, and the
+    // distance is formed BEFORE the transposition: a load inside the pass loop sits behind the previous pass's
+    // stores in the in-order vmcnt queue and would drain them every pass
+    float rn[TM];
+    if (MODE == EPI_L2DIST) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) rn[i] = p.epi.rown[m0 + (wr * TM + i) * 16 + l15];
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       if (MODE == VTC_EPI_RESID && i + 1 < TM) {
@@ -171,8 +203,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       // 1. registers -> LDS: final fp32 values in [16 rows][64 cols]
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        *reinterpret_cast<float4 *>(tr + l15 * TS + 16 * j + 4 * g) =
-            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        float4 a4 = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (MODE == EPI_L2DIST)     // |q|^2 - 2 q.g here, + |g|^2 (a per-column addend like a bias) after the transposition
+          a4 = make_float4(rn[i] - 2.0f * a4.x, rn[i] - 2.0f * a4.y, rn[i] - 2.0f * a4.z, rn[i] - 2.0f * a4.w);
+        *reinterpret_cast<float4 *>(tr + l15 * TS + 16 * j + 4 * g) = a4;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -185,10 +219,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
           const int r = (lane >> 4) + 4 * k, cc = l15 * 4;
           float4 v = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
           const int m = mrow0 + r;
-          {
-            const float rnv = MODE == EPI_L2DIST ? p.epi.rown[m] : 0.f;
-            v.x = fin(v.x, cadd[0], rnv); v.y = fin(v.y, cadd[1], rnv); v.z = fin(v.z, cadd[2], rnv); v.w = fin(v.w, cadd[3], rnv);
-          }
+          v.x = fin(v.x, cadd[0]); v.y = fin(v.y, cadd[1]); v.z = fin(v.z, cadd[2]); v.w = fin(v.w, cadd[3]);
           size_t orow = (size_t)m;
           bool live = true;
           if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && (m % p.epi.skip_mod) == 0) live = false;
@@ -209,10 +240,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
             // skipped rows are written back unchanged (a select, not a branch: an exec-masked store makes hipcc
             // re-wait on the x prefetch after every store, which throttles the store stream)
             const float4 x = xc[k];
-            *reinterpret_cast<float4 *>(o) = make_float4(live ? x.x + v.x : x.x, live ? x.y + v.y : x.y,
-                                                         live ? x.z + v.z : x.z, live ? x.w + v.w : x.w);
+            store16<nt_out>(o, make_float4(live ? x.x + v.x : x.x, live ? x.y + v.y : x.y, live ? x.z + v.z : x.z,
+                                           live ? x.w + v.w : x.w));
           } else {
-            *reinterpret_cast<float4 *>(o) = v;
+            store16<nt_out>(o, v);
           }
         }
       } else {
@@ -221,8 +252,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
           const int r = (lane >> 3) + 8 * k, cc = (lane & 7) * 8;
           float4 v0 = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
           float4 v1 = *reinterpret_cast<const float4 *>(tr + r * TS + cc + 4);
-          v0.x = fin(v0.x, cadd[0], 0.f); v0.y = fin(v0.y, cadd[1], 0.f); v0.z = fin(v0.z, cadd[2], 0.f); v0.w = fin(v0.w, cadd[3], 0.f);
-          v1.x = fin(v1.x, cadd[4], 0.f); v1.y = fin(v1.y, cadd[5], 0.f); v1.z = fin(v1.z, cadd[6], 0.f); v1.w = fin(v1.w, cadd[7], 0.f);
+          v0.x = fin(v0.x, cadd[0]); v0.y = fin(v0.y, cadd[1]); v0.z = fin(v0.z, cadd[2]); v0.w = fin(v0.w, cadd[3]);
+          v1.x = fin(v1.x, cadd[4]); v1.y = fin(v1.y, cadd[5]); v1.z = fin(v1.z, cadd[6]); v1.w = fin(v1.w, cadd[7]);
           uint4 pk;
           pk.x = (unsigned)f2bf(v0.x) | ((unsigned)f2bf(v0.y) << 16);
           pk.y = (unsigned)f2bf(v0.z) | ((unsigned)f2bf(v0.w) << 16);
@@ -271,7 +302,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
               if (p.bias) x += p.bias[n + e];
               if (MODE == VTC_EPI_GELU) x = quick_gelu<sizeof(T) == 4>(x);
               if (MODE == EPI_PATCH) x += posrow[n + e] + (temprow ? temprow[n + e] : 0.f);
-              if (MODE == EPI_L2DIST) x = rn + p.epi.coln[n + e] - 2.0f * x;
+              if (MODE == EPI_L2DIST) x = (rn - 2.0f * x) + p.epi.coln[n + e];   // same rounding sequence as the interior path
               if (MODE == EPI_SCALE) x *= scale;
               if (MODE == VTC_EPI_RESID) reinterpret_cast<float *>(o)[e] += x;
               else ElemOps<OutT>::store(o + e, x);
@@ -329,9 +360,6 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
   const int ldo = p.ldo;
   const bool vec_ok = (ldo & 3) == 0;
 
-  if (p.exp_arg > 0 && bid >= (nwg >> 1)) {   // diagnostic: phase-shift the second workgroup of each CU
-    for (int i = 0; i < p.exp_arg; ++i) __builtin_amdgcn_s_sleep(16);
-  }
   int cur = 0;                                   // LDS buffer of the slab being multiplied
   // both operands addressable with 32-bit byte offsets (true for every tower shape)?
   const bool small32 = (size_t)p.M * p.lda_bytes < (1ull << 32) && (size_t)p.N * p.ldw_bytes < (1ull << 32);
@@ -480,6 +508,10 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
   };
   int li = slot;
   if (li >= nt_x) return;                      // uniform for the whole workgroup
+  if (p.stagger_groups > 1) {
+    const long long t_end = (long long)__builtin_amdgcn_s_memrealtime() + (long long)(slot % p.stagger_groups) * p.stagger_ticks;
+    while ((long long)__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(8);
+  }
   int m0, n0;
   decode(start_x + li, m0, n0);
   int m0n = 0, n0n = 0;
@@ -810,6 +842,11 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
   p.ldo = epi.ldo > 0 ? epi.ldo : N;
   p.MT = 0; p.NT = 0;
   { static int ea = -1; if (ea < 0) { const char *e = getenv("VTC_GEMM_EXP"); ea = e ? atoi(e) : 0; } p.exp_arg = ea; }
+  {
+    static int sg = -1, st = 0;
+    if (sg < 0) { const char *e = getenv("VTC_GEMM_STAGGER"); sg = 0; if (e) sscanf(e, "%d,%d", &sg, &st); }
+    p.stagger_groups = sg; p.stagger_ticks = st;
+  }
   p.epi = epi;
   ProfScope prof(dtype == VTC_BF16 ? VTC_PROF_GEMM_BF16 : VTC_PROF_GEMM_F32, 2.0 * M * N * K, stream);
   return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);

@@ -23,6 +23,8 @@
 
 #include <algorithm>
 
+namespace vtcgemm { int num_cus(); }   // gemm.hip
+
 namespace {
 
 __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict__ x, float *__restrict__ out, int n, int d) {
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__
     for (int h = 0; h < 4; ++h) {
       const int c = base + 256 * h + lane * 4;
       if (vec && c + 3 < c_hi) {
-        const float4 t = *reinterpret_cast<const float4 *>(row + c);
+        typedef float v4f_t __attribute__((ext_vector_type(4)));
+        const v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(row + c));   // read once
         v[4 * h] = t.x; v[4 * h + 1] = t.y; v[4 * h + 2] = t.z; v[4 * h + 3] = t.w;
       } else {
 #pragma unroll
@@ -164,6 +167,121 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__
     } else {
       part_d[(size_t)w * depth + lane] = wl.bd;
       part_i[(size_t)w * depth + lane] = wl.bi;
+    }
+  }
+}
+
+// Column direction of the same matrix (the second retrieval direction needs D^T, so it is read off the block
+// that the first direction's GEMM has just written instead of running a second GEMM): one workgroup per
+// (strip of 64 columns, row segment).  The segment's rows stream through LDS in 64 x 64 tiles (coalesced 256-byte row
+// pieces in, 16-byte LDS accesses both ways: row stride 68 floats); wave w owns columns 16w .. 16w+15 of the strip and
+// keeps one WaveList per column (2 VGPRs each).  The first tile of a segment initialises a list by rank-counting
+// its 64 values (64 serial insertions per column otherwise).  ids are row_id0 + row; partial lists go to
+// part[(col * S_total + seg0 + seg) * depth ..] and are merged over blocks and segments by topk_merge_kernel.
+__global__ __launch_bounds__(256, 4) void col_topk_kernel(const float *__restrict__ dist, int ld, int n_rows, int n_cols, int depth,
+                                                       int row_id0, int S, int seg_rows, int S_total, int seg0,
+                                                       float *__restrict__ part_d, int *__restrict__ part_i) {
+  __shared__ __attribute__((aligned(16))) float tile[64 * 68];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int strip = blockIdx.x / S, seg = blockIdx.x - strip * S;
+  const int c0 = strip * 64;
+  const int r_lo = seg * seg_rows, r_hi = min(n_rows, r_lo + seg_rows);
+  if (r_lo >= r_hi) {            // empty segment (uniform): its partial lists stay "invalid"
+    for (int cc = 0; cc < 16; ++cc) {
+      const int col = c0 + 16 * w + cc;
+      if (col < n_cols && lane < depth) {
+        part_d[((size_t)col * S_total + seg0 + seg) * depth + lane] = INFINITY;
+        part_i[((size_t)col * S_total + seg0 + seg) * depth + lane] = 0x7fffffff;
+      }
+    }
+    return;
+  }
+  WaveList wl[16];
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) wl[cc].init();
+  const int lr = t >> 4, lc = (t & 15) * 4;
+  const bool vec = (ld & 3) == 0 && c0 + 64 <= n_cols;      // uniform: whole strip inside the matrix, rows 16-byte aligned
+  auto load_tile = [&](int r_base, float4 (&pre)[4]) {
+    if (r_base >= r_hi) return;                              // uniform
+    if (vec) {
+      // branch-free: rows past the segment re-read its last row and are replaced by +inf, so the four loads of a
+      // thread are all in flight together
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int r = r_base + lr + 16 * h;
+        pre[h] = *reinterpret_cast<const float4 *>(dist + (size_t)min(r, r_hi - 1) * ld + c0 + lc);
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int r = r_base + lr + 16 * h;
+        float4 v = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+        if (r < r_hi) {
+          const float *src = dist + (size_t)r * ld + c0 + lc;
+          if (c0 + lc < n_cols) v.x = src[0];
+          if (c0 + lc + 1 < n_cols) v.y = src[1];
+          if (c0 + lc + 2 < n_cols) v.z = src[2];
+          if (c0 + lc + 3 < n_cols) v.w = src[3];
+        }
+        pre[h] = v;
+      }
+    }
+  };
+  // one 64-row step: registers -> LDS, refill the registers two tiles ahead, screen the tile from LDS
+  auto step = [&](int r_base, float4 (&pre)[4]) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const bool live = r_base + lr + 16 * h < r_hi;
+      *reinterpret_cast<float4 *>(tile + (lr + 16 * h) * 68 + lc) =
+          make_float4(live ? pre[h].x : INFINITY, live ? pre[h].y : INFINITY, live ? pre[h].z : INFINITY, live ? pre[h].w : INFINITY);
+    }
+    __syncthreads();
+    load_tile(r_base + 128, pre);                            // two tiles (32 KiB per workgroup) in flight
+    const bool valid = r_base + lane < r_hi;
+    const int idx = valid ? row_id0 + r_base + lane : 0x7fffffff;
+    const bool sort_init = r_base == r_lo && r_lo + 64 <= r_hi;   // a full first tile (uniform)
+    float vv[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t4 = *reinterpret_cast<const float4 *>(tile + lane * 68 + 16 * w + 4 * q);
+      vv[4 * q] = t4.x; vv[4 * q + 1] = t4.y; vv[4 * q + 2] = t4.z; vv[4 * q + 3] = t4.w;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      if (c0 + 16 * w + cc >= n_cols) continue;                 // uniform; columns past the matrix hold +inf everywhere
+      const float v = vv[cc];
+      if (sort_init) {
+        int rank = 0;
+#pragma unroll 4
+        for (int l = 0; l < 64; ++l) {
+          const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+          const int oi = __builtin_amdgcn_readlane(idx, l);
+          rank += (ov < v || (ov == v && oi < idx)) ? 1 : 0;
+        }
+        // ranks are a permutation (indices are distinct): forward permute = scatter to lane `rank`
+        wl[cc].bd = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(rank << 2, __builtin_bit_cast(int, v)));
+        wl[cc].bi = __builtin_amdgcn_ds_permute(rank << 2, idx);
+        wl[cc].tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl[cc].bd), depth - 1));
+        wl[cc].tau_i = __builtin_amdgcn_readlane(wl[cc].bi, depth - 1);
+      } else {
+        wl[cc].offer(v, idx, valid && v <= wl[cc].tau, lane, depth);   // offer() re-checks (tau, tau_i) exactly
+      }
+    }
+    __syncthreads();
+  };
+  float4 preA[4], preB[4];
+  load_tile(r_lo, preA);
+  load_tile(r_lo + 64, preB);
+  for (int r_base = r_lo; r_base < r_hi; r_base += 128) {
+    step(r_base, preA);
+    if (r_base + 64 < r_hi) step(r_base + 64, preB);
+  }
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) {
+    const int col = c0 + 16 * w + cc;
+    if (col < n_cols && lane < depth) {
+      part_d[((size_t)col * S_total + seg0 + seg) * depth + lane] = wl[cc].bd;
+      part_i[((size_t)col * S_total + seg0 + seg) * depth + lane] = wl[cc].bi;
     }
   }
 }
@@ -356,14 +474,21 @@ struct SweepWs {
   float *cand_d, *gmax;
   int *flags;
   int cdepth;
+  // both directions from one matrix (vtc_l2_topk_bidir): partial column lists, and the EXACT mode's second candidate set
+  float *cpart_d;
+  int *cpart_i;
+  int c_seg, c_total;            // row segments per block, partial lists per column (blocks x segments)
+  int64_t *cand2;
+  float *cand2_d, *qmax;
   size_t total;
 };
 constexpr int MAX_SEG = 16;
+constexpr int MAX_CSEG = 8;
 
 // candidate list depth of the EXACT mode: 21 spare ranks behind the requested ones, at least 32, at most 64 / n_gallery
 int exact_cdepth(int depth, int ng) { return std::min(std::min(64, ng), std::max(32, depth + 21)); }
 
-SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block, int depth = 0) {
+SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block, bool bidir = false) {
   SweepWs s;
   const bool exact = precision == VTC_SWEEP_EXACT;
   if (exact) precision = VTC_SWEEP_BF16X3;
@@ -394,8 +519,26 @@ SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block,
     s.cdepth = 64;                                          // sized for the deepest list (depth is not known to the size query)
     s.cand = (int64_t *)take((size_t)nq * 64 * 8);
     s.cand_d = (float *)take((size_t)nq * 64 * 4);
-    s.flags = (int *)take((size_t)(nq + 1) * 4);              // [0] = number of flagged rows, then their indices
+    s.flags = (int *)take((size_t)(std::max(nq, bidir ? ng : 0) + 1) * 4);   // [0] = number of flagged rows, then their indices
     s.gmax = (float *)take(256);
+  }
+  s.cpart_d = nullptr; s.cpart_i = nullptr; s.cand2 = nullptr; s.cand2_d = nullptr; s.qmax = nullptr; s.c_seg = 0; s.c_total = 0;
+  if (bidir) {
+    // enough (strip, segment) workgroups to fill the chip: ~4 per CU
+    const int strips = cdiv(ng, 64);
+    // (strip, segment) workgroups, four resident per CU: the fewest segments that put ~3 workgroups on every CU --
+    // the pass is bound by instruction issue, and every extra segment costs a list initialisation plus its own early
+    // insertions (measured at 50k x 50k: 1 / 2 / 3 / 5 segments per block = 4.3 / 4.6 / 5.1 / 6.2 ms per direction)
+    s.c_seg = std::max(1, std::min(MAX_CSEG, cdiv(3 * vtcgemm::num_cus(), strips)));
+    s.c_seg = std::min(s.c_seg, std::max(1, rpb / 128));                    // at least two tiles per segment
+    s.c_total = cdiv(nq, rpb) * s.c_seg;
+    s.cpart_d = (float *)take((size_t)ng * s.c_total * 64 * 4);
+    s.cpart_i = (int *)take((size_t)ng * s.c_total * 64 * 4);
+    if (exact) {
+      s.cand2 = (int64_t *)take((size_t)ng * 64 * 8);
+      s.cand2_d = (float *)take((size_t)ng * 64 * 4);
+      s.qmax = (float *)take(256);
+    }
   }
   s.total = off;
   return s;
@@ -407,8 +550,11 @@ extern "C" size_t vtc_l2_topk_workspace_bytes(int n_gallery, int n_queries, int 
   return plan(nullptr, n_gallery, n_queries, d, precision, rows_per_block).total;
 }
 
+// col_ids != nullptr: also the transposed direction (for every gallery row its nearest query rows), read off the same
+// distance blocks by col_topk_kernel.
 static int l2_topk_impl(const float *gallery, const float *queries, int ng, int nq, int d, int depth, int precision,
-                        int64_t *ids, float *dists, const SweepWs &s, hipStream_t stream) {
+                        int64_t *ids, float *dists, const SweepWs &s, hipStream_t stream, int64_t *col_ids = nullptr,
+                        float *col_dists = nullptr) {
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, queries, s.qn, nq, d);
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(ng, 4)), dim3(256), 0, stream, gallery, s.gn, ng, d);
   const int parts = precision == VTC_SWEEP_BF16X3 ? 3 : 1;
@@ -442,7 +588,38 @@ static int l2_topk_impl(const float *gallery, const float *queries, int ng, int 
                            (size_t)r0);
     }
     VTC_LAUNCH_CHECK("row_topk");
+    if (col_ids) {
+      const int seg_rows = cdiv(cdiv(rows, s.c_seg), 64) * 64;
+      ProfScope prof(VTC_PROF_TOPK, (double)rows * ng * 4, stream);
+      hipLaunchKernelGGL(col_topk_kernel, dim3(cdiv(ng, 64) * s.c_seg), dim3(256), 0, stream, s.dist, ng, rows, ng, depth, r0, s.c_seg,
+                         seg_rows, s.c_total, (r0 / s.rows_per_block) * s.c_seg, s.cpart_d, s.cpart_i);
+      VTC_LAUNCH_CHECK("col_topk");
+    }
   }
+  if (col_ids) {
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(cdiv(ng, 4)), dim3(256), 0, stream, s.cpart_d, s.cpart_i, ng, s.c_total, depth, col_ids,
+                       col_dists, (size_t)0);
+    VTC_LAUNCH_CHECK("col_topk merge");
+  }
+  return 0;
+}
+
+// EXACT tail: re-rank the candidate lists with fp64 distances, accept the rows whose list provably holds the true
+// top-k, recompute the others by fp64 brute force.  qn / gn: fp32 squared norms of the queries / gallery rows.
+static int exact_finish(const float *gallery, const float *queries, int ng, int nq, int d, int depth, int cdepth, const int64_t *cand,
+                        const float *cand_d, const float *qn, const float *gn, float *gmax, int *flags, int64_t *ids, float *dists,
+                        hipStream_t stream) {
+  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, gn, ng, gmax);
+  // worst-case error of a split-bf16 distance, relative to |q|^2 + max|g|^2: dropped lo.lo products and the second
+  // bf16 rounding of both operands (3 * 2^-18), fp32 accumulation of 3 d products (3 d * 2^-24), fp32 row norms
+  // (d * 2^-24), the epilogue's three roundings
+  const float kappa = 3.0f / 262144.0f + 4.0f * d / 16777216.0f + 1e-6f;
+  (void)hipMemsetAsync(flags, 0, sizeof(int), stream);
+  hipLaunchKernelGGL(exact_rerank_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, queries, gallery, nq, ng, d, cand, cand_d, cdepth,
+                     depth, qn, gmax, kappa, ids, dists, flags);
+  hipLaunchKernelGGL(exact_fallback_kernel, dim3(std::min(nq, 2048)), dim3(256), 0, stream, queries, gallery, ng, d, depth, flags, ids,
+                     dists);
+  VTC_LAUNCH_CHECK("l2_topk exact");
   return 0;
 }
 
@@ -459,18 +636,35 @@ extern "C" int vtc_l2_topk(const float *gallery, const float *queries, int ng, i
   // EXACT: BF16X3 candidate lists, fp64 re-rank, verified superset property, fp64 brute force for the rest
   const int cdepth = exact_cdepth(depth, ng);
   if (int rc = l2_topk_impl(gallery, queries, ng, nq, d, cdepth, VTC_SWEEP_BF16X3, s.cand, s.cand_d, s, stream)) return rc;
-  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, s.gn, ng, s.gmax);
-  // worst-case error of a split-bf16 distance, relative to |q|^2 + max|g|^2: dropped lo.lo products and the second
-  // bf16 rounding of both operands (3 * 2^-18), fp32 accumulation of 3 d products (3 d * 2^-24), fp32 row norms
-  // (d * 2^-24), the epilogue's three roundings
-  const float kappa = 3.0f / 262144.0f + 4.0f * d / 16777216.0f + 1e-6f;
-  (void)hipMemsetAsync(s.flags, 0, sizeof(int), stream);
-  hipLaunchKernelGGL(exact_rerank_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, queries, gallery, nq, ng, d, s.cand, s.cand_d, cdepth,
-                     depth, s.qn, s.gmax, kappa, ids, dists, s.flags);
-  hipLaunchKernelGGL(exact_fallback_kernel, dim3(std::min(nq, 2048)), dim3(256), 0, stream, queries, gallery, ng, d, depth, s.flags, ids,
-                     dists);
-  VTC_LAUNCH_CHECK("l2_topk exact");
-  return 0;
+  return exact_finish(gallery, queries, ng, nq, d, depth, cdepth, s.cand, s.cand_d, s.qn, s.gn, s.gmax, s.flags, ids, dists, stream);
+}
+
+// Both retrieval directions of RecallAtK (a -> b and b -> a, evaluation/eval.py:117-127) from ONE distance matrix
+// D[i][j] = |b_i - a_j|^2: rows give, for every b row, its nearest a rows (ids_b2a: what vtc_l2_topk(gallery = a,
+// queries = b) returns); columns give, for every a row, its nearest b rows (ids_a2b = vtc_l2_topk(gallery = b,
+// queries = a)).  Same precisions; EXACT re-ranks both candidate sets in fp64.
+extern "C" size_t vtc_l2_topk_bidir_workspace_bytes(int n_a, int n_b, int d, int precision, int rows_per_block) {
+  return plan(nullptr, n_a, n_b, d, precision, rows_per_block, true).total;
+}
+
+extern "C" int vtc_l2_topk_bidir(const float *a, const float *b, int n_a, int n_b, int d, int depth, int precision,
+                                 int rows_per_block, int64_t *ids_b2a, float *dists_b2a, int64_t *ids_a2b, float *dists_a2b,
+                                 void *ws, size_t ws_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VTC_CHECK(n_a > 0 && n_b > 0 && d > 0, "l2_topk_bidir: empty problem");
+  VTC_CHECK(depth >= 1 && depth <= 64 && depth <= n_a && depth <= n_b, "l2_topk_bidir: depth=%d must be in [1, min(64, n_a, n_b)]", depth);
+  VTC_CHECK(precision >= VTC_SWEEP_F32 && precision <= VTC_SWEEP_EXACT, "l2_topk_bidir: bad precision %d", precision);
+  VTC_CHECK(d % 64 == 0, "l2_topk_bidir: d=%d must be a multiple of 64", d);
+  VTC_CHECK(ids_b2a && ids_a2b, "l2_topk_bidir: both id outputs are required");
+  SweepWs s = plan((char *)ws, n_a, n_b, d, precision, rows_per_block, true);
+  VTC_CHECK(ws && ws_bytes >= s.total, "l2_topk_bidir: workspace too small (%zu < %zu)", ws_bytes, s.total);
+  if (precision != VTC_SWEEP_EXACT)
+    return l2_topk_impl(a, b, n_a, n_b, d, depth, precision, ids_b2a, dists_b2a, s, stream, ids_a2b, dists_a2b);
+  const int cdepth = std::min(exact_cdepth(depth, n_a), exact_cdepth(depth, n_b));
+  if (int rc = l2_topk_impl(a, b, n_a, n_b, d, cdepth, VTC_SWEEP_BF16X3, s.cand, s.cand_d, s, stream, s.cand2, s.cand2_d)) return rc;
+  if (int rc = exact_finish(a, b, n_a, n_b, d, depth, cdepth, s.cand, s.cand_d, s.qn, s.gn, s.gmax, s.flags, ids_b2a, dists_b2a, stream))
+    return rc;
+  return exact_finish(b, a, n_b, n_a, d, depth, cdepth, s.cand2, s.cand2_d, s.gn, s.qn, s.qmax, s.flags, ids_a2b, dists_a2b, stream);
 }
 
 extern "C" int vtc_recall_hits(const int64_t *ids, int nq, int depth, int64_t target_offset, const int *k_vals, int nk,

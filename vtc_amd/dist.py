@@ -63,6 +63,10 @@ def all_gather_rows(x: torch.Tensor, n_total: int, rank: int, world: int) -> tor
     return torch.cat([out[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
 
 
+BIDIR_MIN_ROWS = 24576      # as host/metric.py RecallAtK.bidir_min_rows
+BIDIR_MIN_ROWS_F32 = 4096
+
+
 def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_total: int, k_vals: Sequence[int],
                    rank: int, world: int,
                    topk: Optional[Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor]] = None,
@@ -77,6 +81,7 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
     a_all = all_gather_rows(feats_a_local, n_total, rank, world)
     b_all = all_gather_rows(feats_b_local, n_total, rank, world)
     depth = min(int(max(k_vals)) + 1, n_total)
+    hip_sweep = topk is None
     if topk is None:
         from . import ops
 
@@ -85,9 +90,16 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
     ks = [min(int(k), depth) for k in k_vals]
     tgt = torch.arange(lo, hi, device=feats_a_local.device)[:, None]
     hits = torch.zeros(2, len(ks), dtype=torch.int64, device=feats_a_local.device)
+    both = None
+    if hip_sweep and world == 1 and n_total >= (BIDIR_MIN_ROWS_F32 if precision == 0 else BIDIR_MIN_ROWS):
+        # one rank owns the whole matrix: both directions from one distance GEMM (vtc_l2_topk_bidir); with more
+        # ranks each direction's [N/G, N] block is a different matrix and the two searches stay separate
+        from . import ops
+        i1, _, i2, _ = ops.l2_topk_bidir(a_all, b_all, depth, precision=precision, return_dists=False)
+        both = (i1, i2)
     # compute(a, b): gallery a, queries b (model/metric.py:137-146); this rank owns query rows [lo, hi)
     for d_, (gal, qry) in enumerate(((a_all, feats_b_local), (b_all, feats_a_local))):
-        ids = topk(gal, qry, depth)
+        ids = both[d_] if both is not None else topk(gal, qry, depth)
         if ids.is_cuda and len(ks) <= 4:
             from . import ops
             ops.recall_hits(ids, ks, target_offset=lo, hits=hits[d_])

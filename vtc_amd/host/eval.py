@@ -55,8 +55,7 @@ def main(config: ConfigParser, args, checkpoint_path=None, device="cuda"):
             res_vis.append(out[0])
             res_text.append(out[1])
     res_vis, res_text = torch.cat(res_vis), torch.cat(res_text)
-    t_from_i = RecallAtK("images", "titles", [1, 5, 10]).compute(res_vis, res_text)
-    i_from_t = RecallAtK("titles", "images", [1, 5, 10]).compute(res_text, res_vis)
+    t_from_i, i_from_t = RecallAtK("images", "titles", [1, 5, 10]).compute_both(res_vis, res_text)
     out = {"R1_title_from_im": t_from_i[0][1], "R5_title_from_im": t_from_i[1][1], "R10_title_from_im": t_from_i[2][1],
            "R1_im_from_title": i_from_t[0][1], "R5_im_from_title": i_from_t[1][1], "R10_im_from_title": i_from_t[2][1]}
     with open(save_path, "w") as f:

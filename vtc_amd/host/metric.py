@@ -74,13 +74,35 @@ class RecallAtK(BaseMetric):
     def compute(self, features_a, features_b):
         """metric.py:137-161."""
         num_samples = features_a.shape[0]
-        ids = self.topk_ids(features_a, features_b)
+        return self._hits_to_recall(self.topk_ids(features_a, features_b), num_samples)
+
+    #: galleries at least this large take both directions from ONE distance matrix (vtc_l2_topk_bidir: the second
+    #: direction is read off the columns of the blocks the first direction wrote; -12 % at 50k x 50k, slower
+    #: than two searches below ~20k because the column pass is issue-bound and the GEMM it saves is small there)
+    bidir_min_rows = 24576
+    bidir_min_rows_f32 = 4096      # SWEEP_F32: the fp32-MFMA GEMM it saves is the expensive part at every size
+
+    def _hits_to_recall(self, ids, num_samples):
         ks = [min(int(k), ids.shape[1]) for k in self.k_vals]
         out = []
         for i in range(0, len(ks), 4):
             hits = ops.recall_hits(ids, ks[i:i + 4]).cpu().numpy()
             out += [(k, float(h) / num_samples) for k, h in zip(self.k_vals[i:i + 4], hits)]
         return out
+
+    def compute_both(self, features_a, features_b):
+        """(compute(a, b), compute(b, a)) -- the two calls every caller of the reference makes back to back
+        (metric.py:177-180, evaluation/eval.py:117-127, retrieval_evaluation.py:38-44)."""
+        min_rows = self.bidir_min_rows_f32 if self.precision == L.SWEEP_F32 else self.bidir_min_rows
+        if features_a.shape[0] != features_b.shape[0] or features_a.shape[0] < min_rows:
+            return self.compute(features_a, features_b), self.compute(features_b, features_a)
+        a = torch.as_tensor(features_a, dtype=torch.float32).to(self._dev())
+        b = torch.as_tensor(features_b, dtype=torch.float32).to(self._dev())
+        if a.dim() != 2 or b.dim() != 2:
+            raise ValueError("RecallAtK.compute expects 2-D [N, D] features (one caption per video, SURVEY 3.3)")
+        depth = min(int(np.max(self.k_vals) + 1), a.shape[0])
+        ids_b2a, _, ids_a2b, _ = ops.l2_topk_bidir(a, b, depth, precision=self.precision, return_dists=False)
+        return self._hits_to_recall(ids_b2a, a.shape[0]), self._hits_to_recall(ids_a2b, b.shape[0])
 
     def avg(self):
         return None
@@ -91,9 +113,10 @@ class RecallAtK(BaseMetric):
         fa, fb = torch.cat(self.features_a_list), torch.cat(self.features_b_list)
         assert self.insert_index == len(fa)
         res = {}
-        for k, r in self.compute(fa, fb):
+        r_ab, r_ba = self.compute_both(fa, fb)
+        for k, r in r_ab:
             res[f"{self.name_b}_from_{self.name_a}-recall_at_{k}"] = r
-        for k, r in self.compute(fb, fa):
+        for k, r in r_ba:
             res[f"{self.name_a}_from_{self.name_b}-recall_at_{k}"] = r
         if self.writer:
             for name, r in res.items():

@@ -52,12 +52,12 @@ def chunk_frames(frames: torch.Tensor, frame_stride: int = 16, nframes: int = 8,
 def compute_recall(video_emb, caption_emb, precision=None):
     """compute_recall (:23-47): returns {"Video to Text": [R@1,R@5,R@10], "Text to Video": [...]} in percent,
     named exactly as the reference's DataFrame columns (tvr / vtr, :36-43)."""
-    m_v2t = RecallAtK("videos", "titles", [1, 5, 10])
-    m_t2v = RecallAtK("titles", "videos", [1, 5, 10])
+    m = RecallAtK("videos", "titles", [1, 5, 10])
     if precision is not None:
-        m_v2t.precision = m_t2v.precision = precision
-    vtr = np.array(m_v2t.compute(video_emb, caption_emb))[:, 1] * 100.0
-    tvr = np.array(m_t2v.compute(caption_emb, video_emb))[:, 1] * 100.0
+        m.precision = precision
+    r_v2t, r_t2v = m.compute_both(video_emb, caption_emb)        # compute(video, caption), compute(caption, video)
+    vtr = np.array(r_v2t)[:, 1] * 100.0
+    tvr = np.array(r_t2v)[:, 1] * 100.0
     return {"Video to Text": tvr, "Text to Video": vtr, "index": ["R@1", "R@5", "R@10"]}
 
 

@@ -152,6 +152,27 @@ def l2_topk(gallery: torch.Tensor, queries: torch.Tensor, depth: int, precision:
     return ids, dists
 
 
+def l2_topk_bidir(a: torch.Tensor, b: torch.Tensor, depth: int, precision: int = L.SWEEP_EXACT, rows_per_block: int = 0,
+                  return_dists: bool = True, ws: Optional[torch.Tensor] = None):
+    """Both directions from one distance matrix: (ids_b2a [n_b, depth], dists_b2a, ids_a2b [n_a, depth], dists_a2b),
+    where ids_b2a = l2_topk(gallery=a, queries=b) and ids_a2b = l2_topk(gallery=b, queries=a)."""
+    a, b = _gpu(a, torch.float32, "a"), _gpu(b, torch.float32, "b")
+    na, d = a.shape
+    nb = b.shape[0]
+    need = L.lib().vtc_l2_topk_bidir_workspace_bytes(na, nb, d, precision, rows_per_block)
+    if ws is None or ws.numel() < need:
+        ws = workspace(need, a.device)
+    ids1 = torch.empty(nb, depth, dtype=torch.int64, device=a.device)
+    ids2 = torch.empty(na, depth, dtype=torch.int64, device=a.device)
+    d1 = torch.empty(nb, depth, dtype=torch.float32, device=a.device) if return_dists else None
+    d2 = torch.empty(na, depth, dtype=torch.float32, device=a.device) if return_dists else None
+    L.check(L.lib().vtc_l2_topk_bidir(a.data_ptr(), b.data_ptr(), na, nb, d, depth, precision, rows_per_block,
+                                      ids1.data_ptr(), d1.data_ptr() if d1 is not None else None,
+                                      ids2.data_ptr(), d2.data_ptr() if d2 is not None else None,
+                                      ws.data_ptr(), ws.numel(), _stream()), "vtc_l2_topk_bidir")
+    return ids1, d1, ids2, d2
+
+
 def recall_hits(ids: torch.Tensor, k_vals: Sequence[int], target_offset: int = 0,
                 hits: Optional[torch.Tensor] = None) -> torch.Tensor:
     ids = _gpu(ids, torch.int64, "ids")

@@ -319,6 +319,8 @@ def main():
                 dts = max_over_ranks(time.perf_counter() - t0, world, device) / reps
                 extra[f"sweep_{N}_{prec_name}_ms"] = round(1e3 * dts, 3)
                 extra[f"sweep_{N}_{prec_name}_recall"] = {"t_from_v": r_ab, "v_from_t": r_ba}
+                one_matrix = world == 1 and N >= (vdist.BIDIR_MIN_ROWS_F32 if prec == L.SWEEP_F32 else vdist.BIDIR_MIN_ROWS)
+                extra[f"sweep_{N}_{prec_name}_path"] = "one distance matrix, row + column top-k" if one_matrix else "two searches"
                 # algorithmic HBM bytes, materialised fp32 matrix: 8 N^2 per direction, whole job
                 extra[f"sweep_{N}_{prec_name}_algorithmic_GBps"] = round(2 * 8.0 * N * N / dts / 1e9, 1)
             del va, noise, tb, va_l, tb_l

@@ -44,6 +44,9 @@ template <bool NT>
 __device__ __forceinline__ void store16(void *o, uint4 v) {
   typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
   v4u_t vv = {v.x, v.y, v.z, v.w};
+#ifdef VTC_ABLATE_STORES   // timing experiment: everything but the global stores (one lane's store keeps the values live)
+  if (threadIdx.x != 0 || vv.x != 0x12345678u) return;
+#endif
   // (a run-time flag does not work: the two stores are merged and the hint is dropped)
   if constexpr (NT) __builtin_nontemporal_store(vv, reinterpret_cast<v4u_t *>(o));
   else *reinterpret_cast<v4u_t *>(o) = vv;
@@ -181,10 +184,20 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       const int m = m0 + (wr * TM + i) * 16 + (lane >> 4) + 4 * k;
       return reinterpret_cast<float *>(p.out) + (size_t)m * ldo + ncol0 + l15 * 4;
     };
-    float4 xc[4], xn[4];
+#ifndef VTC_RESID_DEPTH
+#define VTC_RESID_DEPTH 2
+#endif
+    // x rows of the next XD - 1 passes in flight.  Depth 2 (one pass ahead) is enough: these loads queue behind the
+    // previous passes' stores in the in-order vmcnt queue, and the N = 512 residual GEMMs move their 605 MB at
+    // 4.35 TB/s -- the copy rate of the chip -- at depth 2, 3 and 4 alike (3 = +14 VGPRs, 4 spills)
+    constexpr int XD = VTC_RESID_DEPTH;
+    float4 xr[XD][4];
     if (MODE == VTC_EPI_RESID) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) xc[k] = *reinterpret_cast<const float4 *>(x_ptr(0, k));
+      for (int a = 0; a < XD - 1; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (a < TM) xr[a][k] = *reinterpret_cast<const float4 *>(x_ptr(a, k));
     }
     // distance mode: |q|^2 of the lane's rows and |g|^2 of its columns are fetched once, in the MFMA layout, and the
     // distance is formed BEFORE the transposition: a load inside the pass loop sits behind the previous pass's
@@ -196,9 +209,9 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      if (MODE == VTC_EPI_RESID && i + 1 < TM) {
+      if (MODE == VTC_EPI_RESID && i + XD - 1 < TM) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xn[k] = *reinterpret_cast<const float4 *>(x_ptr(i + 1, k));
+        for (int k = 0; k < 4; ++k) xr[(i + XD - 1) % XD][k] = *reinterpret_cast<const float4 *>(x_ptr(i + XD - 1, k));
       }
       // 1. registers -> LDS: final fp32 values in [16 rows][64 cols]
 #pragma unroll
@@ -239,7 +252,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
           if (MODE == VTC_EPI_RESID) {
             // skipped rows are written back unchanged (a select, not a branch: an exec-masked store makes hipcc
             // re-wait on the x prefetch after every store, which throttles the store stream)
-            const float4 x = xc[k];
+            const float4 x = xr[i % XD][k];
             store16<nt_out>(o, make_float4(live ? x.x + v.x : x.x, live ? x.y + v.y : x.y, live ? x.z + v.z : x.z,
                                            live ? x.w + v.w : x.w));
           } else {
@@ -265,10 +278,6 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (MODE == VTC_EPI_RESID) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) xc[k] = xn[k];
-      }
     }
   } else {
     // Generic path: edge tiles (M or N not a multiple of the tile, odd leading dimension).

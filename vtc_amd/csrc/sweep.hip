@@ -176,17 +176,19 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__
 // (strip of 64 columns, row segment).  The segment's rows stream through LDS in 64 x 64 tiles (coalesced 256-byte row
 // pieces in, 16-byte LDS accesses both ways: row stride 68 floats); wave w owns columns 16w .. 16w+15 of the strip and
 // keeps one WaveList per column (2 VGPRs each).  The first tile of a segment initialises a list by rank-counting
-// its 64 values (64 serial insertions per column otherwise).  ids are row_id0 + row; partial lists go to
-// part[(col * S_total + seg0 + seg) * depth ..] and are merged over blocks and segments by topk_merge_kernel.
+// its 64 values (64 serial insertions per column otherwise).  ids are row_id0 + row; partial lists live in
+// part[(col * S_total + seg0 + seg) * depth ..], are CARRIED from one block of rows to the next (carry != 0) and are
+// merged over segments by topk_merge_kernel.
 __global__ __launch_bounds__(256, 4) void col_topk_kernel(const float *__restrict__ dist, int ld, int n_rows, int n_cols, int depth,
-                                                       int row_id0, int S, int seg_rows, int S_total, int seg0,
+                                                       int row_id0, int S, int seg_rows, int S_total, int seg0, int carry,
                                                        float *__restrict__ part_d, int *__restrict__ part_i) {
   __shared__ __attribute__((aligned(16))) float tile[64 * 68];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int strip = blockIdx.x / S, seg = blockIdx.x - strip * S;
   const int c0 = strip * 64;
   const int r_lo = seg * seg_rows, r_hi = min(n_rows, r_lo + seg_rows);
-  if (r_lo >= r_hi) {            // empty segment (uniform): its partial lists stay "invalid"
+  if (r_lo >= r_hi) {            // empty segment (uniform): its partial lists stay as they are / "invalid"
+    if (carry) return;
     for (int cc = 0; cc < 16; ++cc) {
       const int col = c0 + 16 * w + cc;
       if (col < n_cols && lane < depth) {
@@ -198,7 +200,21 @@ __global__ __launch_bounds__(256, 4) void col_topk_kernel(const float *__restric
   }
   WaveList wl[16];
 #pragma unroll
-  for (int cc = 0; cc < 16; ++cc) wl[cc].init();
+  for (int cc = 0; cc < 16; ++cc) {
+    wl[cc].init();
+    const int col = c0 + 16 * w + cc;
+    if (carry && col < n_cols) {
+      // the list of this (column, segment) continues from the previous block of rows: its k-th best is already a
+      // tight threshold, so later blocks insert ~k ln(rows_after / rows_before) times instead of ~k ln(rows / 64)
+      if (lane < depth) {
+        wl[cc].bd = part_d[((size_t)col * S_total + seg0 + seg) * depth + lane];
+        wl[cc].bi = part_i[((size_t)col * S_total + seg0 + seg) * depth + lane];
+      }
+      wl[cc].tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl[cc].bd), depth - 1));
+      wl[cc].tau_i = __builtin_amdgcn_readlane(wl[cc].bi, depth - 1);
+    }
+    if (col >= n_cols) wl[cc].tau = -INFINITY;                  // columns past the matrix never offer anything
+  }
   const int lr = t >> 4, lc = (t & 15) * 4;
   const bool vec = (ld & 3) == 0 && c0 + 64 <= n_cols;      // uniform: whole strip inside the matrix, rows 16-byte aligned
   auto load_tile = [&](int r_base, float4 (&pre)[4]) {
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(256, 4) void col_topk_kernel(const float *__restric
       }
     }
   };
-  // one 64-row step: registers -> LDS, refill the registers two tiles ahead, screen the tile from LDS
+  // one 64-row step: registers -> LDS, refill the registers with the next tile, screen this tile from LDS
   auto step = [&](int r_base, float4 (&pre)[4]) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
@@ -236,21 +252,20 @@ __global__ __launch_bounds__(256, 4) void col_topk_kernel(const float *__restric
           make_float4(live ? pre[h].x : INFINITY, live ? pre[h].y : INFINITY, live ? pre[h].z : INFINITY, live ? pre[h].w : INFINITY);
     }
     __syncthreads();
-    load_tile(r_base + 128, pre);                            // two tiles (32 KiB per workgroup) in flight
+    load_tile(r_base + 64, pre);                             // the next tile is in flight while this one is screened
     const bool valid = r_base + lane < r_hi;
     const int idx = valid ? row_id0 + r_base + lane : 0x7fffffff;
-    const bool sort_init = r_base == r_lo && r_lo + 64 <= r_hi;   // a full first tile (uniform)
+    const bool sort_init = !carry && r_base == r_lo && r_lo + 64 <= r_hi;   // a full first tile of a fresh list (uniform)
     float vv[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 t4 = *reinterpret_cast<const float4 *>(tile + lane * 68 + 16 * w + 4 * q);
       vv[4 * q] = t4.x; vv[4 * q + 1] = t4.y; vv[4 * q + 2] = t4.z; vv[4 * q + 3] = t4.w;
     }
+    if (sort_init) {
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-      if (c0 + 16 * w + cc >= n_cols) continue;                 // uniform; columns past the matrix hold +inf everywhere
-      const float v = vv[cc];
-      if (sort_init) {
+      for (int cc = 0; cc < 16; ++cc) {
+        const float v = vv[cc];
         int rank = 0;
 #pragma unroll 4
         for (int l = 0; l < 64; ++l) {
@@ -263,19 +278,25 @@ __global__ __launch_bounds__(256, 4) void col_topk_kernel(const float *__restric
         wl[cc].bi = __builtin_amdgcn_ds_permute(rank << 2, idx);
         wl[cc].tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl[cc].bd), depth - 1));
         wl[cc].tau_i = __builtin_amdgcn_readlane(wl[cc].bi, depth - 1);
-      } else {
-        wl[cc].offer(v, idx, valid && v <= wl[cc].tau, lane, depth);   // offer() re-checks (tau, tau_i) exactly
+        if (c0 + 16 * w + cc >= n_cols) wl[cc].tau = -INFINITY;   // columns past the matrix never offer anything
+      }
+    } else {
+      // hot path: one compare per column, ORed; the per-column control flow runs only when some lane of the wave
+      // has a candidate in some column
+      bool anyp = false;
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) anyp |= vv[cc] <= wl[cc].tau;
+      if (__ballot(valid && anyp) != 0ull) {
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc)
+          wl[cc].offer(vv[cc], idx, valid && vv[cc] <= wl[cc].tau, lane, depth);   // offer() re-checks (tau, tau_i) exactly
       }
     }
     __syncthreads();
   };
-  float4 preA[4], preB[4];
-  load_tile(r_lo, preA);
-  load_tile(r_lo + 64, preB);
-  for (int r_base = r_lo; r_base < r_hi; r_base += 128) {
-    step(r_base, preA);
-    if (r_base + 64 < r_hi) step(r_base + 64, preB);
-  }
+  float4 pre[4];
+  load_tile(r_lo, pre);
+  for (int r_base = r_lo; r_base < r_hi; r_base += 64) step(r_base, pre);
 #pragma unroll
   for (int cc = 0; cc < 16; ++cc) {
     const int col = c0 + 16 * w + cc;
@@ -477,7 +498,7 @@ struct SweepWs {
   // both directions from one matrix (vtc_l2_topk_bidir): partial column lists, and the EXACT mode's second candidate set
   float *cpart_d;
   int *cpart_i;
-  int c_seg, c_total;            // row segments per block, partial lists per column (blocks x segments)
+  int c_seg, c_total;            // row segments per block = partial lists per column (carried across blocks)
   int64_t *cand2;
   float *cand2_d, *qmax;
   size_t total;
@@ -531,7 +552,7 @@ SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block,
     // insertions (measured at 50k x 50k: 1 / 2 / 3 / 5 segments per block = 4.3 / 4.6 / 5.1 / 6.2 ms per direction)
     s.c_seg = std::max(1, std::min(MAX_CSEG, cdiv(3 * vtcgemm::num_cus(), strips)));
     s.c_seg = std::min(s.c_seg, std::max(1, rpb / 128));                    // at least two tiles per segment
-    s.c_total = cdiv(nq, rpb) * s.c_seg;
+    s.c_total = s.c_seg;                                     // a (column, segment) list is carried from block to block
     s.cpart_d = (float *)take((size_t)ng * s.c_total * 64 * 4);
     s.cpart_i = (int *)take((size_t)ng * s.c_total * 64 * 4);
     if (exact) {
@@ -592,7 +613,7 @@ static int l2_topk_impl(const float *gallery, const float *queries, int ng, int 
       const int seg_rows = cdiv(cdiv(rows, s.c_seg), 64) * 64;
       ProfScope prof(VTC_PROF_TOPK, (double)rows * ng * 4, stream);
       hipLaunchKernelGGL(col_topk_kernel, dim3(cdiv(ng, 64) * s.c_seg), dim3(256), 0, stream, s.dist, ng, rows, ng, depth, r0, s.c_seg,
-                         seg_rows, s.c_total, (r0 / s.rows_per_block) * s.c_seg, s.cpart_d, s.cpart_i);
+                         seg_rows, s.c_total, 0, r0 > 0 ? 1 : 0, s.cpart_d, s.cpart_i);
       VTC_LAUNCH_CHECK("col_topk");
     }
   }

@@ -63,7 +63,7 @@ def all_gather_rows(x: torch.Tensor, n_total: int, rank: int, world: int) -> tor
     return torch.cat([out[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
 
 
-BIDIR_MIN_ROWS = 24576      # as host/metric.py RecallAtK.bidir_min_rows
+BIDIR_MIN_ROWS = 14336      # as host/metric.py RecallAtK.bidir_min_rows
 BIDIR_MIN_ROWS_F32 = 4096
 
 

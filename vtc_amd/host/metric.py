@@ -77,9 +77,10 @@ class RecallAtK(BaseMetric):
         return self._hits_to_recall(self.topk_ids(features_a, features_b), num_samples)
 
     #: galleries at least this large take both directions from ONE distance matrix (vtc_l2_topk_bidir: the second
-    #: direction is read off the columns of the blocks the first direction wrote; -12 % at 50k x 50k, slower
-    #: than two searches below ~20k because the column pass is issue-bound and the GEMM it saves is small there)
-    bidir_min_rows = 24576
+    #: direction is read off the columns of the blocks the first direction wrote).  Measured one-matrix vs two searches,
+    #: EXACT: 10k 1.54 vs 1.33 ms, 16k 2.46 vs 2.65, 25k 5.1 vs 6.0, 50k 15.4 vs 21.1 (the column pass is issue-bound
+    #: and pays a list initialisation per segment; the GEMM it saves grows with N^2)
+    bidir_min_rows = 14336
     bidir_min_rows_f32 = 4096      # SWEEP_F32: the fp32-MFMA GEMM it saves is the expensive part at every size
 
     def _hits_to_recall(self, ids, num_samples):

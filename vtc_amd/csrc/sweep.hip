@@ -360,11 +360,38 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
   const float *q = queries + (size_t)r * d;
   const int64_t my = lane < cdepth ? cand[(size_t)r * cdepth + lane] : -1;
   double md = INFINITY;
-  for (int c = 0; c < cdepth; ++c) {
-    const long long j = __shfl((long long)my, c, 64);
-    if (j < 0) continue;                                  // wave-uniform
-    const double dj = wave_dist64(q, gallery + (size_t)j * d, d, lane);
-    if (lane == c) md = dj;
+  // Four candidates at a time: their row pieces are all requested before the first is used and the four xor
+  // butterflies interleave (one candidate at a time the kernel was a chain of 32 dependent gather latencies).
+  // Per candidate the arithmetic and its order are exactly wave_dist64's, so the fallback kernel forms the same doubles.
+  for (int c0 = 0; c0 < cdepth; c0 += 4) {
+    long long jj[4];
+    double sacc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      jj[u] = c0 + u < cdepth ? __shfl((long long)my, c0 + u, 64) : -1;      // wave-uniform
+      sacc[u] = 0.0;
+    }
+    for (int c = lane * 4; c < d; c += 256) {
+      const float4 a = *reinterpret_cast<const float4 *>(q + c);
+      float4 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        b[u] = *reinterpret_cast<const float4 *>(gallery + (size_t)(jj[u] < 0 ? 0 : jj[u]) * d + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double e0 = (double)a.x - (double)b[u].x, e1 = (double)a.y - (double)b[u].y, e2 = (double)a.z - (double)b[u].z,
+                     e3 = (double)a.w - (double)b[u].w;
+        sacc[u] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o, 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (jj[u] >= 0 && lane == c0 + u) md = sacc[u];
   }
   // rank among the candidates by (fp64 distance, index); absent slots sort last
   int rank = 0;

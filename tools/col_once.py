@@ -1,3 +1,4 @@
+"""One vtc_l2_topk_bidir call (BF16) at N = argv[1] (default 10000): the workload for rocprofv3 --pmc passes over col_topk_kernel."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

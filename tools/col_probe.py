@@ -1,3 +1,4 @@
+"""One search (vtc_l2_topk) vs both directions from one matrix (vtc_l2_topk_bidir), BF16 and EXACT, at N = argv[1]: prints ms per call."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,3 +1,4 @@
+"""50k sweep GEMMs under the -DVTC_GEMM_STAMPS build (VTC_HIP_LIB=vtc_amd/lib/variants/libvtc_stamps.so): per-tile phase cycles on stderr."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from vtc_amd import _lib as L, ops

@@ -603,6 +603,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
   }
 
   u32x4 aS[4][2], wS[2][2];     // register subtile: 4 activation x 2 weight fragments x 2 K halves
+  bool relax_first = false;     // the previous tile's epilogue issued exactly NST stores last (see the phase-end wait)
 #ifdef VTC_GEMM_STAMPS
   // diagnostic build: s_memtime at the tile-level phase boundaries; sums leave through p.dbg only
   unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tsp = 0;
@@ -680,6 +681,19 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
         //     quarter is read three phases after its issue at the earliest, and the half of the workgroup that runs
         //     one barrier ahead must not read what the other half has not waited for yet: hence one phase early.
 #ifndef VTC_ABLATE_VMWAIT
+#ifndef VTC_NO_RELAXED_FIRST
+        // First K-tile after an (interior) epilogue: the wave's NST epilogue stores are older than this K-tile's
+        // pieces in the in-order vmcnt queue, and a plain vmcnt(2) here would park the wave until they are all
+        // acknowledged.  Nothing issued after them is needed before the end of phase 2 (quarter A0 has one phase of
+        // slack in the steady-state schedule: issued in phase 0, read after the barrier that ends phase 3, which the
+        // lagging half reaches with its waits up to phase 2 done), so phases 0 and 1 leave the stores -- and the
+        // quarters issued since -- in flight and only make sure of everything OLDER than the stores.
+        constexpr int NST = sizeof(OutT) == 2 ? 16 : 32;     // 16-byte stores per wave in tile_epilogue's fast paths
+        if (ph < 2 && t == 0 && relax_first) {
+          if constexpr (ph == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NST) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");
+        } else
+#endif
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 #endif
         __builtin_amdgcn_s_barrier();
@@ -702,6 +716,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
     }
 #endif
     if (!has_next) break;
+    relax_first = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 3) == 0);   // the tile just stored took a fast path
     __builtin_amdgcn_s_barrier();          // the transposition area is the next K-tile's DMA target
 #ifdef VTC_GEMM_STAMPS
     { const unsigned long long t = stamp(); ph[3] += t - tsp; tsp = t; }       // post-epilogue barrier

@@ -56,7 +56,10 @@ __device__ __forceinline__ void store16(void *o, float4 v) {
   store16<NT>(o, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
 }
 
-// ---- epilogue (shared by both kernels): the wave's TM x TN accumulator fragments -> out, through a scratch
+// ---- epilogue (shared by both kernels).  CONTRACT with gemm_phased_kernel's relaxed first-K-tile waits: on an interior
+// tile the last vector-memory operations a wave issues here are exactly TM * 2 (bf16 out) or TM * 4 (fp32 out) 16-byte
+// stores, and every load issued here has been consumed before them.
+// The wave's TM x TN accumulator fragments -> out, through a scratch
 // area of the dynamic LDS (byte offset scratch_off, >= 6 KiB per wave) that no DMA targets and nobody reads until
 // the caller's next barrier.  (The area is named by OFFSET and re-based on the extern array here: handed over as
 // a generic pointer, hipcc guards every LDS read behind the preceding global stores -- vmcnt waits that
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
         // slack in the steady-state schedule: issued in phase 0, read after the barrier that ends phase 3, which the
         // lagging half reaches with its waits up to phase 2 done), so phases 0 and 1 leave the stores -- and the
         // quarters issued since -- in flight and only make sure of everything OLDER than the stores.
-        constexpr int NST = sizeof(OutT) == 2 ? 16 : 32;     // 16-byte stores per wave in tile_epilogue's fast paths
+        constexpr int NST = TM * (sizeof(OutT) == 2 ? 2 : 4);   // 16-byte stores per wave in tile_epilogue's fast paths (its LAST vm ops)
         if (ph < 2 && t == 0 && relax_first) {
           if constexpr (ph == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NST) : "memory");
           else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");

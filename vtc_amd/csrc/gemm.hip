@@ -57,8 +57,9 @@ __device__ __forceinline__ void store16(void *o, float4 v) {
 }
 
 // ---- epilogue (shared by both kernels).  CONTRACT with gemm_phased_kernel's relaxed first-K-tile waits: on an interior
-// tile the last vector-memory operations a wave issues here are exactly TM * 2 (bf16 out) or TM * 4 (fp32 out) 16-byte
-// stores, and every load issued here has been consumed before them.
+// tile a wave issues AT LEAST TM * 2 (bf16 out) or TM * 4 (fp32 out) vector-memory operations here (its 16-byte stores;
+// the residual mode's x loads come on top), so the NST youngest operations before the next tile's first LDS-DMA piece
+// all belong to this epilogue -- none of them is a DMA piece the K loop still has to wait for.
 // The wave's TM x TN accumulator fragments -> out, through a scratch
 // area of the dynamic LDS (byte offset scratch_off, >= 6 KiB per wave) that no DMA targets and nobody reads until
 // the caller's next barrier.  (The area is named by OFFSET and re-based on the extern array here: handed over as

@@ -1,0 +1,16 @@
+"""Odd shapes through the four wrappers on the HIP path vs the live oracle: batch sizes 1..33, 1..7 comments per item,
+all-empty / no-empty comments, every residual activation, fp32 and bf16 (tools/fuzz_wrappers.py, two fixed seeds)."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+def test_wrappers_odd_shapes_vs_oracle(seed):
+    import fuzz_wrappers
+    worst = fuzz_wrappers.run_cases(16, seed=seed, verbose=False)
+    assert worst.get("torch.float32", 0.0) < 1e-5

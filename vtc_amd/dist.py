@@ -78,8 +78,15 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
     exercise the sharding logic under gloo."""
     lo, hi = shard_bounds(n_total, rank, world)
     assert feats_a_local.shape[0] == hi - lo and feats_b_local.shape[0] == hi - lo
-    a_all = all_gather_rows(feats_a_local, n_total, rank, world)
-    b_all = all_gather_rows(feats_b_local, n_total, rank, world)
+    if world > 1 and feats_a_local.shape[1] == feats_b_local.shape[1] and feats_a_local.dtype == feats_b_local.dtype:
+        # ONE exchange for both embedding sets ([n_r, 2D] rows): at 10k x 512 the all-gather is latency-bound, a second
+        # collective costs as much as the first
+        d = feats_a_local.shape[1]
+        ab = all_gather_rows(torch.cat([feats_a_local, feats_b_local], dim=1), n_total, rank, world)
+        a_all, b_all = ab[:, :d].contiguous(), ab[:, d:].contiguous()
+    else:
+        a_all = all_gather_rows(feats_a_local, n_total, rank, world)
+        b_all = all_gather_rows(feats_b_local, n_total, rank, world)
     depth = min(int(max(k_vals)) + 1, n_total)
     hip_sweep = topk is None
     if topk is None:

@@ -309,14 +309,21 @@ def main():
             va_l, tb_l = va[lo:hi].to(device), tb[lo:hi].to(device)
             precs = [("exact", L.SWEEP_EXACT), ("f32", L.SWEEP_F32), ("bf16x3", L.SWEEP_BF16X3)] + ([("bf16", L.SWEEP_BF16)] if N == args.stress_n else [])
             for prec_name, prec in precs:
-                vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec)      # warm-up
+                # caller-owned workspace, as a serving loop would hold it (a fresh multi-GiB torch allocation per call
+                # can land on a hipMalloc / cache flush: seen as one 45 ms call in three)
+                lib = L.lib()
+                need = max(lib.vtc_l2_topk_workspace_bytes(N, hi - lo, 512, prec, 0), lib.vtc_l2_topk_workspace_bytes(N, N, 512, prec, 0) if world == 1 else 0,
+                           lib.vtc_l2_topk_bidir_workspace_bytes(N, N, 512, prec, 0) if world == 1 else 0)
+                sweep_ws = ops.workspace(need, device)
+                vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec, ws=sweep_ws)      # warm-up
                 barrier_sync(world)
                 t0 = time.perf_counter()
                 reps = 3
                 for _ in range(reps):
-                    r_ab, r_ba = vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec)
+                    r_ab, r_ba = vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec, ws=sweep_ws)
                 barrier_sync(world)
                 dts = max_over_ranks(time.perf_counter() - t0, world, device) / reps
+                del sweep_ws
                 extra[f"sweep_{N}_{prec_name}_ms"] = round(1e3 * dts, 3)
                 extra[f"sweep_{N}_{prec_name}_recall"] = {"t_from_v": r_ab, "v_from_t": r_ba}
                 one_matrix = world == 1 and N >= (vdist.BIDIR_MIN_ROWS_F32 if prec == L.SWEEP_F32 else vdist.BIDIR_MIN_ROWS)

@@ -70,12 +70,14 @@ BIDIR_MIN_ROWS_F32 = 4096
 def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_total: int, k_vals: Sequence[int],
                    rank: int, world: int,
                    topk: Optional[Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor]] = None,
-                   precision: int = 3):   # _lib.SWEEP_EXACT
+                   precision: int = 3,    # _lib.SWEEP_EXACT
+                   ws: Optional[torch.Tensor] = None):
     """R@K both directions for row-sharded embeddings.
 
     Returns ({k: recall b_from_a-direction as RecallAtK.compute(a, b)}, {k: compute(b, a)}).
     ``topk(gallery, queries, depth) -> ids`` defaults to the HIP sweep; tests inject a CPU one to
-    exercise the sharding logic under gloo."""
+    exercise the sharding logic under gloo.  ``ws``: a caller-owned uint8 workspace reused across calls (grown by the
+    ops layer when too small)."""
     lo, hi = shard_bounds(n_total, rank, world)
     assert feats_a_local.shape[0] == hi - lo and feats_b_local.shape[0] == hi - lo
     if world > 1 and feats_a_local.shape[1] == feats_b_local.shape[1] and feats_a_local.dtype == feats_b_local.dtype:
@@ -93,7 +95,7 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
         from . import ops
 
         def topk(g, q, d):
-            return ops.l2_topk(g, q, d, precision=precision, return_dists=False)[0]
+            return ops.l2_topk(g, q, d, precision=precision, return_dists=False, ws=ws)[0]
     ks = [min(int(k), depth) for k in k_vals]
     tgt = torch.arange(lo, hi, device=feats_a_local.device)[:, None]
     hits = torch.zeros(2, len(ks), dtype=torch.int64, device=feats_a_local.device)
@@ -102,7 +104,7 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
         # one rank owns the whole matrix: both directions from one distance GEMM (vtc_l2_topk_bidir); with more
         # ranks each direction's [N/G, N] block is a different matrix and the two searches stay separate
         from . import ops
-        i1, _, i2, _ = ops.l2_topk_bidir(a_all, b_all, depth, precision=precision, return_dists=False)
+        i1, _, i2, _ = ops.l2_topk_bidir(a_all, b_all, depth, precision=precision, return_dists=False, ws=ws)
         both = (i1, i2)
     # compute(a, b): gallery a, queries b (model/metric.py:137-146); this rank owns query rows [lo, hi)
     for d_, (gal, qry) in enumerate(((a_all, feats_b_local), (b_all, feats_a_local))):

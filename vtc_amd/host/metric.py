@@ -47,6 +47,7 @@ class RecallAtK(BaseMetric):
         self.reset()
 
     def reset(self):
+        self._ws = None
         self.insert_index = 0
         self.features_a_list, self.features_b_list = [], []
 
@@ -68,8 +69,18 @@ class RecallAtK(BaseMetric):
         if a.dim() != 2 or b.dim() != 2:
             raise ValueError("RecallAtK.compute expects 2-D [N, D] features (one caption per video, SURVEY 3.3)")
         depth = min(int(np.max(self.k_vals) + 1), a.shape[0])
-        ids, _ = ops.l2_topk(a, b, depth, precision=self.precision, return_dists=False)
+        ids, _ = ops.l2_topk(a, b, depth, precision=self.precision, return_dists=False, ws=self._workspace(
+            L.lib().vtc_l2_topk_workspace_bytes(a.shape[0], b.shape[0], a.shape[1], self.precision, 0), a.device))
         return ids
+
+    def _workspace(self, nbytes, device):
+        """One sweep workspace per metric object, grown on demand and dropped by reset() (a fresh multi-GiB
+        allocation per search can land on a hipMalloc)."""
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            self._ws = None
+            ws = self._ws = ops.workspace(nbytes, device)
+        return ws
 
     def compute(self, features_a, features_b):
         """metric.py:137-161."""
@@ -102,7 +113,8 @@ class RecallAtK(BaseMetric):
         if a.dim() != 2 or b.dim() != 2:
             raise ValueError("RecallAtK.compute expects 2-D [N, D] features (one caption per video, SURVEY 3.3)")
         depth = min(int(np.max(self.k_vals) + 1), a.shape[0])
-        ids_b2a, _, ids_a2b, _ = ops.l2_topk_bidir(a, b, depth, precision=self.precision, return_dists=False)
+        ids_b2a, _, ids_a2b, _ = ops.l2_topk_bidir(a, b, depth, precision=self.precision, return_dists=False, ws=self._workspace(
+            L.lib().vtc_l2_topk_bidir_workspace_bytes(a.shape[0], b.shape[0], a.shape[1], self.precision, 0), a.device))
         return self._hits_to_recall(ids_b2a, a.shape[0]), self._hits_to_recall(ids_a2b, b.shape[0])
 
     def avg(self):

@@ -272,6 +272,30 @@ def main():
                       if k.startswith("final_transformer.") or k in ("mask_embedding", "model.logit_scale")}
         del m3, vid
         torch.cuda.empty_cache()
+        # ---- the stress config's encoder (BASELINE configs[4]): 16-frame TimeSformer + title + 5 comments ------
+        class _TSF16(HM.PretrainedCLIP_TimeSformer_finaltf):
+            nframes = 16
+        m16 = _TSF16(model_type="ViT-B/32", branch_to_adapt_val="text")
+        for blk in m16.model.visual.transformer.resblocks:
+            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+        m16 = m16.eval().to(device)
+        m16.compute_dtype = cdt
+        B16 = min(B, 128)
+        vid16 = torch.randn(B16, 16, 3, 224, 224, generator=gen).to(device).to(cdt)
+        t16, c16 = title[:B16].contiguous(), comments[:B16].contiguous()
+        for _ in range(2):
+            m16(vid16, t16, c16)
+        barrier_sync(world)
+        k16 = max(2, args.steps // 3)
+        t0 = time.perf_counter()
+        for _ in range(k16):
+            m16(vid16, t16, c16)
+        barrier_sync(world)
+        dt16 = max_over_ranks(time.perf_counter() - t0, world, device)
+        extra["stress_timesformer16_pairs_per_s"] = round(world * B16 * k16 / dt16, 1)
+        extra["stress_timesformer16_pairs_per_gpu"] = B16
+        del m16, vid16
+        torch.cuda.empty_cache()
 
         # ---- adapter-only training step (configs/pretrained_clip_comments_attn_frozen.jsonc:
         # batch 128, frozen towers, clip_loss, Adam amsgrad): forward + backward + update of the CAM on the HIP path

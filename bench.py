@@ -99,8 +99,23 @@ def cpu_baseline(kind_pairs=96):
             t0 = time.perf_counter()
             M.pretrained_clip_finaltf(vis, title, comments, sd, a, "text")
             best = min(best, time.perf_counter() - t0)
-    return dict(value=round(B / best, 3), unit="pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle fp32 forward of config 2 at B={B} (1 title + 5 comments per pair), best of 2, {best:.2f} s")
+    out = dict(value=round(B / best, 3), unit="pairs/s", cores=torch.get_num_threads(), kind="port",
+               sample=f"oracle fp32 forward of config 2 at B={B} (1 title + 5 comments per pair), best of 2, {best:.2f} s")
+    # the second half of the metric: 10k x 10k sim + R@1/5/10, both directions, on the same cores (the oracle's
+    # literal restatement of RecallAtK.compute, model/metric.py:137-161, fp32 numpy)
+    import numpy as np
+    from oracle import eval_ref as E
+    rng = np.random.default_rng(123)
+    n = 10000
+    va = rng.standard_normal((n, 512)).astype(np.float32)
+    va /= np.linalg.norm(va, axis=1, keepdims=True)
+    tb = va + 0.05 * rng.standard_normal((n, 512)).astype(np.float32)
+    tb /= np.linalg.norm(tb, axis=1, keepdims=True)
+    t0 = time.perf_counter()
+    E.recall_at_k(va, tb, [1, 5, 10])
+    E.recall_at_k(tb, va, [1, 5, 10])
+    out["sweep_10000_ms"] = round(1e3 * (time.perf_counter() - t0), 1)
+    return out
 
 
 def pmc_traffic():

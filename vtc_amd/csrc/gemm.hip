@@ -158,23 +158,32 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     // (the other stage already holds the next tile's first slab) and writes whole rows: every
     // store instruction covers 4 (fp32) or 8 (bf16) full 256 / 128-byte row segments.
     constexpr int TS = 68;                                   // padded row stride (floats): conflict-free b128 writes
+    // A pass moves 16 rows x 64 columns: the wave's TN * 16 columns are H = TN / 4 column halves (H = 2 for the
+    // 128 x 512 row-panel tiles), pass pp = (fragment row i, half hh)
+    constexpr int H = TN / 4, NP = TM * H;
+    static_assert(TN % 4 == 0 && (H == 1 || sizeof(OutT) == 4), "wide wave tiles: fp32 outputs only");
     float *tr = reinterpret_cast<float *>(lds + scratch_off + wave * SCRATCH_PER_WAVE);
     const int l15 = lane & 15;
     const int ncol0 = n0 + wc * TN * 16;
     // column addend (bias, or |g|^2 of the distance epilogue) for the columns this lane writes back
     const float *colv = MODE == EPI_L2DIST ? p.epi.coln : p.bias;
-    float cadd[8];
+    float cadd[H][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) cadd[e] = 0.f;
+    for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cadd[hh][e] = 0.f;
     if (colv) {
       if constexpr (sizeof(OutT) == 4) {
-        const float4 c4 = *reinterpret_cast<const float4 *>(colv + ncol0 + l15 * 4);
-        cadd[0] = c4.x; cadd[1] = c4.y; cadd[2] = c4.z; cadd[3] = c4.w;
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) {
+          const float4 c4 = *reinterpret_cast<const float4 *>(colv + ncol0 + 64 * hh + l15 * 4);
+          cadd[hh][0] = c4.x; cadd[hh][1] = c4.y; cadd[hh][2] = c4.z; cadd[hh][3] = c4.w;
+        }
       } else {
         const float4 c0 = *reinterpret_cast<const float4 *>(colv + ncol0 + (lane & 7) * 8);
         const float4 c1 = *reinterpret_cast<const float4 *>(colv + ncol0 + (lane & 7) * 8 + 4);
-        cadd[0] = c0.x; cadd[1] = c0.y; cadd[2] = c0.z; cadd[3] = c0.w;
-        cadd[4] = c1.x; cadd[5] = c1.y; cadd[6] = c1.z; cadd[7] = c1.w;
+        cadd[0][0] = c0.x; cadd[0][1] = c0.y; cadd[0][2] = c0.z; cadd[0][3] = c0.w;
+        cadd[0][4] = c1.x; cadd[0][5] = c1.y; cadd[0][6] = c1.z; cadd[0][7] = c1.w;
       }
     }
     auto fin = [&](float a, float add) -> float {
@@ -183,10 +192,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       if (MODE == EPI_SCALE) v *= scale;
       return v;
     };
-    // residual mode: the x rows of pass i+1 are fetched while pass i is transposed and stored
-    auto x_ptr = [&](int i, int k) -> float * {
-      const int m = m0 + (wr * TM + i) * 16 + (lane >> 4) + 4 * k;
-      return reinterpret_cast<float *>(p.out) + (size_t)m * ldo + ncol0 + l15 * 4;
+    // residual mode: the x rows of pass pp+1 are fetched while pass pp is transposed and stored
+    auto x_ptr = [&](int pp, int k) -> float * {
+      const int m = m0 + (wr * TM + pp / H) * 16 + (lane >> 4) + 4 * k;
+      return reinterpret_cast<float *>(p.out) + (size_t)m * ldo + ncol0 + 64 * (pp % H) + l15 * 4;
     };
 #ifndef VTC_RESID_DEPTH
 #define VTC_RESID_DEPTH 2
@@ -201,7 +210,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       for (int a = 0; a < XD - 1; ++a)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (a < TM) xr[a][k] = *reinterpret_cast<const float4 *>(x_ptr(a, k));
+          if (a < NP) xr[a][k] = *reinterpret_cast<const float4 *>(x_ptr(a, k));
     }
     // distance mode: |q|^2 of the lane's rows and |g|^2 of its columns are fetched once, in the MFMA layout, and the
     // distance is formed BEFORE the transposition: a load inside the pass loop sits behind the previous pass's
@@ -212,15 +221,17 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       for (int i = 0; i < TM; ++i) rn[i] = p.epi.rown[m0 + (wr * TM + i) * 16 + l15];
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      if (MODE == VTC_EPI_RESID && i + XD - 1 < TM) {
+    for (int pp = 0; pp < NP; ++pp) {
+      const int i = pp / H, hh = pp % H;
+      const int ncolh = ncol0 + 64 * hh;
+      if (MODE == VTC_EPI_RESID && pp + XD - 1 < NP) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xr[(i + XD - 1) % XD][k] = *reinterpret_cast<const float4 *>(x_ptr(i + XD - 1, k));
+        for (int k = 0; k < 4; ++k) xr[(pp + XD - 1) % XD][k] = *reinterpret_cast<const float4 *>(x_ptr(pp + XD - 1, k));
       }
       // 1. registers -> LDS: final fp32 values in [16 rows][64 cols]
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float4 a4 = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      for (int j = 0; j < 4; ++j) {
+        float4 a4 = make_float4(acc[i][4 * hh + j][0], acc[i][4 * hh + j][1], acc[i][4 * hh + j][2], acc[i][4 * hh + j][3]);
         if (MODE == EPI_L2DIST)     // |q|^2 - 2 q.g here, + |g|^2 (a per-column addend like a bias) after the transposition
           a4 = make_float4(rn[i] - 2.0f * a4.x, rn[i] - 2.0f * a4.y, rn[i] - 2.0f * a4.z, rn[i] - 2.0f * a4.w);
         *reinterpret_cast<float4 *>(tr + l15 * TS + 16 * j + 4 * g) = a4;
@@ -236,7 +247,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
           const int r = (lane >> 4) + 4 * k, cc = l15 * 4;
           float4 v = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
           const int m = mrow0 + r;
-          v.x = fin(v.x, cadd[0]); v.y = fin(v.y, cadd[1]); v.z = fin(v.z, cadd[2]); v.w = fin(v.w, cadd[3]);
+          v.x = fin(v.x, cadd[hh][0]); v.y = fin(v.y, cadd[hh][1]); v.z = fin(v.z, cadd[hh][2]); v.w = fin(v.w, cadd[hh][3]);
           size_t orow = (size_t)m;
           bool live = true;
           if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && (m % p.epi.skip_mod) == 0) live = false;
@@ -245,18 +256,18 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
             const int tt = ft % p.epi.F, item = ft / p.epi.F;
             orow = p.epi.frames_major ? (size_t)item * p.epi.T + 1 + (size_t)tt * p.epi.P + np
                                       : (size_t)item * p.epi.T + 1 + (size_t)np * p.epi.F + tt;
-            const float4 p4 = *reinterpret_cast<const float4 *>(p.epi.pos + (size_t)(1 + np) * p.N + ncol0 + cc);
+            const float4 p4 = *reinterpret_cast<const float4 *>(p.epi.pos + (size_t)(1 + np) * p.N + ncolh + cc);
             v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
             if (p.epi.temporal) {
-              const float4 t4 = *reinterpret_cast<const float4 *>(p.epi.temporal + (size_t)tt * p.N + ncol0 + cc);
+              const float4 t4 = *reinterpret_cast<const float4 *>(p.epi.temporal + (size_t)tt * p.N + ncolh + cc);
               v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
             }
           }
-          float *o = reinterpret_cast<float *>(p.out) + orow * ldo + ncol0 + cc;
+          float *o = reinterpret_cast<float *>(p.out) + orow * ldo + ncolh + cc;
           if (MODE == VTC_EPI_RESID) {
             // skipped rows are written back unchanged (a select, not a branch: an exec-masked store makes hipcc
             // re-wait on the x prefetch after every store, which throttles the store stream)
-            const float4 x = xr[i % XD][k];
+            const float4 x = xr[pp % XD][k];
             store16<nt_out>(o, make_float4(live ? x.x + v.x : x.x, live ? x.y + v.y : x.y, live ? x.z + v.z : x.z,
                                            live ? x.w + v.w : x.w));
           } else {
@@ -269,8 +280,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
           const int r = (lane >> 3) + 8 * k, cc = (lane & 7) * 8;
           float4 v0 = *reinterpret_cast<const float4 *>(tr + r * TS + cc);
           float4 v1 = *reinterpret_cast<const float4 *>(tr + r * TS + cc + 4);
-          v0.x = fin(v0.x, cadd[0]); v0.y = fin(v0.y, cadd[1]); v0.z = fin(v0.z, cadd[2]); v0.w = fin(v0.w, cadd[3]);
-          v1.x = fin(v1.x, cadd[4]); v1.y = fin(v1.y, cadd[5]); v1.z = fin(v1.z, cadd[6]); v1.w = fin(v1.w, cadd[7]);
+          v0.x = fin(v0.x, cadd[0][0]); v0.y = fin(v0.y, cadd[0][1]); v0.z = fin(v0.z, cadd[0][2]); v0.w = fin(v0.w, cadd[0][3]);
+          v1.x = fin(v1.x, cadd[0][4]); v1.y = fin(v1.y, cadd[0][5]); v1.z = fin(v1.z, cadd[0][6]); v1.w = fin(v1.w, cadd[0][7]);
           uint4 pk;
           pk.x = (unsigned)f2bf(v0.x) | ((unsigned)f2bf(v0.y) << 16);
           pk.y = (unsigned)f2bf(v0.z) | ((unsigned)f2bf(v0.w) << 16);
@@ -816,6 +827,11 @@ int run_cfg(const GemmParams &p, hipStream_t stream) {
     if (g_force_tile == 1) big = false;
     if (g_force_tile == 2) big = true;
     if (g_force_tile == 4) big = true;
+#ifdef VTC_ROW_PANEL_PROBE   // feasibility probe: 128 x 512 row-panel tiles (a full text-tower row per workgroup)
+    if constexpr (MODE == VTC_EPI_RESID) {
+      if (g_force_tile == 6) return run<T, MODE, OutT, 2, 4, 4, 8, 2>(p, stream);
+    }
+#endif
     if (big && g_force_tile != 2) return run_phased<MODE, OutT>(p, stream);
     if (big) return run<T, MODE, OutT, 2, 4, 8, 4, 2>(p, stream);
   }

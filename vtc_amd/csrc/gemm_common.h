@@ -93,8 +93,14 @@ __device__ __forceinline__ void lgkm_wait(u32x4 &x) {
 }
 template <int N, int TN>
 __device__ __forceinline__ void lgkm_wait_frags(u32x4 &x, u32x4 (&w)[TN]) {
-  static_assert(TN == 4, "four weight fragments per wave");
-  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(x), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N));
+  static_assert(TN == 4 || TN == 8, "four or eight weight fragments per wave");
+  if constexpr (TN == 4) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(x), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N));
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(%9)"
+                 : "+v"(x), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7])
+                 : "n"(N));
+  }
 }
 
 // all twelve fragments of the phased kernel's register subtile (whatever subset was just re-read) have landed

@@ -235,166 +235,169 @@ def main():
 
     extra = {}
     if not args.no_extra:
-        # ---- config 2 again with the ragged text tower (tokens after EOT are not computed; identical
-        # outputs -- tests/test_gpu_towers.py::test_ragged_text_tower_equals_dense).  Reported apart from
-        # `value`, which does exactly the reference's work (all 77 positions of every sequence).
-        kr = max(2, args.steps // 2)
-        from vtc_amd import towers as _tw
-        _tw.TEXT_RAGGED = True
-        for _ in range(2):
-            step2()
-        barrier_sync(world)
-        t0 = time.perf_counter()
-        kr = max(2, args.steps // 2)
-        for _ in range(kr):
-            step2()
-        barrier_sync(world)
-        dtr = max_over_ranks(time.perf_counter() - t0, world, device)
-        _tw.TEXT_RAGGED = False
-        n_tok = int((torch.cat([title, comments.reshape(-1, 77)]).argmax(-1) + 1).sum().item())
-        extra["config2_ragged_text_pairs_per_s"] = round(world * B * kr / dtr, 1)
-        extra["config2_ragged_text_ms_per_step"] = round(1e3 * dtr / kr, 3)
-        extra["config2_ragged_text_tokens_computed_frac"] = round(n_tok / (6 * B * 77), 4)
-        # ---- config 3: 8-frame TimeSformer video + title + 5 comments ------------------------
-        del m2
-        torch.cuda.empty_cache()
-        m3 = HM.PretrainedCLIP_TimeSformer_finaltf(model_type="ViT-B/32", branch_to_adapt_val="text")
-        for blk in m3.model.visual.transformer.resblocks:       # trained temporal_fc is not zero
-            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
-        m3 = m3.eval().to(device)
-        m3.compute_dtype = cdt
-        B3 = min(B, 256)      # SURVEY 8d C3 at B = 256 (the config's own batch_size of 50 under-fills the chip)
-        vid = torch.randn(B3, 8, 3, 224, 224, generator=gen).to(device).to(cdt)
-        t3, c3 = title[:B3].contiguous(), comments[:B3].contiguous()
-        for _ in range(2):
-            m3(vid, t3, c3)
-        barrier_sync(world)
-        k3 = max(2, args.steps // 2)
-        t0 = time.perf_counter()
-        for _ in range(k3):
-            o3 = m3(vid, t3, c3)
-        barrier_sync(world)
-        dt3 = max_over_ranks(time.perf_counter() - t0, world, device)
-        extra["config3_timesformer_pairs_per_s"] = round(world * B3 * k3 / dt3, 1)
-        extra["config3_ms_per_step"] = round(1e3 * dt3 / k3, 2)
-        extra["config3_pairs_per_gpu"] = B3
-        m3.overlap_towers = False
-        p3 = prof_run(lambda: m3(vid, t3, c3), stream_ptr)
-        g3 = p3[gk]
-        extra["config3_gemm_tflops"] = round(g3["work"] / (g3["ms"] * 1e-3) / 1e12, 1)
-        extra["config3_kernel_ms"] = {k: round(v["ms"], 3) for k, v in p3.items() if v["launches"]}
-        adapter_sd = {k: v.detach().clone() for k, v in m3.state_dict().items()
-                      if k.startswith("final_transformer.") or k in ("mask_embedding", "model.logit_scale")}
-        del m3, vid
-        torch.cuda.empty_cache()
-        # ---- the stress config's encoder (BASELINE configs[4]): 16-frame TimeSformer + title + 5 comments ------
-        class _TSF16(HM.PretrainedCLIP_TimeSformer_finaltf):
-            nframes = 16
-        m16 = _TSF16(model_type="ViT-B/32", branch_to_adapt_val="text")
-        for blk in m16.model.visual.transformer.resblocks:
-            torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
-        m16 = m16.eval().to(device)
-        m16.compute_dtype = cdt
-        B16 = min(B, 128)
-        vid16 = torch.randn(B16, 16, 3, 224, 224, generator=gen).to(device).to(cdt)
-        t16, c16 = title[:B16].contiguous(), comments[:B16].contiguous()
-        for _ in range(2):
-            m16(vid16, t16, c16)
-        barrier_sync(world)
-        k16 = max(2, args.steps // 3)
-        t0 = time.perf_counter()
-        for _ in range(k16):
-            m16(vid16, t16, c16)
-        barrier_sync(world)
-        dt16 = max_over_ranks(time.perf_counter() - t0, world, device)
-        extra["stress_timesformer16_pairs_per_s"] = round(world * B16 * k16 / dt16, 1)
-        extra["stress_timesformer16_pairs_per_gpu"] = B16
-        del m16, vid16
-        torch.cuda.empty_cache()
-
-        # ---- adapter-only training step (configs/pretrained_clip_comments_attn_frozen.jsonc:
-        # batch 128, frozen towers, clip_loss, Adam amsgrad): forward + backward + update of the CAM on the HIP path
-        from vtc_amd.host.adapter_train import AdapterTrainer
-        trn = AdapterTrainer(adapter_sd)
-        Bt = 128
-        gt = torch.Generator().manual_seed(7)
-        tfv, tft = torch.randn(Bt, 512, generator=gt).to(device), torch.randn(Bt, 512, generator=gt).to(device)
-        tfc = torch.randn(5, Bt, 512, generator=gt).to(device)
-        temp = (torch.rand(Bt, 5, generator=gt) < 0.1).to(device)
-        tskip = (torch.rand(Bt, generator=gt) > 0.5).to(device)
-        for _ in range(3):
-            trn.step(tfv, tft, tfc, temp, tskip)
-        barrier_sync(world)
-        t0 = time.perf_counter()
-        kt = 20
-        for _ in range(kt):
-            tl = trn.step(tfv, tft, tfc, temp, tskip)
-        barrier_sync(world)
-        dtt = max_over_ranks(time.perf_counter() - t0, world, device)
-        extra["adapter_train_step_ms"] = round(1e3 * dtt / kt, 3)
-        extra["adapter_train_batch"] = Bt
-        extra["adapter_train_loss_after"] = round(float(tl), 4)
-        del trn
-
-        # ---- sweep: N x N sim + R@1/5/10 both directions, sharded by query rows ---------------
-        # N = 10k (BASELINE configs[3]) and the 50k stress size (configs[4]); embeddings drawn directly
-        # (SURVEY 8d), planted positives so that R@K < 1.
-        for N in [n for n in (args.sweep_n, args.stress_n) if n > 0]:
-            lo, hi = vdist.shard_bounds(N, rank, world)
-            g2 = torch.Generator().manual_seed(123)
-            va = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
-            noise = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
-            tb = torch.nn.functional.normalize(va + 4.0 * noise * torch.rand(N, 1, generator=g2), dim=-1)
-            va_l, tb_l = va[lo:hi].to(device), tb[lo:hi].to(device)
-            precs = [("exact", L.SWEEP_EXACT), ("f32", L.SWEEP_F32), ("bf16x3", L.SWEEP_BF16X3)] + ([("bf16", L.SWEEP_BF16)] if N == args.stress_n else [])
-            for prec_name, prec in precs:
-                # caller-owned workspace, as a serving loop would hold it (a fresh multi-GiB torch allocation per call
-                # can land on a hipMalloc / cache flush: seen as one 45 ms call in three)
-                lib = L.lib()
-                need = max(lib.vtc_l2_topk_workspace_bytes(N, hi - lo, 512, prec, 0), lib.vtc_l2_topk_workspace_bytes(N, N, 512, prec, 0) if world == 1 else 0,
-                           lib.vtc_l2_topk_bidir_workspace_bytes(N, N, 512, prec, 0) if world == 1 else 0)
-                sweep_ws = ops.workspace(need, device)
-                vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec, ws=sweep_ws)      # warm-up
-                barrier_sync(world)
-                t0 = time.perf_counter()
-                reps = 3
-                for _ in range(reps):
-                    r_ab, r_ba = vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec, ws=sweep_ws)
-                barrier_sync(world)
-                dts = max_over_ranks(time.perf_counter() - t0, world, device) / reps
-                del sweep_ws
-                extra[f"sweep_{N}_{prec_name}_ms"] = round(1e3 * dts, 3)
-                extra[f"sweep_{N}_{prec_name}_recall"] = {"t_from_v": r_ab, "v_from_t": r_ba}
-                one_matrix = world == 1 and N >= (vdist.BIDIR_MIN_ROWS_F32 if prec == L.SWEEP_F32 else vdist.BIDIR_MIN_ROWS)
-                extra[f"sweep_{N}_{prec_name}_path"] = "one distance matrix, row + column top-k" if one_matrix else "two searches"
-                # algorithmic HBM bytes, materialised fp32 matrix: 8 N^2 per direction, whole job
-                extra[f"sweep_{N}_{prec_name}_algorithmic_GBps"] = round(2 * 8.0 * N * N / dts / 1e9, 1)
-            del va, noise, tb, va_l, tb_l
+        try:   # the extras never cost the main line: an exception is recorded in extra["error"]
+            # ---- config 2 again with the ragged text tower (tokens after EOT are not computed; identical
+            # outputs -- tests/test_gpu_towers.py::test_ragged_text_tower_equals_dense).  Reported apart from
+            # `value`, which does exactly the reference's work (all 77 positions of every sequence).
+            kr = max(2, args.steps // 2)
+            from vtc_amd import towers as _tw
+            _tw.TEXT_RAGGED = True
+            for _ in range(2):
+                step2()
+            barrier_sync(world)
+            t0 = time.perf_counter()
+            kr = max(2, args.steps // 2)
+            for _ in range(kr):
+                step2()
+            barrier_sync(world)
+            dtr = max_over_ranks(time.perf_counter() - t0, world, device)
+            _tw.TEXT_RAGGED = False
+            n_tok = int((torch.cat([title, comments.reshape(-1, 77)]).argmax(-1) + 1).sum().item())
+            extra["config2_ragged_text_pairs_per_s"] = round(world * B * kr / dtr, 1)
+            extra["config2_ragged_text_ms_per_step"] = round(1e3 * dtr / kr, 3)
+            extra["config2_ragged_text_tokens_computed_frac"] = round(n_tok / (6 * B * 77), 4)
+            # ---- config 3: 8-frame TimeSformer video + title + 5 comments ------------------------
+            del m2
             torch.cuda.empty_cache()
-        if args.hipgraph:
-            # opt-in and last: in this ROCm build everything that ran after a capture was 1.5-6x slower
-            try:
-                m2g = HM.PretrainedCLIP_finaltf(model_type="ViT-B/32", branch_to_adapt_val="text").eval().to(device)
-                m2g.compute_dtype = cdt
-                visg = torch.randn(B, 3, 224, 224, generator=gen).to(device).to(cdt)
-                m2g(visg, title, comments)
-                gstream = torch.cuda.Stream()
-                gstream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(gstream):
+            m3 = HM.PretrainedCLIP_TimeSformer_finaltf(model_type="ViT-B/32", branch_to_adapt_val="text")
+            for blk in m3.model.visual.transformer.resblocks:       # trained temporal_fc is not zero
+                torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+            m3 = m3.eval().to(device)
+            m3.compute_dtype = cdt
+            B3 = min(B, 256)      # SURVEY 8d C3 at B = 256 (the config's own batch_size of 50 under-fills the chip)
+            vid = torch.randn(B3, 8, 3, 224, 224, generator=gen).to(device).to(cdt)
+            t3, c3 = title[:B3].contiguous(), comments[:B3].contiguous()
+            for _ in range(2):
+                m3(vid, t3, c3)
+            barrier_sync(world)
+            k3 = max(2, args.steps // 2)
+            t0 = time.perf_counter()
+            for _ in range(k3):
+                o3 = m3(vid, t3, c3)
+            barrier_sync(world)
+            dt3 = max_over_ranks(time.perf_counter() - t0, world, device)
+            extra["config3_timesformer_pairs_per_s"] = round(world * B3 * k3 / dt3, 1)
+            extra["config3_ms_per_step"] = round(1e3 * dt3 / k3, 2)
+            extra["config3_pairs_per_gpu"] = B3
+            m3.overlap_towers = False
+            p3 = prof_run(lambda: m3(vid, t3, c3), stream_ptr)
+            g3 = p3[gk]
+            extra["config3_gemm_tflops"] = round(g3["work"] / (g3["ms"] * 1e-3) / 1e12, 1)
+            extra["config3_kernel_ms"] = {k: round(v["ms"], 3) for k, v in p3.items() if v["launches"]}
+            adapter_sd = {k: v.detach().clone() for k, v in m3.state_dict().items()
+                          if k.startswith("final_transformer.") or k in ("mask_embedding", "model.logit_scale")}
+            del m3, vid
+            torch.cuda.empty_cache()
+            # ---- the stress config's encoder (BASELINE configs[4]): 16-frame TimeSformer + title + 5 comments ------
+            class _TSF16(HM.PretrainedCLIP_TimeSformer_finaltf):
+                nframes = 16
+            m16 = _TSF16(model_type="ViT-B/32", branch_to_adapt_val="text")
+            for blk in m16.model.visual.transformer.resblocks:
+                torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+            m16 = m16.eval().to(device)
+            m16.compute_dtype = cdt
+            B16 = min(B, 128)
+            vid16 = torch.randn(B16, 16, 3, 224, 224, generator=gen).to(device).to(cdt)
+            t16, c16 = title[:B16].contiguous(), comments[:B16].contiguous()
+            for _ in range(2):
+                m16(vid16, t16, c16)
+            barrier_sync(world)
+            k16 = max(2, args.steps // 3)
+            t0 = time.perf_counter()
+            for _ in range(k16):
+                m16(vid16, t16, c16)
+            barrier_sync(world)
+            dt16 = max_over_ranks(time.perf_counter() - t0, world, device)
+            extra["stress_timesformer16_pairs_per_s"] = round(world * B16 * k16 / dt16, 1)
+            extra["stress_timesformer16_pairs_per_gpu"] = B16
+            del m16, vid16
+            torch.cuda.empty_cache()
+
+            # ---- adapter-only training step (configs/pretrained_clip_comments_attn_frozen.jsonc:
+            # batch 128, frozen towers, clip_loss, Adam amsgrad): forward + backward + update of the CAM on the HIP path
+            from vtc_amd.host.adapter_train import AdapterTrainer
+            trn = AdapterTrainer(adapter_sd)
+            Bt = 128
+            gt = torch.Generator().manual_seed(7)
+            tfv, tft = torch.randn(Bt, 512, generator=gt).to(device), torch.randn(Bt, 512, generator=gt).to(device)
+            tfc = torch.randn(5, Bt, 512, generator=gt).to(device)
+            temp = (torch.rand(Bt, 5, generator=gt) < 0.1).to(device)
+            tskip = (torch.rand(Bt, generator=gt) > 0.5).to(device)
+            for _ in range(3):
+                trn.step(tfv, tft, tfc, temp, tskip)
+            barrier_sync(world)
+            t0 = time.perf_counter()
+            kt = 20
+            for _ in range(kt):
+                tl = trn.step(tfv, tft, tfc, temp, tskip)
+            barrier_sync(world)
+            dtt = max_over_ranks(time.perf_counter() - t0, world, device)
+            extra["adapter_train_step_ms"] = round(1e3 * dtt / kt, 3)
+            extra["adapter_train_batch"] = Bt
+            extra["adapter_train_loss_after"] = round(float(tl), 4)
+            del trn
+
+            # ---- sweep: N x N sim + R@1/5/10 both directions, sharded by query rows ---------------
+            # N = 10k (BASELINE configs[3]) and the 50k stress size (configs[4]); embeddings drawn directly
+            # (SURVEY 8d), planted positives so that R@K < 1.
+            for N in [n for n in (args.sweep_n, args.stress_n) if n > 0]:
+                lo, hi = vdist.shard_bounds(N, rank, world)
+                g2 = torch.Generator().manual_seed(123)
+                va = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
+                noise = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
+                tb = torch.nn.functional.normalize(va + 4.0 * noise * torch.rand(N, 1, generator=g2), dim=-1)
+                va_l, tb_l = va[lo:hi].to(device), tb[lo:hi].to(device)
+                precs = [("exact", L.SWEEP_EXACT), ("f32", L.SWEEP_F32), ("bf16x3", L.SWEEP_BF16X3)] + ([("bf16", L.SWEEP_BF16)] if N == args.stress_n else [])
+                for prec_name, prec in precs:
+                    # caller-owned workspace, as a serving loop would hold it (a fresh multi-GiB torch allocation per call
+                    # can land on a hipMalloc / cache flush: seen as one 45 ms call in three)
+                    lib = L.lib()
+                    need = max(lib.vtc_l2_topk_workspace_bytes(N, hi - lo, 512, prec, 0), lib.vtc_l2_topk_workspace_bytes(N, N, 512, prec, 0) if world == 1 else 0,
+                               lib.vtc_l2_topk_bidir_workspace_bytes(N, N, 512, prec, 0) if world == 1 else 0)
+                    sweep_ws = ops.workspace(need, device)
+                    vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec, ws=sweep_ws)      # warm-up
+                    barrier_sync(world)
+                    t0 = time.perf_counter()
+                    reps = 3
+                    for _ in range(reps):
+                        r_ab, r_ba = vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec, ws=sweep_ws)
+                    barrier_sync(world)
+                    dts = max_over_ranks(time.perf_counter() - t0, world, device) / reps
+                    del sweep_ws
+                    extra[f"sweep_{N}_{prec_name}_ms"] = round(1e3 * dts, 3)
+                    extra[f"sweep_{N}_{prec_name}_recall"] = {"t_from_v": r_ab, "v_from_t": r_ba}
+                    one_matrix = world == 1 and N >= (vdist.BIDIR_MIN_ROWS_F32 if prec == L.SWEEP_F32 else vdist.BIDIR_MIN_ROWS)
+                    extra[f"sweep_{N}_{prec_name}_path"] = "one distance matrix, row + column top-k" if one_matrix else "two searches"
+                    # algorithmic HBM bytes, materialised fp32 matrix: 8 N^2 per direction, whole job
+                    extra[f"sweep_{N}_{prec_name}_algorithmic_GBps"] = round(2 * 8.0 * N * N / dts / 1e9, 1)
+                del va, noise, tb, va_l, tb_l
+                torch.cuda.empty_cache()
+            if args.hipgraph:
+                # opt-in and last: in this ROCm build everything that ran after a capture was 1.5-6x slower
+                try:
+                    m2g = HM.PretrainedCLIP_finaltf(model_type="ViT-B/32", branch_to_adapt_val="text").eval().to(device)
+                    m2g.compute_dtype = cdt
+                    visg = torch.randn(B, 3, 224, 224, generator=gen).to(device).to(cdt)
                     m2g(visg, title, comments)
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph, stream=gstream):
-                        gout = m2g(visg, title, comments)
-                torch.cuda.current_stream().wait_stream(gstream)
-                graph.replay()
-                barrier_sync(world)
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
+                    gstream = torch.cuda.Stream()
+                    gstream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(gstream):
+                        m2g(visg, title, comments)
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph, stream=gstream):
+                            gout = m2g(visg, title, comments)
+                    torch.cuda.current_stream().wait_stream(gstream)
                     graph.replay()
-                barrier_sync(world)
-                extra["config2_ms_per_step_hipgraph"] = round(1e3 * max_over_ranks(time.perf_counter() - t0, world, device) / args.steps, 3)
-            except Exception as e:
-                extra["config2_hipgraph_error"] = repr(e)[:200]
+                    barrier_sync(world)
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        graph.replay()
+                    barrier_sync(world)
+                    extra["config2_ms_per_step_hipgraph"] = round(1e3 * max_over_ranks(time.perf_counter() - t0, world, device) / args.steps, 3)
+                except Exception as e:
+                    extra["config2_hipgraph_error"] = repr(e)[:200]
+        except Exception as e:   # noqa: BLE001
+            extra["error"] = repr(e)[:300]
         result["extra"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu:

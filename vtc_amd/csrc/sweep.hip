@@ -143,7 +143,23 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float *__restrict__
 #pragma unroll
         for (int q = 1; q < 16; ++q) vm = q == qm ? cur[q] : vm;
         const int im = base + 256 * (qm >> 2) + lane * 4 + (qm & 3);
-        wl.offer(vm, im, im < c_hi, lane, depth);
+        if (base + 1024 <= c_hi) {
+          // a full first step: the 64 lane minima ARE the initial list, sorted by rank counting + one forward
+          // permute (as col_topk_kernel) instead of 64 serial insertions
+          int rank = 0;
+#pragma unroll 4
+          for (int l = 0; l < 64; ++l) {
+            const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vm), l));
+            const int oi = __builtin_amdgcn_readlane(im, l);
+            rank += (ov < vm || (ov == vm && oi < im)) ? 1 : 0;
+          }
+          wl.bd = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(rank << 2, __builtin_bit_cast(int, vm)));
+          wl.bi = __builtin_amdgcn_ds_permute(rank << 2, im);
+          wl.tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl.bd), depth - 1));
+          wl.tau_i = __builtin_amdgcn_readlane(wl.bi, depth - 1);
+        } else {
+          wl.offer(vm, im, im < c_hi, lane, depth);
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int idx = base + 256 * (q >> 2) + lane * 4 + (q & 3);

@@ -1,5 +1,5 @@
 """Random-shape parity probe: the four wrappers on the HIP path vs the live oracle (TINY architecture), odd batch sizes,
-1..7 comments per item, all-empty / no-empty comments, fp32 and bf16.  usage: python tools/fuzz_wrappers.py [n_cases]"""
+1..7 comments per item, all-empty / no-empty comments, fp32 and bf16.  usage: python tests/fuzz_wrappers.py [n_cases]   (test infrastructure: it runs the oracle, so it lives under tests/)"""
 import os
 import sys
 from dataclasses import asdict

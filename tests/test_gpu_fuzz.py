@@ -1,12 +1,12 @@
 """Odd shapes through the four wrappers on the HIP path vs the live oracle: batch sizes 1..33, 1..7 comments per item,
-all-empty / no-empty comments, every residual activation, fp32 and bf16 (tools/fuzz_wrappers.py, two fixed seeds)."""
+all-empty / no-empty comments, every residual activation, fp32 and bf16 (tests/fuzz_wrappers.py, two fixed seeds)."""
 import os
 import sys
 
 import pytest
 
 pytestmark = pytest.mark.gpu
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("seed", [0, 7])

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-enum { VTC_F32 = 0, VTC_BF16 = 1, VTC_U8 = 2 /* pixel_dtype only: raw 0..255 pixels */ };
+enum { VTC_F32 = 0, VTC_BF16 = 1, VTC_U8 = 2 /* pixel_dtype only: raw 0..255 pixels */,
+       VTC_F16 = 3 /* IEEE half operands, fp32 accumulate: vtc_gemm / vtc_layernorm / vtc_attention and the text tower */ };
 
 /* residual activations of the CAM, model/model.py:65-77 (stateless ones) */
 enum { VTC_ACT_NONE = 0, VTC_ACT_NORMALIZE = 1, VTC_ACT_SQUASH = 2, VTC_ACT_TANH = 3,
@@ -80,6 +81,9 @@ typedef struct {
 /* Text tower: upstream CLIP.encode_text. */
 typedef struct {
   int width, heads, layers, ctx, vocab, embed_dim;
+  int half_layers;                /* dtype VTC_BF16 only: blocks [0, half_layers) hold IEEE-half (VTC_F16) weight matrices and
+                                     run with half operands, the others bf16 (the bf16 rounding floor of
+                                     this tower is above the 1e-3 budget; half has 3 more significant bits at the same rate) */
   const float *tok_emb;           /* token_embedding.weight [vocab, W] fp32               */
   const float *pos;               /* positional_embedding [ctx, W]                        */
   const float *ln_final_g, *ln_final_b;
@@ -221,8 +225,14 @@ int vtc_scale_rows(float *x, const float *s, int rows, int d, int group, void *s
  * attention; bytes moved for the others).  Process-global, single-threaded use only. */
 enum { VTC_PROF_GEMM_BF16 = 0, VTC_PROF_GEMM_F32 = 1, VTC_PROF_ATTN = 2, VTC_PROF_NORM = 3, VTC_PROF_EMBED = 4,
        VTC_PROF_TOPK = 5, VTC_PROF_NCLASS = 6 };
+/* Launches also carry the region of the tower they belong to (per thread): the attention branches (LayerNorm + QKV
+ * projection + attention core + output projection [+ temporal_fc] + cls bookkeeping -- what BASELINE.md calls
+ * "TimeSformer attention" for the video tower), the MLP branches, everything else. */
+enum { VTC_PROF_REGION_OTHER = 0, VTC_PROF_REGION_ATTN = 1, VTC_PROF_REGION_MLP = 2, VTC_PROF_NREGION = 3 };
 int vtc_prof_begin(void);
 int vtc_prof_end(void *stream, double *ms, long long *launches, double *work);
+/* as vtc_prof_end, split by region: arrays of VTC_PROF_NCLASS * VTC_PROF_NREGION, index cls * VTC_PROF_NREGION + region */
+int vtc_prof_end_regions(void *stream, double *ms, long long *launches, double *work);
 
 #ifdef __cplusplus
 }

@@ -56,9 +56,8 @@ def run_cases(n_cases, seed=0, verbose=True):
         out = m(*[x.cuda() for x in args])
         scale = float(np.exp(sd["model.logit_scale"].item()))
         errs = [float((o.cpu() - r).abs().max()) for o, r in zip(out[:2], ref[:2])] + [float((out[2].cpu() - ref[2]).abs().max()) / scale]
-        # bf16 on TINY (128-d, elements 2x larger): the text-tower max floor is ~3e-3 (tests/test_gpu_towers.py);
-        # this probe looks for gross shape-dependent errors
-        tol = 1e-5 if dtype == torch.float32 else 5e-3
+        # BASELINE.json: 1e-5 (fp32) / 1e-3 (bf16) on 512-d unit-norm embeddings; TINY's 128-d elements are 2x larger
+        tol = 1e-5 if dtype == torch.float32 else 1e-3 * (512 / a.embed_dim) ** 0.5
         ok = max(errs) < tol
         key = str(dtype)
         worst[key] = max(worst.get(key, 0.0), max(errs))

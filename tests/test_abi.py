@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     declared -= {"vtc_block_w", "vtc_vision_w", "vtc_text_w", "vtc_cam_w"}
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     lib = L.lib()                       # raises if the .so or any symbol is missing
-    assert lib.vtc_abi_version() == 2
+    assert lib.vtc_abi_version() == 3
     for name in declared:
         assert hasattr(lib, name)
 
@@ -70,15 +70,87 @@ def test_cam_init_from_avg_zeroing():
     assert m.final_linear.weight.abs().sum() == 0                  # :452
 
 
+BASELINE_CONFIGS = ["pretrained_clip.jsonc", "pretrained_clip_comments_attention.jsonc",
+                    "pretrained_clip_timesformer_comments_attention.jsonc"]
+
+
+def _config_paths(sub=""):
+    d = os.path.join(ROOT, "configs", sub)
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".jsonc"))
+
+
 def test_reference_configs_load(tmp_path):
     from vtc_amd.host.parse_config import ConfigParser, read_jsonc
-    ref = "/root/reference/configs"
-    paths = [os.path.join(ROOT, "configs", f) for f in os.listdir(os.path.join(ROOT, "configs"))]
-    if os.path.isdir(ref):
-        paths += [os.path.join(ref, f) for f in os.listdir(ref) if f.endswith(".jsonc")]
-    assert paths
+    paths = _config_paths() + _config_paths("synthetic")
+    assert len(paths) >= 7
     for p in paths:
         cfg = read_jsonc(p)
         assert "arch" in cfg and "type" in cfg["arch"]
     c = ConfigParser.from_file(paths[0], modification={"arch;args;branch_to_adapt_val": "skip", "batch_size": 7})
     assert c["batch_size"] == 7
+
+
+def test_shipped_configs_are_the_references_own_files():
+    """configs/*.jsonc are the reference's files byte for byte (checked where the reference checkout exists)."""
+    ref = "/root/reference/configs"
+    if not os.path.isdir(ref):
+        pytest.skip("reference checkout not present on this box")
+    names = sorted(f for f in os.listdir(ref) if f.endswith(".jsonc"))
+    assert set(BASELINE_CONFIGS) <= set(names)
+    for f in names:
+        assert open(os.path.join(ref, f), "rb").read() == open(os.path.join(ROOT, "configs", f), "rb").read(), f
+
+
+@pytest.mark.parametrize("name", BASELINE_CONFIGS + ["pretrained_clip_comments_attn_frozen.jsonc",
+                                                     "pretrained_clip_avg_comments.jsonc",
+                                                     "pretrained_clip_1frame_comments_attention.jsonc"])
+def test_unmodified_reference_configs_resolve_dataset_and_arch(name):
+    """evaluation/eval.py:58,88 on the reference's unmodified configs: ``init_obj("dataset", module_data, train=False,
+    test=True)`` resolves ImTextDataset / VideoDatasetSegments (empty csv_file -> synthetic pairs with the reference's
+    tensor contract) and ``arch.type`` names a class of the drop-in ``model.model`` whose ctor takes ``arch.args``."""
+    import inspect as _inspect
+
+    import model.model as module_arch
+    from vtc_amd.host import datasets as module_data
+    from vtc_amd.host.parse_config import ConfigParser
+    cfg = ConfigParser.from_file(os.path.join(ROOT, "configs", name), modification={"dataset;args;n_pairs": 5})
+    for train, test in ((False, True), (True, False), (False, False)):
+        ds = cfg.init_obj("dataset", module_data, train=train, test=test)
+        assert len(ds) == 5
+        vis, title, comments, meta = ds[3]
+        video = cfg["dataset"]["type"] == "VideoDatasetSegments" and not cfg["dataset"]["args"].get("first_frame_only")
+        assert tuple(vis.shape) == ((8, 3, 224, 224) if video else (3, 224, 224)) and vis.dtype == torch.float32
+        assert tuple(title.shape) == (77,) and title.dtype == torch.int64 and title[0] == 49406 and title.max() == 49407
+        add = {"always": True, "train_only": train, "never": False}[cfg["dataset"]["args"]["add_comments"]]
+        nc = int(cfg["dataset"]["args"].get("num_comms", 0)) if add else 0
+        assert tuple(comments.shape) == (max(nc, 1), 77) and comments.dtype == torch.int64
+        if nc == 0:                                       # _tokenise([""]): one empty comment
+            assert comments[0, 0] == 49406 and comments[0, 1] == 49407 and comments[0, 2:].sum() == 0
+        assert set(meta) == {"id"}
+    cls = getattr(module_arch, cfg["arch"]["type"])
+    params = _inspect.signature(cls.__init__).parameters
+    assert all(k in params for k in cfg["arch"]["args"]), (name, cfg["arch"]["args"])
+
+
+def test_real_csv_is_refused_not_faked():
+    from vtc_amd.host import datasets as module_data
+    with pytest.raises(NotImplementedError):
+        module_data.ImTextDataset(csv_file="posts.csv", root="/data")
+
+
+def test_timesformer_modules_export_the_tower_class():
+    """model.timesformer_clip{,_alt}: VisualTransformer with the reference's ctor signature
+    (model/timesformer_clip_alt.py:203-213) and a real forward (raises off-GPU instead of falling back)."""
+    import model.timesformer_clip as v1
+    import model.timesformer_clip_alt as alt
+    for mod in (alt, v1):
+        got = list(inspect.signature(mod.VisualTransformer.__init__).parameters)[1:]
+        assert got == ["input_resolution", "patch_size", "width", "layers", "heads", "output_dim", "nframes"]
+        t = mod.VisualTransformer(64, 16, 128, 2, 2, 64, 4).eval()
+        assert t.temporal_embed.shape == (4, 128)
+        with pytest.raises(RuntimeError, match="GPU"):
+            t(torch.zeros(1, 4, 3, 64, 64))
+    keys = set(alt.VisualTransformer(64, 16, 128, 1, 2, 64, 4).state_dict())
+    assert {"transformer.resblocks.0.temporal_fc.weight", "transformer.resblocks.0.timeattn.in_proj_weight",
+            "transformer.resblocks.0.ln_time.weight", "temporal_embed", "proj", "conv1.weight"} <= keys
+    assert not any("temporal_fc" in k for k in v1.VisualTransformer(64, 16, 128, 1, 2, 64, 4).state_dict())

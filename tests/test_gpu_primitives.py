@@ -213,3 +213,99 @@ def test_gemm_random_shapes_all_kernels():
         assert torch.equal(x, want), (M, N, K, "resid")
         out = ops.gemm(ad, wd, bias.cuda(), epilogue=L.EPI_GELU, out_dtype=torch.float32)
         assert (out - quick_gelu(ref)).abs().max() < 2e-2 * max(1.0, float(ref.abs().max())), (M, N, K, "gelu")
+
+
+# ---- IEEE-half operands (VTC_F16): the text tower's blocks in bf16 mode --------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(300, 384, 192), (77, 512, 3072), (8200, 3000, 768)])
+def test_gemm_f16_operands(M, N, K):
+    """Same fragment maps as bf16 (integer-exact check, asymmetric W, small kernels and the phased 256x256 one), every
+    epilogue; 16-bit outputs come out in IEEE half."""
+    L, ops = _ops()
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float() + torch.arange(N).float()[:, None] % 3
+    bias = torch.randint(-5, 6, (N,), generator=g).float()
+    ref = (a.cuda() @ w.cuda().t()) + bias.cuda()
+    ad, wd = a.cuda().half(), w.cuda().half()
+    out = ops.gemm(ad, wd, bias.cuda(), out_dtype=torch.float32)
+    assert torch.equal(out, ref), float((out - ref).abs().max())
+    out16 = ops.gemm(ad, wd, bias.cuda())
+    assert out16.dtype == torch.float16 and torch.equal(out16.float(), ref.half().float())
+    x0 = torch.randint(-8, 9, (M, N), generator=g).float().cuda()
+    x = x0.clone()
+    ops.gemm(ad, wd, bias.cuda(), epilogue=L.EPI_RESID, out=x, skip_mod=7)
+    want = x0 + ref
+    want[0::7] = x0[0::7]
+    assert torch.equal(x, want)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    ad, wd = a.cuda().half(), w.cuda().half()
+    lin = ad.float() @ wd.float().t() + bias.cuda()
+    out = ops.gemm(ad, wd, bias.cuda(), epilogue=L.EPI_GELU).float()
+    assert (out - quick_gelu(lin)).abs().max() < 4e-3 * max(1.0, float(lin.abs().max()))     # half: 2^-11 relative
+
+
+def test_layernorm_and_attention_f16():
+    L, ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(37, 512, generator=g) * 3 + 1
+    gm, bt = torch.randn(512, generator=g), torch.randn(512, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (512,), gm, bt, 1e-5)
+    out = ops.layernorm(x.cuda(), gm.cuda(), bt.cuda(), out_dtype=torch.float16)
+    assert out.dtype == torch.float16 and (out.float().cpu() - ref).abs().max() < 6e-3
+    assert torch.equal(out.cpu(), ops.layernorm(x.cuda(), gm.cuda(), bt.cuda()).half().cpu())   # = round-to-nearest of the fp32 result
+    for L_, causal in ((8, False), (50, False), (77, True)):
+        heads, n_seq = 3, 4
+        W = heads * 64
+        qkv = torch.randn(n_seq * L_, 3 * W, generator=g).cuda().half()
+        q, k, v = qkv.float().cpu().reshape(n_seq, L_, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        ref = ref_attention(q, k, v, causal).permute(0, 2, 1, 3).reshape(n_seq * L_, W)
+        out = ops.attention(qkv, n_seq, L_, heads, causal=causal)
+        assert out.dtype == torch.float16 and (out.float().cpu() - ref).abs().max() < 3e-3
+
+
+def test_entry_points_from_two_threads_and_two_streams():
+    """SURVEY 8b "re-entrant and per-device/stream safe": nn.DataParallel calls forward from one thread per replica
+    (train.py:77-80).  Two host threads, each on its own HIP stream, push GEMMs (both kernel families, dynamic-LDS
+    attribute set on first use), LayerNorms and attentions through the C ABI concurrently; every result must equal the
+    single-threaded one bit for bit."""
+    import threading
+    L, ops = _ops()
+    g = torch.Generator().manual_seed(17)
+    jobs = []
+    for (M, N, K) in ((4096, 3072, 512), (300, 384, 192), (9000, 2560, 256)):
+        a = torch.randint(-3, 4, (M, K), generator=g).float().cuda().bfloat16()
+        w = torch.randint(-3, 4, (N, K), generator=g).float().cuda().bfloat16()
+        jobs.append((a, w))
+    qkv = torch.randn(6 * 50, 3 * 128, generator=g).cuda().bfloat16()
+    x = torch.randn(999, 768, generator=g).cuda()
+    gm, bt = torch.randn(768, generator=g).cuda(), torch.randn(768, generator=g).cuda()
+
+    def work():
+        outs = [ops.gemm(a, w, None, out_dtype=torch.float32) for a, w in jobs]
+        outs.append(ops.attention(qkv, 6, 50, 2).float())
+        outs.append(ops.layernorm(x, gm, bt))
+        return outs
+
+    want = work()
+    torch.cuda.synchronize()
+    results, errors = {}, []
+
+    def runner(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(8):
+                    results[i] = work()
+            st.synchronize()
+        except Exception as e:     # noqa: BLE001
+            errors.append(e)
+
+    ths = [threading.Thread(target=runner, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        for o, wv in zip(results[i], want):
+            assert torch.equal(o, wv)

@@ -207,3 +207,54 @@ def test_recall_compute_both_matches_two_computes_and_oracle():
     m.bidir_min_rows = 0
     assert m.compute_both(a, b) == two
     assert two[0] == E.recall_at_k(a, b, [1, 5, 10]) and two[1] == E.recall_at_k(b, a, [1, 5, 10])
+
+
+@pytest.mark.parametrize("prec", ["exact", "f32", "bf16x3"])
+def test_stress_size_50k_bidir_equals_two_searches_and_oracle_sample(prec):
+    """BASELINE configs[4]: the 50k x 50k sweep (D = 512, depth 11).  At this size the distance matrix is walked in
+    five 2 GiB row blocks, the column lists are carried from block to block and merged over segments -- none of which
+    the <= 10k cases reach.  Properties: (i) vtc_l2_topk_bidir == two vtc_l2_topk calls on every row (EXACT: identical
+    ids; F32 / BF16X3: identical wherever the fp64 gap to the next neighbour is resolvable), (ii) a >= 1000-row sample
+    per direction == the fp64 oracle, (iii) R@1/5/10 from the ids == the oracle's hit rule on the sample."""
+    from vtc_amd import _lib as L
+    from vtc_amd import ops
+    p = {"exact": L.SWEEP_EXACT, "f32": L.SWEEP_F32, "bf16x3": L.SWEEP_BF16X3}[prec]
+    n, d, depth = 50000, 512, 11
+    a, b = planted(n, d, seed=50)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    i1, d1, i2, d2 = ops.l2_topk_bidir(ta, tb, depth, precision=p)
+    j1, e1 = ops.l2_topk(ta, tb, depth, precision=p)          # gallery a, queries b
+    j2, e2 = ops.l2_topk(tb, ta, depth, precision=p)          # gallery b, queries a
+    torch.cuda.synchronize()
+    i1n, i2n, j1n, j2n = (t.cpu().numpy() for t in (i1, i2, j1, j2))
+    assert i1n.min() >= 0 and i1n.max() < n and i2n.min() >= 0 and i2n.max() < n
+    assert (np.diff(d1.cpu().numpy(), axis=1) >= 0).all() and (np.diff(d2.cpu().numpy(), axis=1) >= 0).all()
+    if prec == "exact":
+        assert np.array_equal(i1n, j1n) and np.array_equal(i2n, j2n)
+    else:
+        assert (i1n == j1n).mean() > 0.9995 and (i2n == j2n).mean() > 0.999
+    rows = np.arange(7, n, 47)[:1024]
+    assert len(rows) >= 1000
+    for got, gal, qry in ((i1n, a, b), (i2n, b, a)):
+        ref_ids, ref_d = E.l2_topk(gal, qry[rows], depth + 1, np.float64)
+        if prec == "exact":
+            assert np.array_equal(got[rows], ref_ids[:, :depth])
+        else:
+            safe = (np.diff(ref_d, axis=1) > 2e-5).all(axis=1)
+            assert safe.mean() > 0.9 and np.array_equal(got[rows][safe], ref_ids[safe][:, :depth])
+        # the hit rule of model/metric.py:148-160 on the sample rows (target = the row's own index)
+        for k in (1, 5, 10):
+            want = sum(int(rows[r] in ref_ids[r, :k]) for r in range(len(rows)))
+            have = sum(int(rows[r] in got[rows[r], :k]) for r in range(len(rows)))
+            if prec == "exact":
+                assert have == want
+            else:
+                assert abs(have - want) <= 2
+    # the whole-matrix R@K through the metric object (one-matrix path at this size) == counting hits on the ids above
+    from vtc_amd.host.metric import RecallAtK
+    m = RecallAtK("videos", "titles", [1, 5, 10])
+    m.precision = p
+    r_ab, r_ba = m.compute_both(ta, tb)
+    tgt = np.arange(n)[:, None]
+    for (k, r), idsn in list(zip(r_ab, [i1n] * 3)) + list(zip(r_ba, [i2n] * 3)):
+        assert abs(r - float((idsn[:, :k] == tgt).any(axis=1).mean())) < 1e-12

@@ -45,16 +45,15 @@ def report(name, err, tol):
 
 
 def report_text(name, got, want, dtype, embed_dim):
-    """Text-tower features.  fp32: 1e-5 max.  bf16: the operand-rounding floor of bf16 x bf16 MFMA
-    on this tower is rms 3.2e-4 / max ~1.1e-3 (tests/bf16_floor_study.py, a CPU simulation that
-    involves no kernel), so the bf16 criterion is rms <= 4e-4 and max <= 1.5e-3 (x sqrt(512/D))."""
+    """Text-tower features: BASELINE.json's tolerance, 1e-5 (fp32) / 1e-3 (bf16 mode) max abs on the unit-norm
+    embedding (x sqrt(512 / D) for the 128-d TINY architecture).  An all-bf16 text tower sits at rms 3.2e-4 / max
+    1.1-1.4e-3 (tests/bf16_floor_study.py: the operand-rounding floor, no kernel involved), so in bf16 mode the text
+    blocks run with IEEE-half operands (vtc_amd.towers.TEXT_HALF_LAYERS) -- same rate, 3 more significant bits."""
     d = np.abs(got - want)
-    if dtype == torch.float32:
-        return report(name, d.max(), 1e-5)
-    k = (512 / embed_dim) ** 0.5
+    tol = tol_for(dtype, embed_dim)
     rms = float(np.sqrt((d ** 2).mean()))
-    print(f"[parity] {name}: max abs err {d.max():.3e} rms {rms:.3e} (bf16 floor criterion: max 1.5e-3, rms 4e-4, x{k:.1f})")
-    assert d.max() < 1.5e-3 * k and rms < 4e-4 * k, f"{name}: max {d.max()} rms {rms}"
+    print(f"[parity] {name}: max abs err {d.max():.3e} rms {rms:.3e} (tol {tol:.1e})")
+    assert d.max() < tol, f"{name}: max {d.max()} rms {rms} >= {tol}"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -70,7 +69,7 @@ def test_timesformer_tower_vs_golden(fname, dtype):
         out = pv.forward(x.cuda()).cpu().numpy()
         # compare as the wrappers consume it: L2-normalised embedding (model.py:501)
         report(f"{fname} {dtype} fuse={fuse}", np.abs(unit(out) - unit(g["out"])).max(),
-                   tol_for(dtype, a.embed_dim) * (3 if fuse and dtype == torch.float32 else 1))
+                   tol_for(dtype, a.embed_dim))      # fp32: 1e-5 with the pre-multiplied temporal_fc o out_proj too
         if dtype == torch.float32 and not fuse:
             assert np.abs(out - g["out"]).max() < 2e-5 * max(1.0, np.abs(g["out"]).max())
 
@@ -134,7 +133,7 @@ def test_ragged_text_tower_equals_dense(dtype):
         assert np.abs(unit(ragged) - unit(ref)).max() < 1e-5
     else:
         report_text("ragged text bf16", unit(ragged), unit(ref), dtype, a.embed_dim)
-        assert np.abs(unit(ragged) - unit(dense)).max() < 1.5e-3
+        assert np.abs(unit(ragged) - unit(dense)).max() < 1e-3
 
 
 def test_identity_at_init_timesformer_equals_vit_gpu():
@@ -178,7 +177,7 @@ def test_wrappers_vs_golden(fname, dtype):
     comments = A.synth_tokens(B * 5, a, case["cseed"], empty_frac=case["empty_frac"]).reshape(B, 5, -1).cuda()
     out = m(vis, title, comments) if case["comments"] else m(vis, title)
     fv, ft, sim = (o.cpu().numpy() for o in out)
-    tol = tol_for(dtype, a.embed_dim) * (3 if (dtype == torch.float32 and "timesformer" in case["model"]) else 1)  # fused temporal map
+    tol = tol_for(dtype, a.embed_dim)
     report(f"{fname} feats_vis {dtype}", np.abs(fv - g["feats_vis"]).max(), tol)
     if dtype == torch.float32:
         report(f"{fname} feats_text {dtype}", np.abs(ft - g["feats_text"]).max(), tol)
@@ -263,7 +262,7 @@ def test_full_size_batch_independence_and_oracle_spot_check():
     small_v = pv.forward(img[:8].cuda()).cpu().numpy()
     small_t = pt.forward(txt[:24].cuda()).cpu().numpy()
     report("ViT batch independence (256 vs 8)", np.abs(unit(big_v[:8]) - unit(small_v)).max(), 1e-3)
-    report("text batch independence (1536 vs 24)", np.abs(unit(big_t[:24]) - unit(small_t)).max(), 1.5e-3)
+    report("text batch independence (1536 vs 24)", np.abs(unit(big_t[:24]) - unit(small_t)).max(), 1e-3)
     ref_v = CR.encode_image(img[:3], sd, a, "model.visual.").numpy()
     ref_t = CR.encode_text(txt[:6], sd, a, "model.").numpy()
     report("ViT @B=256 vs oracle", np.abs(unit(big_v[:3]) - unit(ref_v)).max(), 1e-3)
@@ -295,3 +294,93 @@ def test_timesformer_16_frames_vs_oracle(dtype):
         pv = towers.PackedVision(cuda_sd(sd), "v.", dtype)
         out = pv.forward(x.cuda()).cpu().numpy()
         report(f"TimeSformer F=16 {a.vision_width} {dtype}", np.abs(unit(out) - unit(ref)).max(), tol_for(dtype, a.embed_dim))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_tower_module_entry_points_vs_golden(dtype):
+    """model.timesformer_clip_alt.VisualTransformer / model.timesformer_clip.VisualTransformer are drop-in modules: the
+    reference's constructor, strict state-dict loading and ``forward([B,F,3,H,W])`` (model/timesformer_clip_alt.py:252-286,
+    model/timesformer_clip.py:384-438; called directly at timesformer_clip_alt.py:333-360 and as ``self.model.visual(vis)``
+    at model/model.py:497,613) reproduce the tower goldens made by the reference's own classes."""
+    import model.timesformer_clip as v1
+    import model.timesformer_clip_alt as alt
+    for prefix, mod, variant in (("tower_alt_", alt, "alt"), ("tower_v1_", v1, "v1")):
+        for fname in golden_files(prefix):
+            case, g = load_golden(fname)
+            a = ARCH[case["arch"]]
+            sd = A.synth_visual(a, case["wseed"], nframes=case["nframes"], variant=variant)
+            t = mod.VisualTransformer(a.image_resolution, a.vision_patch_size, a.vision_width, a.vision_layers, a.vision_heads,
+                                      a.embed_dim, case["nframes"])
+            t.load_state_dict(sd, strict=True)
+            t = t.eval().cuda()
+            t.compute_dtype = dtype
+            x = A.synth_pixels((case["B"], case["nframes"], 3, a.image_resolution, a.image_resolution), case["xseed"])
+            out = t(x.cuda()).cpu().numpy()
+            report(f"{fname} via {mod.__name__}.VisualTransformer {dtype}", np.abs(unit(out) - unit(g["out"])).max(),
+                   tol_for(dtype, a.embed_dim))
+
+
+def test_make_timesformer_factory_runs_forward():
+    """make_timesformer_clip_vit_alt(nframes)(x): the factory's product has a working forward (model/__init__.py:21-22)."""
+    from vtc_amd.host import clip_arch
+    cfg = clip_arch.ClipConfig(**asdict(A.TINY))
+    t = clip_arch.make_timesformer_clip_vit_alt(4, clip_model=clip_arch.load(cfg), cfg=cfg).eval().cuda()
+    x = A.synth_pixels((2, 4, 3, A.TINY.image_resolution, A.TINY.image_resolution), 3).cuda()
+    out = t(x)
+    assert out.shape == (2, A.TINY.embed_dim) and torch.isfinite(out).all()
+    # the CLIP container's own encode_image / encode_text (upstream API used at model/model.py:332,340)
+    m = clip_arch.load(cfg).eval().cuda()
+    m.compute_dtype = torch.float32
+    m.visual.compute_dtype = torch.float32
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    img = A.synth_pixels((3, 3, A.TINY.image_resolution, A.TINY.image_resolution), 4)
+    txt = A.synth_tokens(5, A.TINY, 6, empty_frac=0.2)
+    assert (m.encode_image(img.cuda()).cpu() - CR.encode_image(img, sd, A.TINY, "visual.")).abs().max() < 2e-5
+    assert (m.encode_text(txt.cuda()).cpu() - CR.encode_text(txt, sd, A.TINY, "")).abs().max() < 2e-5
+
+
+def test_repack_then_forward_with_overlapping_towers():
+    """The weights are re-packed (dtype conversion, transposes, the fp64 temporal fuse) on the caller's stream BEFORE the
+    visual tower forks to its side stream: a forward right after a compute_dtype change / an in-place weight update must
+    see fully converted weights in BOTH towers (ViT-B/32 size, where the conversions take longer than the first launches)."""
+    from vtc_amd.host import model as HM
+    a = A.VIT_B32
+    m = HM.PretrainedCLIP_TimeSformer_finaltf(model_type=HM.clip_arch.ClipConfig(**asdict(a)), branch_to_adapt_val="text")
+    sd = A.synth_model(a, 5, "timesformer_finaltf", nframes=8)
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().cuda()
+    B = 4
+    vis = A.synth_pixels((B, 8, 3, 224, 224), 8).cuda()
+    title = A.synth_tokens(B, a, 9).cuda()
+    comments = A.synth_tokens(B * 5, a, 10, empty_frac=0.3).reshape(B, 5, -1).cuda()
+    assert m.overlap_towers
+    for dtype in (torch.bfloat16, torch.float32, torch.bfloat16):
+        m.compute_dtype = dtype                      # forces a repack inside the next forward
+        first = [o.clone() for o in m(vis, title, comments)]
+        torch.cuda.synchronize()
+        again = m(vis, title, comments)              # packed weights now long since converted
+        for x, y in zip(first, again):
+            assert torch.equal(x, y)
+    with torch.no_grad():                            # in-place update (what training does): version bump -> repack
+        m.model.text_projection.mul_(1.5)
+    first = [o.clone() for o in m(vis, title, comments)]
+    torch.cuda.synchronize()
+    for x, y in zip(first, m(vis, title, comments)):
+        assert torch.equal(x, y)
+
+
+def test_text_tower_half_layers_statistics():
+    """What the IEEE-half text blocks buy: error of the unit-norm text embedding against the fp32 oracle with 0 / 12 half
+    layers, 64 sequences of the ViT-B/32 text tower (printed for DESIGN.md; asserted: the shipped setting meets 1e-3)."""
+    from vtc_amd import towers
+    a = A.VIT_B32
+    for wseed in (52, 7):
+        sd = A.synth_text(a, wseed, prefix="model.")
+        txt = A.synth_tokens(64, a, 54 + wseed, empty_frac=0.25)
+        ref = unit(CR.encode_text(txt, sd, a, "model.").numpy())
+        for hl in (0, 12):
+            pt = towers.PackedText(cuda_sd(sd), "model.", torch.bfloat16, heads=a.transformer_heads, half_layers=hl)
+            d = np.abs(unit(pt.forward(txt.cuda()).cpu().numpy()) - ref)
+            print(f"[parity] text tower seed {wseed} half_layers={hl}: max {d.max():.3e} rms {np.sqrt((d ** 2).mean()):.3e}")
+            if hl == towers.TEXT_HALF_LAYERS:
+                assert d.max() < 1e-3

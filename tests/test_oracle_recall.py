@@ -81,3 +81,26 @@ def test_chunking_and_mean():
     assert torch.equal(ch[1], strided[0, 8:][idx])
     m = E.mean_chunks([torch.tensor([[1.0, 0.0], [0.0, 1.0]]), torch.tensor([[2.0, 2.0]])])
     assert torch.allclose(m, torch.tensor([[0.5, 0.5], [2.0, 2.0]]))   # not renormalised
+
+
+def test_oracle_recall_equals_the_references_own_recallatk():
+    """tests/golden/recall_cases.npz = outputs of the reference's own ``RecallAtK.compute`` / ``update`` / ``result``
+    (model/metric.py:103-187, run by tests/golden/make_recall_golden.py under a numpy ``faiss`` stand-in): pins the
+    oracle's bookkeeping -- depth max(k)+1, ``target in rp[:k]``, denominator len(features_a), direction naming."""
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "recall_cases.npz"), allow_pickle=False)
+    desc = json.loads(str(z["case"]))
+    assert len(desc) >= 7
+    for name, c in desc.items():
+        a, b = z[f"{name}.a"], z[f"{name}.b"]
+        ks = c["k_vals"] if isinstance(c["k_vals"], list) else [c["k_vals"]]
+        assert c["ks_returned"] == ks
+        got = E.recall_at_k(a, b, ks)
+        assert [k for k, _ in got] == ks
+        assert np.array_equal(np.array([r for _, r in got]), z[f"{name}.recall"]), name
+        if "result_keys" in c:
+            both = E.recall_at_k(a, b, ks) + E.recall_at_k(b, a, ks)
+            assert np.array_equal(np.array([r for _, r in both]), z[f"{name}.result"]), name
+            assert c["result_keys"] == [f"titles_from_visual-recall_at_{k}" for k in ks] + \
+                [f"visual_from_titles-recall_at_{k}" for k in ks]

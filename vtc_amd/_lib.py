@@ -18,6 +18,8 @@ ACT_NONE, ACT_NORMALIZE, ACT_SQUASH, ACT_TANH, ACT_SUB_MEAN, ACT_BN = 0, 1, 2, 3
 SWEEP_F32, SWEEP_BF16X3, SWEEP_BF16, SWEEP_EXACT = 0, 1, 2, 3
 EPI_STORE, EPI_GELU, EPI_RESID = 0, 1, 2
 PROF_CLASSES = ("gemm_bf16", "gemm_f32", "attention", "norm", "embed", "topk")
+PROF_REGIONS = ("other", "attn", "mlp")
+VTC_F16 = 3
 
 vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
 
@@ -39,7 +41,7 @@ class VisionW(C.Structure):
 
 class TextW(C.Structure):
     _fields_ = [("width", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("ctx", C.c_int), ("vocab", C.c_int),
-                ("embed_dim", C.c_int),
+                ("embed_dim", C.c_int), ("half_layers", C.c_int),
                 ("tok_emb", C.c_void_p), ("pos", C.c_void_p), ("ln_final_g", C.c_void_p), ("ln_final_b", C.c_void_p),
                 ("proj_t", C.c_void_p), ("blocks", C.POINTER(BlockW))]
 
@@ -78,6 +80,7 @@ SIGNATURES = {
     "vtc_layernorm": (C.c_int, [fp, fp, fp, vp, C.c_int, C.c_int, C.c_int, ip, C.c_int, vp]),
     "vtc_prof_begin": (C.c_int, []),
     "vtc_prof_end": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    "vtc_prof_end_regions": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "vtc_attention": (C.c_int, [vp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, vp]),
     # adapter-only training step (backward + optimizer primitives)

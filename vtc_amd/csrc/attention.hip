@@ -39,6 +39,7 @@ template <> struct AT<bf16_t> {
   static constexpr int KS = 2;    // QK k-steps (4 chunks each)
   static constexpr int EPC = 8;   // elements per chunk
 };
+template <> struct AT<f16_t> : AT<bf16_t> {};
 template <> struct AT<float> {
   static constexpr int NCH = 16;
   static constexpr int KS = 4;
@@ -47,6 +48,9 @@ template <> struct AT<float> {
 
 __device__ __forceinline__ void mma_qk(bf16_t, const uint4 &k, const uint4 &q, f32x4 &acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k), __builtin_bit_cast(bf16x8, q), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_qk(f16_t, const uint4 &k, const uint4 &q, f32x4 &acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, k), __builtin_bit_cast(f16x8, q), acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma_qk(float, const uint4 &k, const uint4 &q, f32x4 &acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, k.x), __builtin_bit_cast(float, q.x), acc, 0, 0, 0);
@@ -164,20 +168,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
       for (int kk = 0; kk < (NT + 1) / 2; ++kk) {
         const int k0 = 2 * kk, k1 = 2 * kk + 1;
-        bf16x8 pf;
+        bf16x8 pf;   // raw 16-bit lanes of the operand format (bf16 or IEEE half)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pf[r] = (short)f2bf(sc[k0][r]);
-          pf[4 + r] = k1 < NT ? (short)f2bf(sc[k1 < NT ? k1 : k0][r]) : (short)0;
+          pf[r] = (short)cvt16<T>(sc[k0][r]);
+          pf[4 + r] = k1 < NT ? (short)cvt16<T>(sc[k1 < NT ? k1 : k0][r]) : (short)0;
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const bf16_t *vr = reinterpret_cast<const bf16_t *>(vt) + (dt * 16 + c16) * VS + g * 4;
+          const unsigned short *vr = reinterpret_cast<const unsigned short *>(vt) + (dt * 16 + c16) * VS + g * 4;
           const uint2 lo = *reinterpret_cast<const uint2 *>(vr + k0 * 16);
           uint2 hi = make_uint2(0, 0);
           if (k1 < NT) hi = *reinterpret_cast<const uint2 *>(vr + k1 * 16);
           const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[dt], 0, 0, 0);
+          mma_qk(T(), vf, __builtin_bit_cast(uint4, pf), o[dt]);
         }
       }
     } else {
@@ -254,12 +258,8 @@ template <typename T, int NT>
 int run(const AttnParams &p, hipStream_t stream) {
   constexpr int VS = 16 * NT + 4;
   const size_t shmem = (size_t)4 * 64 * VS * sizeof(T);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_kernel<T, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)shmem);
-    attr_done = true;
-  }
+  static PerDeviceOnce attr;
+  if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&attn_kernel<T, NT>), (int)shmem, "attention")) return 1;
   const int total = p.n_seq * p.heads;
   hipLaunchKernelGGL((attn_kernel<T, NT>), dim3(cdiv(total, 4)), dim3(256), shmem, stream, p);
   VTC_LAUNCH_CHECK("attention");
@@ -291,6 +291,7 @@ int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int 
   p.seq_offsets = nullptr;
   p.W = heads * 64;
   ProfScope prof(VTC_PROF_ATTN, 4.0 * L * L * 64 * (double)n_seq * heads, stream);
+  if (dtype == VTC_F16) return dispatch<f16_t>(p, stream);
   return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
 }
 
@@ -305,6 +306,7 @@ int launch_attention_ragged(const void *qkv, void *out, int n_seq, int max_L, in
   p.seq_offsets = seq_offsets;
   p.W = heads * 64;
   ProfScope prof(VTC_PROF_ATTN, flops, stream);
+  if (dtype == VTC_F16) return dispatch<f16_t>(p, stream);
   return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
 }
 
@@ -324,7 +326,7 @@ int launch_cls_global_attention(const void *qkv, void *out, int n_items, int Tto
 
 extern "C" int vtc_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2,
                              int a0, int a1, int a2, int a3, int pstride, int dtype, void *stream) {
-  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "attention: bad dtype %d", dtype);
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16 || dtype == VTC_F16, "attention: bad dtype %d", dtype);
   return launch_attention(qkv, out, cls_out, n_seq, L, heads, causal, s2, a0, a1, a2, a3, pstride, dtype,
                           (hipStream_t)stream);
 }

@@ -42,6 +42,21 @@ __device__ __forceinline__ float bf2f(bf16_t b) {
   return __builtin_bit_cast(float, ((unsigned)b) << 16);
 }
 
+// IEEE half as a second 16-bit operand format (VTC_F16): a distinct tag type so that templates can tell it from bf16.
+// Same MFMA rate and bytes as bf16, 11 significant bits instead of 8, range +-65504 (the format upstream CLIP itself
+// runs in on a GPU; clip.load(..., device="cuda") returns fp16 weights).
+struct f16_t { unsigned short v; };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ unsigned short f2h(float f) {
+  _Float16 h = (_Float16)f;   // v_cvt_f16_f32, round to nearest even
+  return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float h2f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+// float -> raw 16 bits of the operand format T
+template <typename T> __device__ __forceinline__ unsigned short cvt16(float f);
+template <> __device__ __forceinline__ unsigned short cvt16<bf16_t>(float f) { return f2bf(f); }
+template <> __device__ __forceinline__ unsigned short cvt16<f16_t>(float f) { return f2h(f); }
+
 template <typename T> struct ElemOps;
 template <> struct ElemOps<float> {
   static constexpr int kDtype = VTC_F32;
@@ -67,6 +82,21 @@ template <> struct ElemOps<bf16_t> {
   }
 };
 
+template <> struct ElemOps<f16_t> {
+  static constexpr int kDtype = VTC_F16;
+  __device__ static __forceinline__ float load(const f16_t *p) { return h2f(p->v); }
+  __device__ static __forceinline__ void store(f16_t *p, float v) { p->v = f2h(v); }
+  __device__ static __forceinline__ void store4(f16_t *p, float a, float b, float c, float d) {
+    ushort4 v;
+    v.x = f2h(a); v.y = f2h(b); v.z = f2h(c); v.w = f2h(d);
+    *reinterpret_cast<ushort4 *>(p) = v;
+  }
+  __device__ static __forceinline__ float4 load4(const f16_t *p) {
+    ushort4 v = *reinterpret_cast<const ushort4 *>(p);
+    return make_float4(h2f(v.x), h2f(v.y), h2f(v.z), h2f(v.w));
+  }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -81,12 +111,43 @@ __device__ __forceinline__ float wave_max(float v) {
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- per-device launch state ----------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: a process that drives several GPUs (one
+// thread per replica, train.py:77-80) must opt every device in.  One bit per device; setting it twice is harmless, so
+// a race between two threads costs at most a redundant call.
+#include <atomic>
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> done{0};
+};
+// returns 0 on success; reports through vtc_set_error otherwise
+inline int ensure_dynamic_lds(PerDeviceOnce &once, const void *kernel, int bytes, const char *name) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  const unsigned long long bit = 1ull << dev;
+  if (once.done.load(std::memory_order_acquire) & bit) return 0;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    vtc_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed on device %d: %s", name, bytes, dev,
+                  hipGetErrorString(e));
+    return 1;
+  }
+  once.done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
+
 // ---- optional per-launch event timing (prof.hip) -------------------------------------------
 struct ProfScope {
   ProfScope(int cls, double work, hipStream_t s);
   ~ProfScope();
   hipStream_t stream_;
   int idx_;
+};
+
+// marks every launch made while it is alive (on this thread) with a VTC_PROF_REGION_*
+struct ProfRegion {
+  explicit ProfRegion(int region);
+  ~ProfRegion();
+  int prev_;
 };
 
 // ---- internal launchers shared between translation units --------------------------------

@@ -116,8 +116,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
             v2 = quick_gelu<sizeof(T) == 4>(v2); v3 = quick_gelu<sizeof(T) == 4>(v3);
           }
           uint2 pk;
-          pk.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-          pk.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+          pk.x = (unsigned)cvt16<OutT>(v0) | ((unsigned)cvt16<OutT>(v1) << 16);
+          pk.y = (unsigned)cvt16<OutT>(v2) | ((unsigned)cvt16<OutT>(v3) << 16);
           *reinterpret_cast<uint2 *>(buf + l15 * TSB + j * 32 + g * 8) = pk;
         }
       };
@@ -141,7 +141,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int r = (lane >> 3) + 8 * k, c = lane & 7;
-          bf16_t *o = reinterpret_cast<bf16_t *>(p.out) + (size_t)(mrow0 + r) * ldo + ncol0 + c * 8;
+          unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + (size_t)(mrow0 + r) * ldo + ncol0 + c * 8;
           store16<nt_out>(o, make_uint4(lo[k].x, lo[k].y, hi[k].x, hi[k].y));
         }
       }
@@ -283,11 +283,11 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
           v0.x = fin(v0.x, cadd[0][0]); v0.y = fin(v0.y, cadd[0][1]); v0.z = fin(v0.z, cadd[0][2]); v0.w = fin(v0.w, cadd[0][3]);
           v1.x = fin(v1.x, cadd[0][4]); v1.y = fin(v1.y, cadd[0][5]); v1.z = fin(v1.z, cadd[0][6]); v1.w = fin(v1.w, cadd[0][7]);
           uint4 pk;
-          pk.x = (unsigned)f2bf(v0.x) | ((unsigned)f2bf(v0.y) << 16);
-          pk.y = (unsigned)f2bf(v0.z) | ((unsigned)f2bf(v0.w) << 16);
-          pk.z = (unsigned)f2bf(v1.x) | ((unsigned)f2bf(v1.y) << 16);
-          pk.w = (unsigned)f2bf(v1.z) | ((unsigned)f2bf(v1.w) << 16);
-          bf16_t *o = reinterpret_cast<bf16_t *>(p.out) + (size_t)(mrow0 + r) * ldo + ncol0 + cc;
+          pk.x = (unsigned)cvt16<OutT>(v0.x) | ((unsigned)cvt16<OutT>(v0.y) << 16);
+          pk.y = (unsigned)cvt16<OutT>(v0.z) | ((unsigned)cvt16<OutT>(v0.w) << 16);
+          pk.z = (unsigned)cvt16<OutT>(v1.x) | ((unsigned)cvt16<OutT>(v1.y) << 16);
+          pk.w = (unsigned)cvt16<OutT>(v1.z) | ((unsigned)cvt16<OutT>(v1.w) << 16);
+          unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + (size_t)(mrow0 + r) * ldo + ncol0 + cc;
           *reinterpret_cast<uint4 *>(o) = pk;
         }
       }
@@ -505,9 +505,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
 // in a quarter per phase with one quarter always in flight across the barriers (counted vmcnt, never 0).  Quadrant walk (0,0) (0,1) (1,1) (1,0): 12 / 4 / 8 / 4 fragment reads; a quarter is the
 // 128 activation rows or weight rows the next K-tile's phase needs first: A0, W0, W1, A1.
 // (structure after the 8-phase schedule of the CDNA HIP guide, section 5.)
-template <int MODE, typename OutT>
+template <int MODE, typename OutT, typename T>
 __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p) {
-  using T = bf16_t;
+  static_assert(sizeof(T) == 2, "16-bit operands (bf16 or IEEE half)");
   constexpr int WM = 2, WN = 4, TM = 8, TN = 4, NW = 8, BM = 256, BN = 256;
   constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;
   constexpr int SUPER = SUPER_ROWS / BM;
@@ -744,15 +744,18 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
 
 }  // namespace
 namespace vtcgemm {
-static int g_num_cus = 0;
+// CU count of the CURRENT device (cached per device: grids are sized for the card the launch goes to)
 int num_cus() {
-  if (g_num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
-    if (g_num_cus <= 0) g_num_cus = 256;
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev].store(n = v, std::memory_order_relaxed);
   }
-  return g_num_cus;
+  return n;
 }
 }  // namespace vtcgemm
 namespace {
@@ -765,36 +768,28 @@ int run(GemmParams p, hipStream_t stream) {
   const size_t shmem = (size_t)NSTAGE * (BM + BN) * ROWB;
   const int wg_per_cu = shmem > 80 * 1024 ? 1 : 2;
   const int grid = min(ntiles, num_cus() * wg_per_cu);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<T, MODE, OutT, WM, WN, TM, TN, NSTAGE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    attr_done = true;
-  }
+  static PerDeviceOnce attr;
+  if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&gemm_kernel<T, MODE, OutT, WM, WN, TM, TN, NSTAGE>), (int)shmem, "gemm")) return 1;
   hipLaunchKernelGGL((gemm_kernel<T, MODE, OutT, WM, WN, TM, TN, NSTAGE>), dim3(grid), dim3(NT_), shmem, stream, p);
   VTC_LAUNCH_CHECK("gemm");
   return 0;
 }
 
-template <int MODE, typename OutT>
+template <int MODE, typename OutT, typename T>
 int run_phased(GemmParams p, hipStream_t stream) {
   p.MT = cdiv(p.M, 256); p.NT = cdiv(p.N, 256);
   const int ntiles = p.MT * p.NT;
   const size_t shmem = (size_t)2 * 512 * ROWB;          // 128 KiB: one workgroup per CU
   const int grid = min(ntiles, num_cus());
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_phased_kernel<MODE, OutT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    attr_done = true;
-  }
+  static PerDeviceOnce attr;
+  if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&gemm_phased_kernel<MODE, OutT, T>), (int)shmem, "gemm_phased")) return 1;
 #ifdef VTC_GEMM_STAMPS
   static unsigned long long *dbg = nullptr;
   if (!dbg) (void)hipMalloc(&dbg, (size_t)256 * 8 * 8 * sizeof(unsigned long long));
   (void)hipMemsetAsync(dbg, 0, (size_t)256 * 8 * 8 * sizeof(unsigned long long), stream);
   p.dbg = dbg;
 #endif
-  hipLaunchKernelGGL((gemm_phased_kernel<MODE, OutT>), dim3(grid), dim3(512), shmem, stream, p);
+  hipLaunchKernelGGL((gemm_phased_kernel<MODE, OutT, T>), dim3(grid), dim3(512), shmem, stream, p);
 #ifdef VTC_GEMM_STAMPS
   {
     static unsigned long long host[256 * 8 * 8];
@@ -832,7 +827,7 @@ int run_cfg(const GemmParams &p, hipStream_t stream) {
       if (g_force_tile == 6) return run<T, MODE, OutT, 2, 4, 4, 8, 2>(p, stream);
     }
 #endif
-    if (big && g_force_tile != 2) return run_phased<MODE, OutT>(p, stream);
+    if (big && g_force_tile != 2) return run_phased<MODE, OutT, T>(p, stream);
     if (big) return run<T, MODE, OutT, 2, 4, 8, 4, 2>(p, stream);
   }
   // few 128x128 tiles (CAM: 1536 x 512, the output projections): 64x64 tiles, two waves, put 4x the workgroups
@@ -845,13 +840,14 @@ int run_cfg(const GemmParams &p, hipStream_t stream) {
 template <typename T>
 int dispatch(const GemmParams &p, hipStream_t stream) {
   const bool out_f32 = p.epi.out_dtype == VTC_F32;
+  using Out16 = std::conditional_t<sizeof(T) == 2, T, bf16_t>;   // 16-bit outputs are in the operand format (fp32 operands: bf16)
   switch (p.epi.mode) {
     case VTC_EPI_STORE:
       if (out_f32) return run_cfg<T, VTC_EPI_STORE, float>(p, stream);
-      return run_cfg<T, VTC_EPI_STORE, bf16_t>(p, stream);
+      return run_cfg<T, VTC_EPI_STORE, Out16>(p, stream);
     case VTC_EPI_GELU:
       if (out_f32) return run_cfg<T, VTC_EPI_GELU, float>(p, stream);
-      return run_cfg<T, VTC_EPI_GELU, bf16_t>(p, stream);
+      return run_cfg<T, VTC_EPI_GELU, Out16>(p, stream);
     case VTC_EPI_RESID: return run_cfg<T, VTC_EPI_RESID, float>(p, stream);
     case EPI_PATCH: return run_cfg<T, EPI_PATCH, float>(p, stream);
     case EPI_L2DIST: return run_cfg<T, EPI_L2DIST, float>(p, stream);
@@ -865,34 +861,37 @@ int dispatch(const GemmParams &p, hipStream_t stream) {
 
 int launch_gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype,
                 const GemmEpi &epi, hipStream_t stream) {
-  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "gemm: bad dtype %d", dtype);
-  const int esz = dtype == VTC_BF16 ? 2 : 4;
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16 || dtype == VTC_F16, "gemm: bad dtype %d", dtype);
+  VTC_CHECK(epi.out_dtype == VTC_F32 || epi.out_dtype == (dtype == VTC_F16 ? VTC_F16 : VTC_BF16),
+            "gemm: out_dtype %d does not go with operand dtype %d (16-bit outputs are in the operand format)", epi.out_dtype, dtype);
+  const int esz = dtype == VTC_F32 ? 4 : 2;
   const int kpr = ROWB / esz;
   VTC_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   VTC_CHECK(K % kpr == 0, "gemm: K=%d must be a multiple of %d for dtype %d", K, kpr, dtype);
   VTC_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: operands must be 16-byte aligned");
-  VTC_CHECK(!(epi.out_dtype == VTC_BF16 && (epi.mode == VTC_EPI_RESID || epi.mode >= EPI_PATCH)),
+  VTC_CHECK(!(epi.out_dtype != VTC_F32 && (epi.mode == VTC_EPI_RESID || epi.mode >= EPI_PATCH)),
             "gemm: epilogue %d writes fp32 only", epi.mode);
-  static bool env_done = false;
-  if (!env_done) {
-    const char *e = getenv("VTC_GEMM_TILE");
-    if (e) g_force_tile = atoi(e);
-    env_done = true;
-  }
+  // diagnostics knobs, read once (C++11 static initialisation is thread-safe; never written afterwards)
+  struct Env { int tile = 0, exp_arg = 0, sg = 0, st = 0; };
+  static const Env env = [] {
+    Env v;
+    if (const char *e = getenv("VTC_GEMM_TILE")) v.tile = atoi(e);
+    if (const char *e = getenv("VTC_GEMM_EXP")) v.exp_arg = atoi(e);
+    if (const char *e = getenv("VTC_GEMM_STAGGER")) sscanf(e, "%d,%d", &v.sg, &v.st);
+    return v;
+  }();
+  g_force_tile = env.tile;
   GemmParams p;
   p.A = (const char *)A; p.W = (const char *)W; p.bias = bias; p.out = out;
   p.M = M; p.N = N; p.K = K;
   p.lda_bytes = K * esz; p.ldw_bytes = K * esz;
   p.ldo = epi.ldo > 0 ? epi.ldo : N;
   p.MT = 0; p.NT = 0;
-  { static int ea = -1; if (ea < 0) { const char *e = getenv("VTC_GEMM_EXP"); ea = e ? atoi(e) : 0; } p.exp_arg = ea; }
-  {
-    static int sg = -1, st = 0;
-    if (sg < 0) { const char *e = getenv("VTC_GEMM_STAGGER"); sg = 0; if (e) sscanf(e, "%d,%d", &sg, &st); }
-    p.stagger_groups = sg; p.stagger_ticks = st;
-  }
+  p.exp_arg = env.exp_arg;
+  p.stagger_groups = env.sg; p.stagger_ticks = env.st;
   p.epi = epi;
-  ProfScope prof(dtype == VTC_BF16 ? VTC_PROF_GEMM_BF16 : VTC_PROF_GEMM_F32, 2.0 * M * N * K, stream);
+  ProfScope prof(dtype != VTC_F32 ? VTC_PROF_GEMM_BF16 : VTC_PROF_GEMM_F32, 2.0 * M * N * K, stream);   // 16-bit operand class
+  if (dtype == VTC_F16) return dispatch<f16_t>(p, stream);
   return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
 }
 

@@ -21,6 +21,15 @@ template <> struct Mma<bf16_t> {
                                                   0, 0, 0);
   }
 };
+template <> struct Mma<f16_t> {
+  static constexpr int KPR = 64;
+  __device__ static __forceinline__ void run(const u32x4v &w, const u32x4v &a, f32x4 &acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
+  }
+  __device__ static __forceinline__ void run(const uint4 &w, const uint4 &a, f32x4 &acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
+  }
+};
 template <> struct Mma<float> {
   static constexpr int KPR = 32;
   __device__ static __forceinline__ void run(const u32x4v &w, const u32x4v &a, f32x4 &acc) {

@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, const fl
       }
       if constexpr (sizeof(OutT) == 2) {
         uint4 pk;
-        pk.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-        pk.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
-        pk.z = (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16);
-        pk.w = (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16);
+        pk.x = (unsigned)cvt16<OutT>(o[0]) | ((unsigned)cvt16<OutT>(o[1]) << 16);
+        pk.y = (unsigned)cvt16<OutT>(o[2]) | ((unsigned)cvt16<OutT>(o[3]) << 16);
+        pk.z = (unsigned)cvt16<OutT>(o[4]) | ((unsigned)cvt16<OutT>(o[5]) << 16);
+        pk.w = (unsigned)cvt16<OutT>(o[6]) | ((unsigned)cvt16<OutT>(o[7]) << 16);
         *reinterpret_cast<uint4 *>(yr + c) = pk;
       } else {
         ElemOps<OutT>::store4(yr + c, o[0], o[1], o[2], o[3]);
@@ -125,8 +125,11 @@ int launch_layernorm(const float *x, const float *g, const float *b, void *y, in
   VTC_CHECK(rows > 0, "layernorm: rows=%d", rows);
   VTC_CHECK(width % 8 == 0 && width <= 512 * MAXV, "layernorm: width=%d unsupported (multiple of 8, <= 1024)", width);
   const dim3 grid(cdiv(rows, 4)), block(256);
-  ProfScope prof(VTC_PROF_NORM, (double)rows * width * (4 + (out_dtype == VTC_BF16 ? 2 : 4)), stream);
-  if (out_dtype == VTC_BF16) {
+  ProfScope prof(VTC_PROF_NORM, (double)rows * width * (4 + (out_dtype != VTC_F32 ? 2 : 4)), stream);
+  if (out_dtype == VTC_F16) {
+    if (no_norm) hipLaunchKernelGGL((layernorm_kernel<f16_t, true>), grid, block, 0, stream, x, g, b, (f16_t *)y, rows, width, row_index, row_mul);
+    else hipLaunchKernelGGL((layernorm_kernel<f16_t, false>), grid, block, 0, stream, x, g, b, (f16_t *)y, rows, width, row_index, row_mul);
+  } else if (out_dtype == VTC_BF16) {
     if (no_norm) hipLaunchKernelGGL((layernorm_kernel<bf16_t, true>), grid, block, 0, stream, x, g, b, (bf16_t *)y, rows, width, row_index, row_mul);
     else hipLaunchKernelGGL((layernorm_kernel<bf16_t, false>), grid, block, 0, stream, x, g, b, (bf16_t *)y, rows, width, row_index, row_mul);
   } else {

@@ -31,7 +31,7 @@ void vtc_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 extern "C" const char *vtc_last_error(void) { return g_err; }
-extern "C" int vtc_abi_version(void) { return 2; }
+extern "C" int vtc_abi_version(void) { return 3; }
 
 int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res, const float *mean, const float *stdv, hipStream_t stream);
 int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, int T, int W, hipStream_t stream);
@@ -62,7 +62,7 @@ struct Bump {
     if (rc_) return rc_; \
   } while (0)
 
-inline int esz(int dtype) { return dtype == VTC_BF16 ? 2 : 4; }
+inline int esz(int dtype) { return dtype == VTC_F32 ? 4 : 2; }
 
 int gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype, int mode, int out_dtype,
          int skip_mod, hipStream_t s) {
@@ -73,6 +73,7 @@ int gemm(const void *A, const void *W, const float *bias, void *out, int M, int 
 
 // x += MLP(ln_2 x)   (timesformer_clip_alt.py:174 / upstream block)
 int mlp_part(const vtc_block_w &b, float *x, void *h, void *big, int rows, int W, int dtype, hipStream_t s) {
+  ProfRegion region(VTC_PROF_REGION_MLP);
   RUN(launch_layernorm(x, b.ln2_g, b.ln2_b, h, rows, W, dtype, nullptr, 1, false, s));
   RUN(gemm(h, b.fc_w, b.fc_b, big, rows, 4 * W, W, dtype, VTC_EPI_GELU, dtype, 0, s));
   RUN(gemm(big, b.proj_w, b.proj_b, x, rows, W, 4 * W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
@@ -83,11 +84,17 @@ int mlp_part(const vtc_block_w &b, float *x, void *h, void *big, int rows, int W
 int attn_part_contig(const vtc_block_w &b, float *x, void *h, void *big, int n_seq, int L, int W, int heads, int causal, int dtype,
                      hipStream_t s) {
   const int rows = n_seq * L;
+  ProfRegion region(VTC_PROF_REGION_ATTN);
   RUN(launch_layernorm(x, b.ln1_g, b.ln1_b, h, rows, W, dtype, nullptr, 1, false, s));
   RUN(gemm(h, b.qkv_w, b.qkv_b, big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
   RUN(launch_attention(big, h, nullptr, n_seq, L, heads, causal, 1, 0, L, 0, 0, 1, dtype, s));
   RUN(gemm(h, b.out_w, b.out_b, x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
   return 0;
+}
+
+// operand format of text block l: with dtype == VTC_BF16 the first half_layers blocks run on IEEE half
+inline int layer_dtype(const vtc_text_w *w, int l, int dtype) {
+  return (dtype == VTC_BF16 && l < w->half_layers) ? VTC_F16 : dtype;
 }
 
 struct VisionWs {
@@ -170,6 +177,8 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
 
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
+    {
+    ProfRegion region(VTC_PROF_REGION_ATTN);   // time + space branches: what BASELINE.md calls "TimeSformer attention"
     if (tsf && w->variant == 1) {
       // model/timesformer_clip.py:308-315: x += time(ln_time x); x += space(ln_1 x); x += mlp(ln_2 x).
       // Tokens are (frames patches): row item*T + 1 + t*P + n (:392).  In both attentions the cls query
@@ -206,6 +215,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
     } else {
       RUN(attn_part_contig(b, v.x, v.h, v.big, n_items, T, W, w->heads, 0, dtype, s));
     }
+    }
     RUN(mlp_part(b, v.x, v.h, v.big, rows, W, dtype, s));
   }
   // ln_post(x[:,0]) @ proj -- always fp32 (n_items rows only): the embedding the sweep ranks on
@@ -224,7 +234,7 @@ extern "C" int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_s
                                 int dtype, void *stream_) {
   hipStream_t s = (hipStream_t)stream_;
   VTC_CHECK(w && ids && out && ws, "text_forward: null argument");
-  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "text_forward: bad dtype %d", dtype);
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16 || dtype == VTC_F16, "text_forward: bad dtype %d", dtype);
   VTC_CHECK(n_seq > 0, "text_forward: n_seq=%d", n_seq);
   VTC_CHECK(w->ctx <= 80, "text_forward: context %d > 80 unsupported", w->ctx);
   VTC_CHECK(w->width == w->heads * 64, "text_forward: head_dim must be 64");
@@ -234,8 +244,9 @@ extern "C" int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_s
   RUN(launch_text_embed(ids, w->tok_emb, w->pos, t.x, t.eot, n_seq, w->ctx, W, w->vocab, s));
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
-    RUN(attn_part_contig(b, t.x, t.h, t.big, n_seq, w->ctx, W, w->heads, 1, dtype, s));
-    RUN(mlp_part(b, t.x, t.h, t.big, rows, W, dtype, s));
+    const int dl = layer_dtype(w, l, dtype);
+    RUN(attn_part_contig(b, t.x, t.h, t.big, n_seq, w->ctx, W, w->heads, 1, dl, s));
+    RUN(mlp_part(b, t.x, t.h, t.big, rows, W, dl, s));
   }
   // ln_final on the EOT row only (LayerNorm is per-row, so gathering first is identical), then @ text_projection
   // (always fp32, as for the vision tower)
@@ -255,7 +266,7 @@ extern "C" int vtc_text_forward_ragged(const vtc_text_w *w, const int64_t *ids, 
                                        float *out, void *ws, size_t ws_bytes, int dtype, void *stream_) {
   hipStream_t s = (hipStream_t)stream_;
   VTC_CHECK(w && ids && seq_offsets && out && ws, "text_forward_ragged: null argument");
-  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "text_forward_ragged: bad dtype %d", dtype);
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16 || dtype == VTC_F16, "text_forward_ragged: bad dtype %d", dtype);
   VTC_CHECK(n_seq > 0 && total_rows >= n_seq && total_rows <= n_seq * w->ctx, "text_forward_ragged: n_seq=%d total_rows=%d", n_seq, total_rows);
   VTC_CHECK(w->ctx <= 80 && w->width == w->heads * 64, "text_forward_ragged: unsupported shape");
   const int W = w->width, rows = total_rows;
@@ -266,11 +277,15 @@ extern "C" int vtc_text_forward_ragged(const vtc_text_w *w, const int64_t *ids, 
   const double avgL = (double)rows / n_seq;
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
-    RUN(launch_layernorm(t.x, b.ln1_g, b.ln1_b, t.h, rows, W, dtype, nullptr, 1, false, s));
-    RUN(gemm(t.h, b.qkv_w, b.qkv_b, t.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
-    RUN(launch_attention_ragged(t.big, t.h, n_seq, w->ctx, w->heads, 1, seq_offsets, 4.0 * avgL * rows * 64 * w->heads, dtype, s));
-    RUN(gemm(t.h, b.out_w, b.out_b, t.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
-    RUN(mlp_part(b, t.x, t.h, t.big, rows, W, dtype, s));
+    const int dl = layer_dtype(w, l, dtype);
+    {
+      ProfRegion region(VTC_PROF_REGION_ATTN);
+      RUN(launch_layernorm(t.x, b.ln1_g, b.ln1_b, t.h, rows, W, dl, nullptr, 1, false, s));
+      RUN(gemm(t.h, b.qkv_w, b.qkv_b, t.big, rows, 3 * W, W, dl, VTC_EPI_STORE, dl, 0, s));
+      RUN(launch_attention_ragged(t.big, t.h, n_seq, w->ctx, w->heads, 1, seq_offsets, 4.0 * avgL * rows * 64 * w->heads, dl, s));
+      RUN(gemm(t.h, b.out_w, b.out_b, t.x, rows, W, W, dl, VTC_EPI_RESID, VTC_F32, 0, s));
+    }
+    RUN(mlp_part(b, t.x, t.h, t.big, rows, W, dl, s));
   }
   RUN(launch_layernorm(t.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, VTC_F32, t.eot, 1, false, s));
   RUN(gemm(t.lnp, w->proj_t, nullptr, out, n_seq, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));

@@ -34,8 +34,8 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)     # every backend: the rank's tensors and launches live on its own card
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 

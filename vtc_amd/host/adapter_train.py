@@ -103,6 +103,7 @@ class AdapterTrainer:
     def _p(self, l, name):
         return self.params[f"final_transformer.resblocks.{l}.{name}"]
 
+    @ops.on_device
     def step(self, feats_vis: torch.Tensor, feats_title: torch.Tensor, feats_comm_raw: torch.Tensor, empty: torch.Tensor,
              skip_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """feats_vis / feats_title [B,D], feats_comm_raw [nc,B,D] (text-tower outputs before the empty-comment

@@ -97,12 +97,23 @@ class Transformer(NoForward):
         self.resblocks = nn.Sequential(*[BlockParams(width, layers, timesformer, v1) for _ in range(layers)])
 
 
-class VisionParams(NoForward):
+class VisionParams(nn.Module):
     """Upstream VisionTransformer (nframes = 0) or the TimeSformer VisualTransformer
-    (model/timesformer_clip_alt.py:203-250)."""
+    (model/timesformer_clip_alt.py:203-250; v1: model/timesformer_clip.py:341-382).
+
+    ``forward`` is the tower's own entry point -- ``self.model.visual(vis)`` in the reference
+    (model/model.py:497,613) and the direct call of model/timesformer_clip_alt.py:333-360: it packs the
+    parameters once per (parameter versions, compute dtype) and runs vtc_vision_forward in
+    libvtc_hip.so.  Eval only, GPU only, no fallback."""
+
+    #: arithmetic of the GEMM/attention operands (LayerNorm, softmax, residual stream, output stay fp32)
+    compute_dtype = torch.bfloat16
+    #: multiply temporal_fc and timeattn.out_proj together at pack time (one GEMM instead of two)
+    fuse_temporal = True
 
     def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, nframes=0, v1=False):
         super().__init__()
+        self._packed_sig, self._packed = None, None
         self.input_resolution, self.output_dim, self.nframes, self.width = input_resolution, output_dim, nframes, width
         self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)
         scale = width ** -0.5
@@ -115,8 +126,47 @@ class VisionParams(NoForward):
         self.ln_post = nn.LayerNorm(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """[B, F, 3, H, W] (TimeSformer, model/timesformer_clip_alt.py:252-286 / timesformer_clip.py:384-438) or
+        [B, 3, H, W] (upstream VisionTransformer.forward) -> [B, output_dim] fp32."""
+        if self.training:
+            raise RuntimeError("vtc_amd implements the forward/eval path only: call .eval()")
+        if not x.is_cuda:
+            raise RuntimeError("vtc_amd: inputs must be on the GPU (no CPU fallback)")
+        if (x.dim() == 5) != bool(self.nframes):
+            raise ValueError(f"expected {'[B,F,3,H,W]' if self.nframes else '[B,3,H,W]'} pixels, got {tuple(x.shape)}")
+        from .. import towers
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (self.compute_dtype, self.fuse_temporal)
+        if self._packed_sig != sig:
+            if next(self.parameters()).device != x.device:
+                raise RuntimeError("vtc_amd: module and input are on different devices")
+            self._packed = towers.PackedVision(dict(self.state_dict()), "", self.compute_dtype, self.fuse_temporal)
+            self._packed_sig = sig
+        return self._packed.forward(x)
 
-class ClipParams(NoForward):
+
+class VisualTransformer(VisionParams):
+    """``model.timesformer_clip_alt.VisualTransformer`` (model/timesformer_clip_alt.py:203-286): same
+    constructor signature, parameter names and ``forward([B,F,3,H,W]) -> [B,output_dim]``."""
+
+    def __init__(self, input_resolution: int, patch_size: int, width: int, layers: int, heads: int, output_dim: int,
+                 nframes: int):
+        if width != heads * 64:
+            raise NotImplementedError(f"head_dim must be 64 on the HIP path (width {width}, heads {heads})")
+        super().__init__(input_resolution, patch_size, width, layers, heads, output_dim, nframes=nframes)
+
+
+class VisualTransformerV1(VisionParams):
+    """``model.timesformer_clip.VisualTransformer`` (model/timesformer_clip.py:341-438): the older variant."""
+
+    def __init__(self, input_resolution: int, patch_size: int, width: int, layers: int, heads: int, output_dim: int,
+                 nframes: int):
+        if width != heads * 64:
+            raise NotImplementedError(f"head_dim must be 64 on the HIP path (width {width}, heads {heads})")
+        super().__init__(input_resolution, patch_size, width, layers, heads, output_dim, nframes=nframes, v1=True)
+
+
+class ClipParams(nn.Module):
     """Upstream CLIP container: what ``clip.load`` returns in the reference (model/model.py:317)."""
 
     def __init__(self, cfg: ClipConfig):
@@ -138,6 +188,34 @@ class ClipParams(NoForward):
     def dtype(self):
         return self.visual.conv1.weight.dtype
 
+    #: arithmetic of the text tower's GEMM/attention operands when called through ``encode_text`` directly
+    compute_dtype = torch.bfloat16
+
+    def encode_image(self, image: torch.Tensor) -> torch.Tensor:
+        """Upstream ``CLIP.encode_image`` (called at model/model.py:332,335,464,467): the visual tower."""
+        return self.visual(image)
+
+    def encode_text(self, text: torch.Tensor) -> torch.Tensor:
+        """Upstream ``CLIP.encode_text`` (called at model/model.py:210,340,351,472,499,615) on libvtc_hip.so."""
+        if self.training:
+            raise RuntimeError("vtc_amd implements the forward/eval path only: call .eval()")
+        if not text.is_cuda:
+            raise RuntimeError("vtc_amd: inputs must be on the GPU (no CPU fallback)")
+        from .. import towers
+        own = [p for n, p in self.named_parameters() if not n.startswith("visual.")]
+        sig = tuple((p.data_ptr(), p._version) for p in own) + (self.compute_dtype,)
+        if getattr(self, "_text_sig", None) != sig:
+            self._text_packed = towers.PackedText(dict(self.state_dict()), "", self.compute_dtype, heads=self.transformer.heads)
+            self._text_sig = sig
+        return self._text_packed.forward(text)
+
+
+def pretrained_weights_available() -> bool:
+    return bool(os.environ.get("VTC_CLIP_WEIGHTS"))
+
+
+_warned_random = False
+
 
 def load(model_type: str = "ViT-B/32", device="cpu", cfg: ClipConfig = None) -> ClipParams:
     """Stand-in for ``clip.load(model_type, device="cpu", jit=False)[0]`` (model/model.py:317).
@@ -157,6 +235,15 @@ def load(model_type: str = "ViT-B/32", device="cpu", cfg: ClipConfig = None) -> 
         sd = sd.get("state_dict", sd)
         sd = {k: v.float() for k, v in sd.items() if k not in ("input_resolution", "context_length", "vocab_size")}
         m.load_state_dict(sd, strict=True)
+    elif not isinstance(model_type, ClipConfig):
+        # a named upstream model without its weights: say so once (a ClipConfig instance is a test/bench architecture)
+        global _warned_random
+        if not _warned_random:
+            import warnings
+            warnings.warn(f"vtc_amd: clip_arch.load({model_type!r}) has no pretrained weights (VTC_CLIP_WEIGHTS is unset, and "
+                          "there is no network to download them as the reference's clip.load does): the towers are "
+                          "RANDOMLY initialised until a checkpoint / state dict is loaded", stacklevel=2)
+            _warned_random = True
     return m.to(device).eval()
 
 
@@ -165,8 +252,8 @@ def make_timesformer_clip_vit_alt(nframes: int, model="ViT-B/32", clip_model: Cl
     weights; only time/temporal keys may be missing (:325-328)."""
     if cfg is None:
         cfg = clip_model.cfg if clip_model is not None else CONFIGS[model]
-    t = VisionParams(cfg.image_resolution, cfg.vision_patch_size, cfg.vision_width, cfg.vision_layers,
-                     cfg.vision_width // 64, cfg.embed_dim, nframes=nframes)
+    t = VisualTransformer(cfg.image_resolution, cfg.vision_patch_size, cfg.vision_width, cfg.vision_layers,
+                          cfg.vision_width // 64, cfg.embed_dim, nframes=nframes)
     if clip_model is None:
         clip_model = load(model, cfg=cfg)
     missing, unexpected = t.load_state_dict(clip_model.visual.state_dict(), strict=False)
@@ -180,8 +267,8 @@ def make_timesformer_clip_vit(nframes: int, model="ViT-B/32", clip_model: ClipPa
     to cls + same frame / same position; no temporal_fc), initialised from the CLIP ViT weights."""
     if cfg is None:
         cfg = clip_model.cfg if clip_model is not None else CONFIGS[model]
-    t = VisionParams(cfg.image_resolution, cfg.vision_patch_size, cfg.vision_width, cfg.vision_layers,
-                     cfg.vision_width // 64, cfg.embed_dim, nframes=nframes, v1=True)
+    t = VisualTransformerV1(cfg.image_resolution, cfg.vision_patch_size, cfg.vision_width, cfg.vision_layers,
+                            cfg.vision_width // 64, cfg.embed_dim, nframes=nframes)
     if clip_model is None:
         clip_model = load(model, cfg=cfg)
     missing, unexpected = t.load_state_dict(clip_model.visual.state_dict(), strict=False)

@@ -1,10 +1,22 @@
-"""Synthetic stand-in for the reference's dataset loaders (dataset_loaders/*.py, out of scope: they
-need torchvision video IO, PIL, ffmpeg and the VTC csv/images).  Only the TENSOR CONTRACT the hot
-path consumes is reproduced (evaluation/eval.py:101-116): items are
+"""Stand-ins for the reference's dataset loaders (dataset_loaders/dataset_loaders.py, out of scope: they
+need torchvision video IO, PIL, ffmpeg, the CLIP tokenizer, RAKE and the VTC csv/images).  Only the TENSOR
+CONTRACT the hot path consumes is reproduced (evaluation/eval.py:101-116): items are
 ``(vis [3,224,224] | [F,3,224,224], title [77] int64, comments [nc,77] int64, meta {"id": int})``.
-Pixels ~ N(0,1) (the distribution tests/test_pretrained_clip.py:8 uses); tokens are
-``[SOT, t_1..t_L, EOT, 0...]`` with L ~ U{1..75}; 10 % of comments are the empty string."""
+
+``ImTextDataset`` (dataset_loaders.py:924-1046) and ``VideoDatasetSegments`` (:440-566) keep the
+reference's class names and constructor keywords, so that ``config.init_obj("dataset", module_data,
+train=..., test=...)`` (evaluation/eval.py:58, train.py:45-64) resolves the reference's UNMODIFIED
+``configs/pretrained_clip*.jsonc``.  Those configs ship with ``"csv_file": ""`` (the VTC data is not
+released, README.md:105): an empty ``csv_file`` selects synthetic pairs of the same tensor contract;
+a non-empty one raises -- reading real posts needs the loaders above.
+
+Synthetic items: pixels ~ N(0,1) (the distribution tests/test_pretrained_clip.py:8 uses); tokens are
+``[SOT, t_1..t_L, EOT, 0...]`` with L ~ U{1..75}; 10 % of comments are the empty string
+``[SOT, EOT, 0...]`` (what ``_tokenise([""])`` produces, dataset_loaders.py:224-248, and what
+``preprocess_comments`` pads with, :274-275)."""
 from __future__ import annotations
+
+import os
 
 import torch
 from torch.utils.data import Dataset
@@ -42,3 +54,76 @@ class SyntheticPairs(Dataset):
         shape = (3, self.res, self.res) if self.kind == "image" else (self.nframes, 3, self.res, self.res)
         vis = torch.randn(shape, generator=g)
         return vis, self.titles[i], self.comments[i], {"id": i}
+
+
+def _should_add_comments(add_comments, train):
+    """dataset_loaders.py:215-222."""
+    cases = {"always": [True, True], "train_only": [False, True], "never": [False, False]}
+    return cases[add_comments][int(bool(train))]
+
+
+class _ReferenceNamedDataset(SyntheticPairs):
+    """Shared body of the two reference-named classes: same keywords as the reference's constructors; with
+    ``csv_file == ""`` the items are synthetic.  ``n_pairs`` (extra keyword, or env VTC_SYNTHETIC_PAIRS) sizes
+    the synthetic split; ``resolution`` / ``context`` exist for small test architectures."""
+    _kind = "image"
+    _default_pairs = 1024
+
+    def _setup(self, csv_file, train, test, add_comments, num_comms, n_pairs, seed, resolution, context, nframes=8):
+        if csv_file not in ("", None):
+            raise NotImplementedError(
+                f"{type(self).__name__}: reading {csv_file!r} needs the reference's dataset_loaders (torchvision video "
+                "IO, PIL, CLIP tokenizer, RAKE), which are outside the hot path; an empty csv_file -- what the "
+                "reference's configs ship with -- selects synthetic pairs of the same tensor contract")
+        if test:
+            assert not train                                   # dataset_loaders.py:204-205
+        n = int(n_pairs or os.environ.get("VTC_SYNTHETIC_PAIRS", self._default_pairs))
+        self.train = train
+        self.with_comments = _should_add_comments(add_comments, train)
+        nc = int(num_comms) if self.with_comments else 0
+        # the three splits are disjoint synthetic sets
+        super().__init__(n_pairs=n, kind=self._kind, add_comments=add_comments, num_comms=max(nc, 1),
+                         seed=int(seed) + (0 if test else (1 if train else 2)), nframes=nframes, resolution=resolution,
+                         context=context)
+        if nc == 0:
+            # `comments_tok = self._tokenise([""])` (dataset_loaders.py:1024-1025, :562-563): one empty comment
+            self.comments = torch.zeros(self.n, 1, context, dtype=torch.int64)
+            self.comments[:, 0, 0], self.comments[:, 0, 1] = SOT, EOT
+
+
+class ImTextDataset(_ReferenceNamedDataset):
+    """dataset_loaders/dataset_loaders.py:924-1046 (constructor keywords :938-954)."""
+    _kind = "image"
+
+    def __init__(self, csv_file, root="", train=True, test=False, add_comments="train_only", num_comms=0,
+                 comment_sampling="random", cached_vision_features=None, test_on_over_k_comms=None, test_set_limit=None,
+                 use_augmentation=False, cached_audio_features=None, audio_with_comms=None, audio_instead_of_title=False,
+                 n_pairs=None, seed=123, resolution=224, context=77):
+        if cached_audio_features is not None or audio_with_comms or audio_instead_of_title:
+            raise NotImplementedError("ImTextDataset: the audio branch (needs the external GDT repository) is out of scope")
+        if cached_vision_features is not None:
+            raise NotImplementedError("ImTextDataset: cached features are produced/consumed by vtc_amd.host.cache_features")
+        self.root, self.comment_sampling = root, (comment_sampling if train else None)
+        self._setup(csv_file, train, test, add_comments, num_comms, n_pairs, seed, resolution, context)
+
+
+class VideoDatasetSegments(_ReferenceNamedDataset):
+    """dataset_loaders/dataset_loaders.py:440-566 (constructor keywords :449-467): 8-frame segments."""
+    _kind = "video"
+    _default_pairs = 200
+
+    def __init__(self, csv_file, root="", train=True, test=False, add_comments="train_only", num_comms=2,
+                 comment_sampling="random", use_kinetics_train=None, kinetics_csv=None, kinetics_root=None,
+                 use_howto100m_train=None, howto100m_csv=None, howto100m_root=None, first_frame_only=False,
+                 test_on_over_k_comms=None, test_set_limit=None, n_pairs=None, seed=123, resolution=224, context=77,
+                 nframes=8):
+        if use_kinetics_train or use_howto100m_train:
+            raise NotImplementedError("VideoDatasetSegments: Kinetics / HowTo100M mixing needs real video files")
+        self.root, self.first_frame_only = root, first_frame_only
+        self._setup(csv_file, train, test, add_comments, num_comms, n_pairs, seed, resolution, context, nframes)
+
+    def __getitem__(self, i):
+        vis, title, comments, meta = super().__getitem__(i)
+        if self.first_frame_only:                              # dataset_loaders.py:543-544
+            vis = vis[0]
+        return vis, title, comments, meta

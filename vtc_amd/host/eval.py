@@ -7,7 +7,9 @@ Same flags, same result JSON keys (R{1,5,10}_title_from_im / _im_from_title, :13
 loop semantics (encode every pair, stack, Recall@K both directions).  Differences, all inside the
 hot path's boundary: embeddings stay on the GPU between batches instead of a D2H per batch
 (:114-115), the k-NN runs in libvtc_hip.so instead of faiss, and the dataset ``type`` may be
-``SyntheticPairs`` so that the configs need no csv/images."""
+``SyntheticPairs``; the reference's own ``ImTextDataset`` / ``VideoDatasetSegments`` names resolve too and, with the
+empty ``csv_file`` the reference's configs ship with, yield synthetic pairs of the same tensor contract
+(vtc_amd/host/datasets.py), so ``configs/pretrained_clip*.jsonc`` run unmodified."""
 from __future__ import annotations
 
 import argparse
@@ -22,6 +24,28 @@ from . import datasets as module_data
 from . import model as module_arch
 from .metric import RecallAtK
 from .parse_config import ConfigParser
+
+
+def add_irrelevant_comms(comments: torch.Tensor, num_irrelevant_comments: int) -> torch.Tensor:
+    """evaluation/eval.py:23-47: append ``num_irrelevant_comments`` comments drawn from other items of the batch
+    ("all additional comments come from different elements in the batch").  Same numpy draws in the same order
+    (comment indices first, then one batch index per comment, re-drawn once when it hits the item itself).  The
+    reference's body cannot run as written -- ``torch.cat([comments[i], new_comm_list], 0)`` concatenates a tensor
+    with a list and ``return`` sits inside the loop, after item 0 -- so this is its documented intent applied to
+    every item, on the token ids (before the hot path)."""
+    import numpy as np
+    bs, nc, ntok = comments.shape
+    out = torch.zeros((bs, nc + num_irrelevant_comments, ntok), dtype=comments.dtype)
+    for i in range(bs):
+        comm_indices = np.random.randint(low=0, high=nc, size=num_irrelevant_comments)
+        extra = []
+        for comm_ind in comm_indices:
+            batch_ind = int(np.random.randint(low=0, high=bs, size=[1])[0])
+            if batch_ind == i:
+                batch_ind = int(np.random.randint(low=0, high=bs, size=[1])[0])
+            extra.append(comments[batch_ind, comm_ind])
+        out[i] = torch.cat([comments[i], torch.stack(extra)], 0) if extra else comments[i]
+    return out.long()
 
 
 def main(config: ConfigParser, args, checkpoint_path=None, device="cuda"):
@@ -46,11 +70,22 @@ def main(config: ConfigParser, args, checkpoint_path=None, device="cuda"):
     if checkpoint_path is not None:
         checkpoint = torch.load(checkpoint_path, map_location="cpu")
         model.load_state_dict(checkpoint["state_dict"])            # strict, eval.py:90-91
-    model = model.eval().to(device)
+    if checkpoint_path is None and not module_arch.clip_arch.pretrained_weights_available():
+        logging.warning("zero-shot eval WITHOUT pretrained CLIP weights: VTC_CLIP_WEIGHTS is unset, the towers are randomly "
+                        "initialised and the recall numbers are meaningless (the reference's clip.load downloads ViT-B/32)")
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)            # launches go to the tensors' device anyway (ops.on_device); this keeps torch's
+    model = model.eval().to(device)           # own allocations and the default stream on it too
+    num_irrelevant_comments = getattr(args, "num_irrelevant_comments", 0)
 
     res_vis, res_text = [], []
     with torch.no_grad():
         for vis, title, comments, meta in loader:
+            if num_irrelevant_comments:
+                assert num_irrelevant_comments <= config["batch_size"], \
+                    "Number of irrelevant comments needs to be smaller than batch size."        # eval.py:105-107
+                comments = add_irrelevant_comms(comments, num_irrelevant_comments)
             out = model.forward(vis.to(device), title.to(device), comments.to(device))
             res_vis.append(out[0])
             res_text.append(out[1])
@@ -76,10 +111,8 @@ def cli(argv=None):
     ap.add_argument("--ac", "--add_comments", dest="ac", type=str, default=None)
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--workers", type=int, default=0)
-    ap.add_argument("--n_pairs", type=int, default=None, help="SyntheticPairs only: number of pairs")
+    ap.add_argument("--n_pairs", type=int, default=None, help="synthetic datasets only: number of pairs")
     args = ap.parse_args(argv)
-    if args.num_irrelevant_comments:
-        raise NotImplementedError("--num_irrelevant_comments (evaluation/eval.py:23-47) is an ablation outside the hot path")
     mods = {"batch_size": args.bs, "arch;args;branch_to_adapt_val": args.bv, "dataset;args;num_comms": args.nc,
             "arch;args;comment_fusion": args.am, "dataset;args;add_comments": args.ac, "dataset;args;n_pairs": args.n_pairs}
     config = ConfigParser.from_file(args.config, resume=args.resume, modification=mods)

@@ -63,12 +63,26 @@ class RecallAtK(BaseMetric):
     def _dev(self):
         return self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
 
-    def topk_ids(self, features_a, features_b) -> torch.Tensor:
+    def _prep(self, features_a, features_b):
+        """fp32 [N, D] on the GPU; D zero-padded to the sweep's granule of 64 (squared L2 distances are unchanged;
+        faiss.IndexFlatL2 takes any D), depth = max(k) + 1 (metric.py:145) capped by the gallery size."""
         a = torch.as_tensor(features_a, dtype=torch.float32).to(self._dev())
         b = torch.as_tensor(features_b, dtype=torch.float32).to(self._dev())
         if a.dim() != 2 or b.dim() != 2:
             raise ValueError("RecallAtK.compute expects 2-D [N, D] features (one caption per video, SURVEY 3.3)")
+        if a.shape[1] != b.shape[1]:
+            raise ValueError(f"RecallAtK: feature dims differ ({a.shape[1]} vs {b.shape[1]})")
+        pad = -a.shape[1] % 64
+        if pad:
+            a, b = torch.nn.functional.pad(a, (0, pad)), torch.nn.functional.pad(b, (0, pad))
         depth = min(int(np.max(self.k_vals) + 1), a.shape[0])
+        if depth > 64:
+            raise ValueError(f"RecallAtK: max(k_vals) + 1 = {depth} exceeds the sweep's list depth of 64 (one entry per lane of "
+                             "a wavefront); the reference's callers use k in {1, 5, 10}")
+        return a, b, depth
+
+    def topk_ids(self, features_a, features_b) -> torch.Tensor:
+        a, b, depth = self._prep(features_a, features_b)
         ids, _ = ops.l2_topk(a, b, depth, precision=self.precision, return_dists=False, ws=self._workspace(
             L.lib().vtc_l2_topk_workspace_bytes(a.shape[0], b.shape[0], a.shape[1], self.precision, 0), a.device))
         return ids
@@ -108,11 +122,7 @@ class RecallAtK(BaseMetric):
         min_rows = self.bidir_min_rows_f32 if self.precision == L.SWEEP_F32 else self.bidir_min_rows
         if features_a.shape[0] != features_b.shape[0] or features_a.shape[0] < min_rows:
             return self.compute(features_a, features_b), self.compute(features_b, features_a)
-        a = torch.as_tensor(features_a, dtype=torch.float32).to(self._dev())
-        b = torch.as_tensor(features_b, dtype=torch.float32).to(self._dev())
-        if a.dim() != 2 or b.dim() != 2:
-            raise ValueError("RecallAtK.compute expects 2-D [N, D] features (one caption per video, SURVEY 3.3)")
-        depth = min(int(np.max(self.k_vals) + 1), a.shape[0])
+        a, b, depth = self._prep(features_a, features_b)
         ids_b2a, _, ids_a2b, _ = ops.l2_topk_bidir(a, b, depth, precision=self.precision, return_dists=False, ws=self._workspace(
             L.lib().vtc_l2_topk_bidir_workspace_bytes(a.shape[0], b.shape[0], a.shape[1], self.precision, 0), a.device))
         return self._hits_to_recall(ids_b2a, a.shape[0]), self._hits_to_recall(ids_a2b, b.shape[0])

@@ -77,18 +77,26 @@ class PretrainedCLIPBase(nn.Module):
 
     def _encode_both(self, vis, title):
         """(visual features, title features); the two towers are independent until the CAM / similarity."""
-        enc = self.encode_image if self._video_tower else self._encode_vis
+        pk = self._pack()        # ONE signature walk per forward; the towers below use the packed structs directly
+        enc = pk["visual"].forward if self._video_tower else (lambda v: self._encode_vis(v, pk))
         if not self.overlap_towers or len(vis.shape) == 2:
-            return enc(vis), self.encode_text(title)
-        cur = torch.cuda.current_stream()
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream()
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
-            fv = enc(vis)
-        ft = self.encode_text(title)
-        cur.wait_stream(self._side)
-        fv.record_stream(cur)
+            return enc(vis), pk["text"].forward(title)
+        # The weights were packed (converted / transposed / fused) above, on the CALLER's stream, before the fork: the side stream inherits
+        # the dependency through wait_stream, and the packed tensors belong to the caller stream's allocator pool.
+        # (Packed lazily inside the fork, the conversions would be enqueued on the side stream only, and the text
+        # tower on the caller's stream could read half-converted weights.)
+        dev = vis.device
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            side = getattr(self, "_side", None)
+            if side is None or side.device != dev:
+                side = self._side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                fv = enc(vis)
+            ft = pk["text"].forward(title)
+            cur.wait_stream(side)
+            fv.record_stream(cur)
         return fv, ft
 
     def _check_mode(self, *tensors):
@@ -106,15 +114,16 @@ class PretrainedCLIPBase(nn.Module):
     def encode_text(self, text):
         return self._pack()["text"].forward(text)
 
-    def _encode_vis(self, vis):
+    def _encode_vis(self, vis, pk=None):
         """vis.ndim dispatch of model/model.py:327-338 / :459-470."""
         shp = vis.shape
         if len(shp) == 2 and shp[1] == self.feature_dim:
             return vis.float()                                   # precomputed feature
+        tower = (pk or self._pack())["visual"]
         if len(shp) == 4:
-            return self.encode_image(vis)
+            return tower.forward(vis)
         if len(shp) == 5:                                        # frames -> mean over time
-            f = self.encode_image(vis.reshape(shp[0] * shp[1], shp[2], shp[3], shp[4]))
+            f = tower.forward(vis.reshape(shp[0] * shp[1], shp[2], shp[3], shp[4]))
             return ops.mean_groups(f, shp[1])
         raise ValueError(f"unsupported visual input shape {tuple(shp)}")
 
@@ -140,7 +149,7 @@ class PretrainedCLIPBase(nn.Module):
             b, ncomms, ntoks = comments.shape
             if feats_comm is None:
                 feats_comm = self.encode_text(comments.reshape(b * ncomms, ntoks))
-            cam = self._pack()["cam"]
+            cam = self._packed["cam"] if self._packed.get("cam") is not None and feats_comm is not None else self._pack()["cam"]
             if branch == "text":
                 feats_title = cam.forward(feats_title, feats_comm, comments)
             else:

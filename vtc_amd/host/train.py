@@ -40,6 +40,8 @@ def main(config: ConfigParser, args=None, device="cuda"):
     if oc["type"] != "Adam" or float(oc["args"].get("weight_decay", 0)) != 0.0:
         raise NotImplementedError("train: optimizer must be Adam with weight_decay 0 (configs/pretrained_clip_comments_attn_frozen.jsonc)")
     torch.manual_seed(1023)                                   # train.py:34
+    if torch.device(device).type == "cuda":
+        torch.cuda.set_device(torch.device(device))
     model = config.init_obj("arch", module_arch).eval().to(device)   # towers: forward path; adapter train-mode semantics live in AdapterTrainer
     if getattr(model, "random_comment_masking", False):
         raise NotImplementedError("random_comment_masking=True (model/model.py:236-246) is not part of the slice")
@@ -83,11 +85,86 @@ def main(config: ConfigParser, args=None, device="cuda"):
     with torch.no_grad():
         for k, v in trainer.params.items():
             named[k].copy_(v.reshape(named[k].shape))         # in-place (bumps the version: the packed weights are rebuilt)
-    save = getattr(args, "save", None) or os.path.join(config["trainer"].get("save_dir", "saved/"), config["name"], "model_last.pth")
+    save = getattr(args, "save", None) or os.path.join(config["trainer"].get("save_dir", "saved/"), config["name"],
+                                                       f"checkpoint-epoch{epochs}.pth")
     os.makedirs(os.path.dirname(os.path.abspath(save)), exist_ok=True)
-    torch.save({"arch": arch["type"], "epoch": epochs, "state_dict": {k: v.cpu() for k, v in model.state_dict().items()},
-                "config": json.dumps(config.config, default=str)}, save)
+    torch.save(checkpoint_state(model, trainer, config, epochs, lr), save)
     return model, log, save
+
+
+def reference_param_groups(model, config):
+    """The optimizer parameter groups exactly as train.py:94-192 builds them (rest / final adapter @ adapter_lr /
+    CLIP final linears @ fc_lr / time layers @ time_lr, each split into decay / no-decay), so that the saved
+    optimizer state carries the parameter numbering the reference's ``optimizer.load_state_dict`` expects."""
+    cfg = config.config
+    fc_lr, time_lr, adapter_lr = cfg.get("fc_lr"), cfg.get("time_lr"), cfg.get("adapter_lr")
+    clip_final_linear = ["model.text_projection", "model.visual.proj"]
+    time_layers = ["time", "temporal"]
+    final_adapter_layers = ["final_transformer.", "final_linear.", "mask_embedding"]
+    nodecay = ["bias", ".ln", "embedding", "temporal_embed"]
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    lin = [(n, p) for n, p in named if n in clip_final_linear]
+    tim = [(n, p) for n, p in named if any(t in n for t in time_layers)]
+    ada = [(n, p) for n, p in named if any(t in n for t in final_adapter_layers)]
+    taken = {id(p) for _, p in lin + tim + ada}
+    rest = [(n, p) for n, p in named if id(p) not in taken]
+
+    def dicts(nps, lr_):
+        out = []
+        dec = [p for n, p in nps if all(t not in n for t in nodecay)]
+        nod = [p for n, p in nps if any(t in n for t in nodecay)]
+        for ps, extra in ((dec, {}), (nod, {"weight_decay": 0.0})):
+            if ps:
+                d = {"params": ps, **extra}
+                if lr_ is not None:
+                    d["lr"] = lr_
+                out.append(d)
+        return out
+
+    return dicts(rest, None) + dicts(ada, adapter_lr) + dicts(lin, fc_lr) + dicts(tim, time_lr)
+
+
+def checkpoint_state(model, trainer, config, epoch, base_lr):
+    """The reference's checkpoint (trainer/base_trainer.py:116-145): ``{arch, epoch, state_dict, optimizer,
+    lr_scheduler, monitor_best, config}``.  ``config`` is the plain dict (indexable like the reference's ConfigParser:
+    evaluation/retrieval_evaluation.py:69 reads ``checkpoint["config"]["arch"]["args"]``, base_trainer.py:161,178-189
+    read ``["arch"]``, ``["optimizer"]``, ``["lr_scheduler"]``).  ``optimizer`` / ``lr_scheduler`` are the state dicts of
+    REAL torch objects built over the reference's parameter groups, with this trainer's Adam moments (exp_avg,
+    exp_avg_sq, max_exp_avg_sq, step) put in, so ``optimizer.load_state_dict`` of the reference resumes them."""
+    import warnings
+    cfg = config.config
+    oc = cfg["optimizer"]
+    cpu_model = {n: p for n, p in model.named_parameters()}
+    groups = reference_param_groups(model, config)
+    opt = getattr(torch.optim, oc["type"])(groups, **oc["args"])
+    by_param = {id(p): n for n, p in cpu_model.items()}
+    for g in opt.param_groups:
+        for p in g["params"]:
+            n = by_param[id(p)]
+            if n in trainer.params:                            # parameters that received gradients (torch keeps no state for the others)
+                st = {"step": torch.tensor(float(trainer.t)), "exp_avg": trainer.m[n].reshape(p.shape).clone(),
+                      "exp_avg_sq": trainer.v[n].reshape(p.shape).clone()}
+                if trainer.amsgrad:
+                    st["max_exp_avg_sq"] = trainer.vmax[n].reshape(p.shape).clone()
+                opt.state[p] = st
+    sc = cfg.get("lr_scheduler")
+    sched_state = None
+    if sc is not None:
+        sched = getattr(torch.optim.lr_scheduler, sc["type"])(opt, **sc["args"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for _ in range(epoch):
+                sched.step()
+        sched_state = sched.state_dict()
+    mon = cfg.get("trainer", {}).get("monitor", "off")
+    mnt_best = 0 if mon == "off" else (float("inf") if mon.split()[0] == "min" else float("-inf"))   # base_trainer.py:27-37
+    osd = opt.state_dict()
+    for st in osd["state"].values():
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                st[k] = v.cpu()
+    return {"arch": type(model).__name__, "epoch": epoch, "state_dict": {k: v.cpu() for k, v in model.state_dict().items()},
+            "optimizer": osd, "lr_scheduler": sched_state, "monitor_best": mnt_best, "config": json.loads(json.dumps(cfg, default=str))}
 
 
 def cli(argv=None):

@@ -6,17 +6,40 @@ computation below happens in libvtc_hip.so.  Inputs must live on a ROCm GPU.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import Optional, Sequence
 
 import torch
 
 from . import _lib as L
 
-_TDT = {torch.float32: L.VTC_F32, torch.bfloat16: L.VTC_BF16}
+_TDT = {torch.float32: L.VTC_F32, torch.bfloat16: L.VTC_BF16, torch.float16: L.VTC_F16}
 
 
 def _stream() -> int:
+    """The current HIP stream of the CURRENT device -- call inside an ``on_device`` wrapper, which makes the
+    tensors' device current first."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def on_device(fn):
+    """Every launch goes to the current stream of the device its tensors live on: the wrapper checks that all GPU
+    tensor arguments share one device and makes it current for the call (the reference's entry points run on
+    ``cuda:<-d>``, evaluation/eval.py:196, without that device being the current one)."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = None
+        for a in args + tuple(kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if dev is None:
+                    dev = a.device
+                elif a.device != dev:
+                    raise RuntimeError(f"vtc_amd.{fn.__name__}: tensors on different devices ({dev} and {a.device})")
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapped
 
 
 def _gpu(t: torch.Tensor, dtype=None, name="tensor") -> torch.Tensor:
@@ -34,7 +57,7 @@ def dtype_code(dtype) -> int:
 
 
 def torch_dtype(code: int):
-    return torch.bfloat16 if code == L.VTC_BF16 else torch.float32
+    return {L.VTC_BF16: torch.bfloat16, L.VTC_F16: torch.float16}.get(code, torch.float32)
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
@@ -42,6 +65,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 
 # ---- primitives ---------------------------------------------------------------------------
+@on_device
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = L.EPI_STORE,
          out: Optional[torch.Tensor] = None, out_dtype=None, skip_mod: int = 0) -> torch.Tensor:
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  a, w: fp32 or bf16 (same dtype)."""
@@ -60,6 +84,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+@on_device
 def layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, out_dtype=torch.float32, rows: Optional[int] = None,
               row_index: Optional[torch.Tensor] = None, row_mul: int = 1) -> torch.Tensor:
     x = _gpu(x, torch.float32, "x")
@@ -72,6 +97,7 @@ def layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, out_dtype=torch
     return y
 
 
+@on_device
 def attention(qkv: torch.Tensor, n_seq: int, L_: int, heads: int, causal: bool = False, s2: int = 1, a0: int = 0,
               a1: Optional[int] = None, a2: int = 0, a3: int = 0, pstride: int = 1, cls_out: Optional[torch.Tensor] = None,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -90,6 +116,7 @@ def attention(qkv: torch.Tensor, n_seq: int, L_: int, heads: int, causal: bool =
 
 
 # ---- wrapper-level fp32 ops ---------------------------------------------------------------
+@on_device
 def normalize_rows(x: torch.Tensor) -> torch.Tensor:
     x = _gpu(x, torch.float32, "x")
     out = torch.empty_like(x)
@@ -97,6 +124,7 @@ def normalize_rows(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@on_device
 def mean_groups(x: torch.Tensor, group: int) -> torch.Tensor:
     x = _gpu(x, torch.float32, "x")
     n, d = x.shape
@@ -106,6 +134,7 @@ def mean_groups(x: torch.Tensor, group: int) -> torch.Tensor:
     return out
 
 
+@on_device
 def segment_mean(x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     """Mean of rows [offsets[g], offsets[g+1]) per group g (int32 offsets on the GPU)."""
     x = _gpu(x, torch.float32, "x")
@@ -116,6 +145,7 @@ def segment_mean(x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@on_device
 def similarity(v: torch.Tensor, t: torch.Tensor, logit_scale: torch.Tensor) -> torch.Tensor:
     v, t = _gpu(v, torch.float32, "v"), _gpu(t, torch.float32, "t")
     ls = _gpu(logit_scale.detach().reshape(1), torch.float32, "logit_scale")
@@ -125,6 +155,7 @@ def similarity(v: torch.Tensor, t: torch.Tensor, logit_scale: torch.Tensor) -> t
     return sim
 
 
+@on_device
 def clip_loss(sim: torch.Tensor) -> torch.Tensor:
     sim = _gpu(sim, torch.float32, "sim")
     n = sim.shape[0]
@@ -136,6 +167,7 @@ def clip_loss(sim: torch.Tensor) -> torch.Tensor:
 
 
 # ---- sweep --------------------------------------------------------------------------------
+@on_device
 def l2_topk(gallery: torch.Tensor, queries: torch.Tensor, depth: int, precision: int = L.SWEEP_EXACT,
             rows_per_block: int = 0, return_dists: bool = True, ws: Optional[torch.Tensor] = None):
     gallery, queries = _gpu(gallery, torch.float32, "gallery"), _gpu(queries, torch.float32, "queries")
@@ -152,6 +184,7 @@ def l2_topk(gallery: torch.Tensor, queries: torch.Tensor, depth: int, precision:
     return ids, dists
 
 
+@on_device
 def l2_topk_bidir(a: torch.Tensor, b: torch.Tensor, depth: int, precision: int = L.SWEEP_EXACT, rows_per_block: int = 0,
                   return_dists: bool = True, ws: Optional[torch.Tensor] = None):
     """Both directions from one distance matrix: (ids_b2a [n_b, depth], dists_b2a, ids_a2b [n_a, depth], dists_a2b),
@@ -173,6 +206,7 @@ def l2_topk_bidir(a: torch.Tensor, b: torch.Tensor, depth: int, precision: int =
     return ids1, d1, ids2, d2
 
 
+@on_device
 def recall_hits(ids: torch.Tensor, k_vals: Sequence[int], target_offset: int = 0,
                 hits: Optional[torch.Tensor] = None) -> torch.Tensor:
     ids = _gpu(ids, torch.int64, "ids")

@@ -67,6 +67,21 @@ BIDIR_MIN_ROWS = 14336      # as host/metric.py RecallAtK.bidir_min_rows
 BIDIR_MIN_ROWS_F32 = 4096
 
 
+def sweep_path(n_total: int, precision: int, world: int) -> str:
+    one = world == 1 and n_total >= (BIDIR_MIN_ROWS_F32 if precision == 0 else BIDIR_MIN_ROWS)
+    return "one distance matrix, row + column top-k" if one else "two searches per rank ([N/G, N] blocks)"
+
+
+def sweep_workspace_bytes(n_total: int, n_local: int, d: int, precision: int, world: int) -> int:
+    """Bytes of caller-owned workspace that sharded_recall needs for this shape (largest of the paths it may take)."""
+    from . import _lib as L
+    lib = L.lib()
+    need = lib.vtc_l2_topk_workspace_bytes(n_total, n_local, d, precision, 0)
+    if world == 1:
+        need = max(need, lib.vtc_l2_topk_bidir_workspace_bytes(n_total, n_total, d, precision, 0))
+    return int(need)
+
+
 def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_total: int, k_vals: Sequence[int],
                    rank: int, world: int,
                    topk: Optional[Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor]] = None,

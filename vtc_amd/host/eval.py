@@ -74,7 +74,7 @@ def main(config: ConfigParser, args, checkpoint_path=None, device="cuda"):
         logging.warning("zero-shot eval WITHOUT pretrained CLIP weights: VTC_CLIP_WEIGHTS is unset, the towers are randomly "
                         "initialised and the recall numbers are meaningless (the reference's clip.load downloads ViT-B/32)")
     dev = torch.device(device)
-    if dev.type == "cuda":
+    if dev.type == "cuda" and dev.index is not None:
         torch.cuda.set_device(dev)            # launches go to the tensors' device anyway (ops.on_device); this keeps torch's
     model = model.eval().to(device)           # own allocations and the default stream on it too
     num_irrelevant_comments = getattr(args, "num_irrelevant_comments", 0)

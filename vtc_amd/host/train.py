@@ -40,7 +40,7 @@ def main(config: ConfigParser, args=None, device="cuda"):
     if oc["type"] != "Adam" or float(oc["args"].get("weight_decay", 0)) != 0.0:
         raise NotImplementedError("train: optimizer must be Adam with weight_decay 0 (configs/pretrained_clip_comments_attn_frozen.jsonc)")
     torch.manual_seed(1023)                                   # train.py:34
-    if torch.device(device).type == "cuda":
+    if torch.device(device).type == "cuda" and torch.device(device).index is not None:
         torch.cuda.set_device(torch.device(device))
     model = config.init_obj("arch", module_arch).eval().to(device)   # towers: forward path; adapter train-mode semantics live in AdapterTrainer
     if getattr(model, "random_comment_masking", False):

@@ -26,9 +26,11 @@ VISION_CHUNK = 0
 # (x fp32 + h + qkv/hidden, ~8 KB per token at W = 512) stay inside the 256 MiB Infinity Cache turns the
 # HBM-bound stages (LayerNorm, attention, residual epilogues) into cache-bound ones.
 TEXT_CHUNK = int(__import__("os").environ.get("VTC_TEXT_CHUNK", "0"))
-# Text tower on ragged batches: compute only tokens 0..EOT of every sequence (identical outputs under the
-# causal mask).  Off by default: the dense path does exactly the work the reference does.
-TEXT_RAGGED = False
+# Text tower on ragged batches: compute only tokens 0..EOT of every sequence.  Identical outputs: under the causal
+# mask no token after EOT can reach the EOT feature, and every other op of the tower is per-row
+# (tests/test_gpu_towers.py::test_ragged_text_tower_equals_dense).  On by default (VTC_TEXT_RAGGED=0: the dense path,
+# which computes all 77 positions of every sequence as the reference does).
+TEXT_RAGGED = __import__("os").environ.get("VTC_TEXT_RAGGED", "1") != "0"
 # bf16 mode of the TEXT tower: the first TEXT_HALF_LAYERS blocks run with IEEE-half operands instead of bf16 (same MFMA
 # rate, same bytes, 11 significant bits instead of 8; |values| up to 65504 -- the format upstream CLIP itself runs in
 # on a GPU).  The operand-rounding floor of an all-bf16 text tower is rms 3.2e-4 / max 1.1-1.4e-3 on the unit-norm

@@ -194,6 +194,17 @@ int vtc_layernorm(const float *x, const float *g, const float *b, void *y, int r
 int vtc_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2, int a0,
                   int a1, int a2, int a3, int pstride, int dtype, void *stream);
 
+/* QKV projection + attention core in one kernel (16-bit operand formats only): what vtc_gemm(h, w_qkv, b_qkv) followed by
+ * vtc_attention computes, bit for bit, without the packed qkv matrix in HBM.  h: LayerNorm output [rows, W]; w_qkv
+ * in_proj_weight [3W, W]; out [rows, W] (operand format; same row map as vtc_attention); rows = row count of h / out.
+ * Replaces model/timesformer_clip_alt.py:50-58 (in_proj, scaling, attn) per attention branch. */
+int vtc_qkv_attention(const void *h, const void *w_qkv, const float *b_qkv, void *out, float *cls_out, int n_seq, int L, int heads,
+                      int causal, int s2, int a0, int a1, int a2, int a3, int pstride, long long rows, int dtype, void *stream);
+
+/* Which attention branches of the towers use vtc_qkv_attention instead of vtc_gemm + vtc_attention (same results): bit 0 =
+ * contiguous sequences + time branch, bit 1 = space branch.  Default 0 (or env VTC_FUSED_ATTN); process-wide. */
+int vtc_set_fused_attention(int mask);
+
 /* ---- adapter-only training step: backward + optimizer primitives, fp32 -------------------
  * Replace, for PretrainedCLIP_finaltf with frozen towers (configs/pretrained_clip_comments_attn_frozen.jsonc), what
  * torch.autograd does behind `loss.backward()` (trainer/trainer.py) for clip_loss (model/loss.py:18-22), normalize

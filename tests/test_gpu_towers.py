@@ -384,3 +384,35 @@ def test_text_tower_half_layers_statistics():
             print(f"[parity] text tower seed {wseed} half_layers={hl}: max {d.max():.3e} rms {np.sqrt((d ** 2).mean()):.3e}")
             if hl == towers.TEXT_HALF_LAYERS:
                 assert d.max() < 1e-3
+
+
+def test_towers_with_fused_qkv_attention_are_bit_identical():
+    """vtc_set_fused_attention(3): the towers take QKV projection + attention core as ONE kernel per branch (qkv_attn.hip)
+    -- ViT, dense text (causal), TimeSformer time and space branches, 8 and 16 frames.  Same roundings in the same places
+    as the two-kernel path, so the embeddings must be bit-identical to it (which the goldens / oracle pin)."""
+    from vtc_amd import _lib as L
+    from vtc_amd import towers
+    lib = L.lib()
+    a = A.VIT_B32
+    sdv = cuda_sd(A.synth_visual(a, 65, nframes=8, prefix="v."))
+    sd16 = cuda_sd(A.synth_visual(a, 66, nframes=16, prefix="v."))
+    sdi = cuda_sd(A.synth_visual(a, 67, prefix="v."))
+    sdt = cuda_sd(A.synth_text(a, 68, prefix="model."))
+    vid = A.synth_pixels((6, 8, 3, 224, 224), 1).cuda()
+    vid16 = A.synth_pixels((3, 16, 3, 224, 224), 2).cuda()
+    img = A.synth_pixels((11, 3, 224, 224), 3).cuda()
+    txt = A.synth_tokens(19, a, 4, empty_frac=0.2).cuda()
+    for dtype in (torch.bfloat16,):
+        runs = []
+        for mask in (0, 3):
+            L.check(lib.vtc_set_fused_attention(mask), "vtc_set_fused_attention")
+            try:
+                outs = [towers.PackedVision(sdv, "v.", dtype).forward(vid), towers.PackedVision(sd16, "v.", dtype).forward(vid16),
+                        towers.PackedVision(sdi, "v.", dtype).forward(img),
+                        towers.PackedText(sdt, "model.", dtype, heads=a.transformer_heads).forward(txt, ragged=False),
+                        towers.PackedText(sdt, "model.", dtype, heads=a.transformer_heads, half_layers=0).forward(txt, ragged=False)]
+                runs.append([o.clone() for o in outs])
+            finally:
+                lib.vtc_set_fused_attention(0)
+        for x, y in zip(*runs):
+            assert torch.isfinite(x).all() and torch.equal(x, y)

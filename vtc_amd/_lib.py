@@ -83,6 +83,9 @@ SIGNATURES = {
     "vtc_prof_end_regions": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "vtc_attention": (C.c_int, [vp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, vp]),
+    "vtc_qkv_attention": (C.c_int, [vp, vp, fp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_longlong, C.c_int, vp]),
+    "vtc_set_fused_attention": (C.c_int, [C.c_int]),
     # adapter-only training step (backward + optimizer primitives)
     "vtc_transpose_f32": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),
     "vtc_colsum_f32": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),

@@ -32,6 +32,12 @@ void vtc_set_error(const char *fmt, ...) {
 }
 extern "C" const char *vtc_last_error(void) { return g_err; }
 extern "C" int vtc_abi_version(void) { return 3; }
+namespace { extern std::atomic<int> g_fused_attn; }
+extern "C" int vtc_set_fused_attention(int mask) {
+  VTC_CHECK(mask >= 0 && mask <= 3, "set_fused_attention: mask %d outside [0, 3]", mask);
+  g_fused_attn.store(mask);
+  return 0;
+}
 
 int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res, const float *mean, const float *stdv, hipStream_t stream);
 int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, int T, int W, hipStream_t stream);
@@ -43,7 +49,29 @@ int launch_cam_tokens(const float *main_f, const float *comm, const int64_t *com
 int launch_cls_global_attention(const void *qkv, void *out, int n_items, int Ttok, int heads, int dtype, hipStream_t stream);
 int launch_cam_finalize(const float *Y, const float *lin, const float *main_f, float *out, int B, int Lc, int D, int init_from_avg, int act, float scale, const float *bn_mean, const float *bn_var, hipStream_t stream);
 
+bool qkv_attention_supported(int L, int heads, int W, int dtype, size_t rows);
+int launch_qkv_attention(const void *h, const void *w_qkv, const float *b_qkv, void *out, float *cls_out, int n_seq, int L, int heads,
+                         int causal, int s2, int a0, int a1, int a2, int a3, int pstride, size_t rows, int dtype, hipStream_t stream);
+
 namespace {
+
+// QKV projection + attention core in one kernel (qkv_attn.hip) instead of {QKV GEMM -> packed qkv in HBM -> attention
+// kernel}.  Bit-identical results.  Bit 0: contiguous sequences (ViT, dense text) and the time branch; bit 1: the space
+// branch.  OFF by default: measured on MI355X the fused kernel's GEMM phase runs at 0.99 PFLOP/s but its QKV -> LDS,
+// attention and store phases are serial per tile (28 % of its time with the matrix pipe idle), while the stand-alone
+// attention kernel streams its packed qkv at 4.8-5.1 TB/s -- the two-kernel path wins by 1-4 % per step.
+// vtc_set_fused_attention() / VTC_FUSED_ATTN select it.
+std::atomic<int> g_fused_attn{-1};
+int fused_attn_mask() {
+  int m = g_fused_attn.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char *e = getenv("VTC_FUSED_ATTN");
+    m = e ? atoi(e) & 3 : 0;
+    g_fused_attn.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+bool fused_attn_enabled() { return fused_attn_mask() & 1; }
 
 struct Bump {
   char *base;
@@ -86,6 +114,11 @@ int attn_part_contig(const vtc_block_w &b, float *x, void *h, void *big, int n_s
   const int rows = n_seq * L;
   ProfRegion region(VTC_PROF_REGION_ATTN);
   RUN(launch_layernorm(x, b.ln1_g, b.ln1_b, h, rows, W, dtype, nullptr, 1, false, s));
+  if (fused_attn_enabled() && qkv_attention_supported(L, heads, W, dtype, (size_t)rows)) {
+    RUN(launch_qkv_attention(h, b.qkv_w, b.qkv_b, big, nullptr, n_seq, L, heads, causal, 1, 0, L, 0, 0, 1, (size_t)rows, dtype, s));
+    RUN(gemm(big, b.out_w, b.out_b, x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+    return 0;
+  }
   RUN(gemm(h, b.qkv_w, b.qkv_b, big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
   RUN(launch_attention(big, h, nullptr, n_seq, L, heads, causal, 1, 0, L, 0, 0, 1, dtype, s));
   RUN(gemm(h, b.out_w, b.out_b, x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
@@ -195,6 +228,28 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
       RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, P, 1, dtype, s));
       RUN(launch_cls_global_attention(v.big, v.h, n_items, T, w->heads, dtype, s));
       RUN(gemm(v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+    } else if (tsf && fused_attn_enabled() && qkv_attention_supported(1 + P, w->heads, W, dtype, (size_t)rows)) {
+      // Same two branches with QKV + attention core in one kernel each (qkv_attn.hip): the attention output lands in
+      // `big` (as [rows, W]); the packed qkv matrix never exists.
+      RUN(launch_layernorm(v.x, b.lnt_g, b.lnt_b, v.h, rows, W, dtype, nullptr, 1, false, s));
+      RUN(launch_qkv_attention(v.h, b.tqkv_w, b.tqkv_b, v.big, nullptr, n_items * P, F, w->heads, 0, P, 1, T, F, 0, 1, (size_t)rows, dtype, s));
+      if (b.tout_w) {
+        RUN(gemm(v.big, b.tout_w, b.tout_b, v.h, rows, W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+        RUN(gemm(v.h, b.tfc_w, b.tfc_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, T, s));
+      } else {
+        RUN(gemm(v.big, b.tfc_w, b.tfc_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, T, s));
+      }
+      RUN(launch_layernorm(v.x, b.ln1_g, b.ln1_b, v.h, rows, W, dtype, nullptr, 1, false, s));
+      if (fused_attn_mask() & 2) {
+        RUN(launch_qkv_attention(v.h, b.qkv_w, b.qkv_b, v.big, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, 1, F, (size_t)rows, dtype, s));
+        RUN(launch_cls_mean(v.cls_tmp, v.big, dtype, n_items, F, T, W, s));
+        RUN(gemm(v.big, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+      } else {
+        RUN(gemm(v.h, b.qkv_w, b.qkv_b, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+        RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, 1, F, dtype, s));
+        RUN(launch_cls_mean(v.cls_tmp, v.h, dtype, n_items, F, T, W, s));
+        RUN(gemm(v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+      }
     } else if (tsf) {
       // temporal branch (timesformer_clip_alt.py:142-149): sequences = the F frames of one (item, patch)
       RUN(launch_layernorm(v.x, b.lnt_g, b.lnt_b, v.h, rows, W, dtype, nullptr, 1, false, s));

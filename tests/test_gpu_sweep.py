@@ -258,3 +258,30 @@ def test_stress_size_50k_bidir_equals_two_searches_and_oracle_sample(prec):
     tgt = np.arange(n)[:, None]
     for (k, r), idsn in list(zip(r_ab, [i1n] * 3)) + list(zip(r_ba, [i2n] * 3)):
         assert abs(r - float((idsn[:, :k] == tgt).any(axis=1).mean())) < 1e-12
+
+
+@pytest.mark.parametrize("scale", [1.0, 25.0])
+def test_exact_block_minima_path_on_unnormalised_and_clustered_data(scale):
+    """The block-minima EXACT path (galleries of >= 1024 rows): embeddings of very different norms (the error bound of the
+    bf16 distance keys scales with |q|^2 + max|g|^2), tight clusters (many rows inside one 2-eps window and inside one
+    64-row block: the rows the certificate must refuse and hand to the fp64 brute force), self-search (distances that
+    round negative clamp to zero).  ids == fp64 oracle on EVERY row, both directions, one-matrix and two-search forms."""
+    from vtc_amd import _lib as L
+    from vtc_amd import ops
+    rng = np.random.default_rng(77)
+    n, d = 3000, 128
+    a = rng.standard_normal((n, d)).astype(np.float32) * rng.uniform(0.2, 1.0, (n, 1)).astype(np.float32) * np.float32(scale)
+    centres = a[rng.integers(0, 40, n)]                      # 40 clusters ...
+    a[500:1500] = centres[500:1500] + np.float32(0.02 * scale) * rng.standard_normal((1000, d)).astype(np.float32)
+    a[64:128] = a[64] + np.float32(1e-3 * scale) * rng.standard_normal((64, d)).astype(np.float32)   # ... and one whole block of near-duplicates
+    b = a + np.float32(0.05 * scale) * rng.standard_normal((n, d)).astype(np.float32)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    r1 = E.l2_topk(a, b, 11, np.float64)[0]
+    r2 = E.l2_topk(b, a, 11, np.float64)[0]
+    i1, _, i2, _ = ops.l2_topk_bidir(ta, tb, 11, precision=L.SWEEP_EXACT)
+    assert np.array_equal(i1.cpu().numpy(), r1) and np.array_equal(i2.cpu().numpy(), r2)
+    j1, _ = ops.l2_topk(ta, tb, 11, precision=L.SWEEP_EXACT)
+    j2, _ = ops.l2_topk(tb, ta, 11, precision=L.SWEEP_EXACT)
+    assert np.array_equal(j1.cpu().numpy(), r1) and np.array_equal(j2.cpu().numpy(), r2)
+    s, _ = ops.l2_topk(ta, ta, 5, precision=L.SWEEP_EXACT)
+    assert np.array_equal(s.cpu().numpy(), E.l2_topk(a, a, 5, np.float64)[0])

@@ -167,8 +167,15 @@ struct GemmEpi {
   // internal: scale by exp(*scale_log) (mode 5)
   const float *scale_log = nullptr;
   int ldo = 0;                // output leading dimension (0 => N)
+  // internal: block-minima epilogue of the sweep (mode 6): no matrix is written.  Per (row, block of 64 columns): the three
+  // smallest distance keys + the fourth smallest as a bound -> rowk[4][nblk_c][M]; with colk != nullptr also per (column,
+  // block of RB rows, RB = the kernel's wave tile height) -> colk[4][nblk_r][N].
+  // key = (bits(max(d, 0)) & ~127) | index in block: a non-negative float, compared as an unsigned integer.
+  unsigned *rowk = nullptr, *colk = nullptr;
+  int nblk_c = 0, nblk_r = 0, rb = 0;
 };
-enum { EPI_PATCH = 3, EPI_L2DIST = 4, EPI_SCALE = 5 };
+enum { EPI_PATCH = 3, EPI_L2DIST = 4, EPI_SCALE = 5, EPI_L2MIN = 6 };
+#define L2MIN_PLANES 4
 
 int launch_gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype,
                 const GemmEpi &epi, hipStream_t stream);

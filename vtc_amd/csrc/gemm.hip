@@ -65,8 +65,142 @@ __device__ __forceinline__ void store16(void *o, float4 v) {
 // the caller's next barrier.  (The area is named by OFFSET and re-based on the extern array here: handed over as
 // a generic pointer, hipcc guards every LDS read behind the preceding global stores -- vmcnt waits that
 // serialise the store stream; measured -20 % on the residual shapes.)
+// ---- block-minima epilogue of the retrieval sweep (EPI_L2MIN): the distance matrix is never written ----------------------
+// A key is a NON-NEGATIVE fp32 distance (negative rounding results clamp to zero) whose low 7 mantissa bits are replaced
+// by an index inside the block: unsigned-integer order = distance order, ties by index, and min / max / med3 on the keys
+// are single VALU instructions.  An empty slot is +inf (0x7F800000).
+// (Integer min / max / med3 on the bit patterns: the float forms would each drag a canonicalising v_max_f32 x, x, x along.)
+#define VTC_L2MIN_INF 0x7F800000u
+__device__ __forceinline__ unsigned umed3(unsigned x, unsigned y, unsigned z) {
+  unsigned r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  return r;
+}
+// Sorted quadruple of the four smallest keys seen.
+struct Min4 {
+  unsigned a, b, c, d;
+  __device__ __forceinline__ void init() { a = b = c = d = VTC_L2MIN_INF; }
+  __device__ __forceinline__ void insert(unsigned k) {       // 5 VALU: a, b, c shift up around k; d = fourth smallest
+    d = min(d, max(c, k));
+    c = umed3(b, c, k);
+    b = umed3(a, b, k);
+    a = min(a, k);
+  }
+  // the four smallest of two sorted quadruples, sorted: reversed elementwise min (a bitonic sequence), then two exchange stages
+  __device__ __forceinline__ void merge(unsigned oa, unsigned ob, unsigned oc, unsigned od) {
+    const unsigned x0 = min(a, od), x1 = min(b, oc), x2 = min(c, ob), x3 = min(d, oa);
+    const unsigned y0 = min(x0, x2), y2 = max(x0, x2), y1 = min(x1, x3), y3 = max(x1, x3);
+    a = min(y0, y1); b = max(y0, y1); c = min(y2, y3); d = max(y2, y3);
+  }
+};
+
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmParams &p, int m0, int n0) {
+  static_assert(TN == 4, "a wave's columns are one 64-column block");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave / WN, wc = wave % WN;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int nbase = n0 + wc * 64, mbase = m0 + wr * TM * 16;
+  const bool cols_too = p.epi.colk != nullptr;
+  const bool interior = nbase + 64 <= p.N && mbase + TM * 16 <= p.M;     // wave-uniform: no masking needed
+  // |g|^2 (+ the offset) of the lane's 16 columns n = nbase + 16 j + 4 g + e; columns past N get no key
+  float cn[TN][4];
+  unsigned cvalid = 0;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = nbase + 16 * j + 4 * g + e;
+      const bool v = n < p.N;
+      cn[j][e] = v ? p.epi.coln[n] : 0.f;
+      cvalid |= (unsigned)v << (4 * j + e);
+    }
+  Min4 col[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) col[j][e].init();
+  const size_t rstride = (size_t)p.epi.nblk_c * p.M;     // elements between the planes (key 1, key 2, key 3, bound)
+  const int cblk = nbase >> 6;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mbase + 16 * i + l15;
+    const bool mv = m < p.M;
+    const float rn = mv ? p.epi.rown[m] : 0.f;
+    Min4 row;
+    row.init();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // a distance that rounding made negative (a query against itself: |q|^2 in fp32 minus |bf16(q)|^2) clamps to zero --
+        // as a signed-integer max, which needs no canonicalisation; its key then sorts first, as it must
+        const unsigned bits = (unsigned)max(__float_as_int((rn - 2.0f * acc[i][j][e]) + cn[j][e]), 0) & ~127u;
+        unsigned kr = bits | (unsigned)(16 * j + 4 * g + e), kc = bits | (unsigned)(16 * i + l15);
+        if (!interior) {
+          const bool v = mv && ((cvalid >> (4 * j + e)) & 1);
+          kr = v ? kr : VTC_L2MIN_INF;
+          kc = v ? kc : VTC_L2MIN_INF;
+        }
+        row.insert(kr);
+        if (cols_too) col[j][e].insert(kc);
+      }
+    // the row's 64 columns of this wave sit in the four lanes l15 + 16 g: merge (xor 16, xor 32)
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const unsigned oa = __shfl_xor(row.a, o, 64), ob = __shfl_xor(row.b, o, 64), oc = __shfl_xor(row.c, o, 64), od = __shfl_xor(row.d, o, 64);
+      row.merge(oa, ob, oc, od);
+    }
+    // lane g stores plane g (keys 1-3, bound): 16 consecutive rows each (64-byte segments).  A wave whose 64 columns lie
+    // wholly past N owns no block (its slot would be the next plane's block 0).
+    if (mv && nbase < p.N) {
+      p.epi.rowk[(size_t)g * rstride + (size_t)cblk * p.M + m] = g == 0 ? row.a : (g == 1 ? row.b : (g == 2 ? row.c : row.d));
+    }
+  }
+  if (cols_too) {
+    // a column's TM * 16 rows of this wave sit in the 16 lanes of its DPP row: butterfly (quad xor 1, xor 2, then the
+    // mirrors -- after two steps a quad is uniform, after three a half row, so a mirror pairs the right lanes)
+    const size_t cstride = (size_t)p.epi.nblk_r * p.N;
+    const int rblk = mbase / (TM * 16);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Min4 &c = col[j][e];
+#define VTC_DPPF(x, ctrl) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, 0xf, 0xf, false)
+#define VTC_STEP(ctrl) { const unsigned oa = VTC_DPPF(c.a, ctrl), ob = VTC_DPPF(c.b, ctrl), oc = VTC_DPPF(c.c, ctrl), od = VTC_DPPF(c.d, ctrl); c.merge(oa, ob, oc, od); }
+        VTC_STEP(0xB1)     // quad_perm [1,0,3,2]
+        VTC_STEP(0x4E)     // quad_perm [2,3,0,1]
+        VTC_STEP(0x141)    // row_half_mirror
+        VTC_STEP(0x140)    // row_mirror
+#undef VTC_STEP
+#undef VTC_DPPF
+      }
+      // lanes l15 = 0..3 store plane l15 of their four consecutive columns
+      const int n = nbase + 16 * j + 4 * g;
+      if (l15 < 4 && n < p.N && mbase < p.M) {
+        unsigned *dst = p.epi.colk + (size_t)l15 * cstride + (size_t)rblk * p.N + n;
+        auto pick = [&](const Min4 &q) { return l15 == 0 ? q.a : (l15 == 1 ? q.b : (l15 == 2 ? q.c : q.d)); };
+        const unsigned v0 = pick(col[j][0]), v1 = pick(col[j][1]), v2 = pick(col[j][2]), v3 = pick(col[j][3]);
+        if (n + 3 < p.N && (p.N & 3) == 0) {
+          *reinterpret_cast<uint4 *>(dst) = make_uint4(v0, v1, v2, v3);
+        } else {
+          dst[0] = v0;
+          if (n + 1 < p.N) dst[1] = v1;
+          if (n + 2 < p.N) dst[2] = v2;
+          if (n + 3 < p.N) dst[3] = v3;
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int MODE, typename OutT, int WM, int WN, int TM, int TN, int SCRATCH_PER_WAVE>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmParams &p, int m0, int n0, unsigned scratch_off) {
+  if constexpr (MODE == EPI_L2MIN) {
+    if constexpr (TN == 4) l2min_epilogue<WM, WN, TM, TN>(acc, p, m0, n0);
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -731,7 +865,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
     }
 #endif
     if (!has_next) break;
-    relax_first = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 3) == 0);   // the tile just stored took a fast path
+    relax_first = MODE != EPI_L2MIN && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 3) == 0);   // the tile just stored took a fast path
     __builtin_amdgcn_s_barrier();          // the transposition area is the next K-tile's DMA target
 #ifdef VTC_GEMM_STAMPS
     { const unsigned long long t = stamp(); ph[3] += t - tsp; tsp = t; }       // post-epilogue barrier
@@ -837,6 +971,13 @@ int run_cfg(const GemmParams &p, hipStream_t stream) {
   return run<T, MODE, OutT, 2, 2, 4, 4, 2>(p, stream);
 }
 
+// sweep epilogue: 0 = phased 256 x 256 tiles (row blocks of 128), 1 = 128 x 128 tiles, two workgroups per CU (row blocks of 64)
+int l2min_row_block(int variant) { return variant == 0 ? 128 : 64; }
+int run_l2min(const GemmParams &p, hipStream_t stream) {
+  if (p.epi.rb == 128) return run_phased<EPI_L2MIN, float, bf16_t>(p, stream);
+  return run<bf16_t, EPI_L2MIN, float, 2, 2, 4, 4, 2>(p, stream);
+}
+
 template <typename T>
 int dispatch(const GemmParams &p, hipStream_t stream) {
   const bool out_f32 = p.epi.out_dtype == VTC_F32;
@@ -852,6 +993,9 @@ int dispatch(const GemmParams &p, hipStream_t stream) {
     case EPI_PATCH: return run_cfg<T, EPI_PATCH, float>(p, stream);
     case EPI_L2DIST: return run_cfg<T, EPI_L2DIST, float>(p, stream);
     case EPI_SCALE: return run_cfg<T, EPI_SCALE, float>(p, stream);
+    case EPI_L2MIN:
+      if constexpr (sizeof(T) == 2 && !std::is_same<T, f16_t>::value) return run_l2min(p, stream);
+      break;
   }
   vtc_set_error("gemm: unknown epilogue %d", p.epi.mode);
   return 1;

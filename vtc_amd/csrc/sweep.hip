@@ -345,6 +345,159 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
   }
 }
 
+// ---- block-minima path: certified candidate sets from the per-block keys of the EPI_L2MIN epilogue ----------------------
+// keys[4][nblk][R]: for owner r (a query row; a gallery column in the transposed direction) and block blk of BW gallery
+// entries, the three smallest distance keys (the POOL) and the fourth smallest (a bound on everything else in the block).
+// With eps_r >= |approx - exact| for every entry of the row:
+//   u      = the depth-th smallest pool key of the row     (depth DISTINCT entries lie at or below it, so the exact
+//                                                           depth-th distance t satisfies t <= u + eps)
+//   theta  = u + 2 eps                                      (every true top-depth entry has approx <= t + eps <= theta)
+//   C_r    = all pool entries with key <= theta             (the candidate set handed to the fp64 re-rank)
+//   proof of completeness: if the smallest fourth-in-block key of the row is > theta, no entry outside the pool can have
+//   approx <= theta, hence C_r contains every entry with approx <= theta, hence the true top-depth.  Otherwise (or if
+//   |C_r| > 64) cand_n[r] = -1 and the row is recomputed by fp64 brute force.
+// One workgroup per 64 owners; blocks of 64 x 64 keys are transposed through LDS (coalesced 256-byte reads in, one
+// owner's 64 keys per wave read out).  Pass 1 reads plane 0 only (u is taken over block minima: still depth distinct
+// entries, a valid if slightly larger u); pass 2 reads all four planes and emits C_r with ballot compaction.
+__global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict__ keys, int R, int nblk, int bw, int n_gallery, int depth,
+                                                     const float *__restrict__ own_norm, const float *__restrict__ other_max, float kappa,
+                                                     int64_t *__restrict__ cand, int *__restrict__ cand_n) {
+  __shared__ unsigned tl[3][64 * 65];
+  __shared__ float bmin[16][64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int r0 = blockIdx.x * 64;
+  const size_t plane = (size_t)nblk * R;
+  const bool rv = r0 + lane < R;
+  const float INF = __builtin_bit_cast(float, 0x7F800000u);
+  // ---- pass 1: per owner, the two smallest block minima each lane has seen ----
+  float m1[16], m2[16];
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) m1[cc] = m2[cc] = INF;
+  // tile loads: 16-byte loads (four consecutive owners per thread, all of a chunk's loads in flight at once) when the
+  // planes' rows are 16-byte aligned, else one key per thread
+  const bool vec = (R & 3) == 0;
+  const int og = 4 * (t & 15), sub = t >> 4;
+  float bq[4] = {INF, INF, INF, INF};
+  auto load_chunk = [&](int c0, int npl) __attribute__((always_inline)) {
+    if (vec) {
+      uint4 v[4][4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int blk = c0 + sub + 16 * it;
+        const bool ok = blk < nblk && r0 + og < R;
+        const size_t o = (size_t)blk * R + r0 + og;
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl)
+          if (pl < npl) v[it][pl] = ok ? *reinterpret_cast<const uint4 *>(keys + pl * plane + o) : make_uint4(0x7F800000u, 0x7F800000u, 0x7F800000u, 0x7F800000u);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int bl = sub + 16 * it;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          if (pl < npl) {
+            tl[pl][bl * 65 + og + 0] = v[it][pl].x; tl[pl][bl * 65 + og + 1] = v[it][pl].y;
+            tl[pl][bl * 65 + og + 2] = v[it][pl].z; tl[pl][bl * 65 + og + 3] = v[it][pl].w;
+          }
+        if (npl == 4) {     // fourth-in-block keys: running min per owner, reduced over the threads at the end
+          bq[0] = fminf(bq[0], __uint_as_float(v[it][3].x)); bq[1] = fminf(bq[1], __uint_as_float(v[it][3].y));
+          bq[2] = fminf(bq[2], __uint_as_float(v[it][3].z)); bq[3] = fminf(bq[3], __uint_as_float(v[it][3].w));
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int q = 0; q < 16; ++q) {
+        const int bl = w + 4 * q, blk = c0 + bl;
+        const bool ok = blk < nblk && rv;
+        const size_t o = (size_t)blk * R + r0 + lane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          if (pl < npl) tl[pl][bl * 65 + lane] = ok ? keys[pl * plane + o] : 0x7F800000u;
+        if (npl == 4 && ok) bq[0] = fminf(bq[0], __uint_as_float(keys[3 * plane + o]));
+      }
+    }
+  };
+  for (int c0 = 0; c0 < nblk; c0 += 64) {
+    load_chunk(c0, 1);
+    __syncthreads();
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      const float k = __uint_as_float(tl[0][lane * 65 + 16 * w + cc]);
+      m2[cc] = fminf(m2[cc], fmaxf(m1[cc], k));
+      m1[cc] = fminf(m1[cc], k);
+    }
+    __syncthreads();
+  }
+  // depth-th smallest of the wave's 128 values per owner: the 64 lane minima sorted by rank counting, then the few second
+  // minima that beat the running depth-th
+  float theta[16];
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) {
+    const float v = m1[cc];
+    int rank = 0;
+#pragma unroll 4
+    for (int l = 0; l < 64; ++l) {
+      const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+      rank += (ov < v || (ov == v && l < lane)) ? 1 : 0;
+    }
+    WaveList wl;
+    wl.bd = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(rank << 2, __builtin_bit_cast(int, v)));
+    wl.bi = __builtin_amdgcn_ds_permute(rank << 2, lane);
+    wl.tau = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl.bd), depth - 1));
+    wl.tau_i = __builtin_amdgcn_readlane(wl.bi, depth - 1);
+    wl.offer(m2[cc], 64 + lane, wl.beats(m2[cc], 64 + lane), lane, depth);
+    const float u = wl.tau;
+    const int r = min(r0 + 16 * w + cc, R - 1);
+    const float eps = kappa * (own_norm[r] + *other_max);
+    theta[cc] = u + 2.0f * eps;          // u == +inf (fewer than depth pool entries) keeps theta infinite: everything is a candidate
+  }
+  // ---- pass 2: every pool entry with key <= theta, and the smallest fourth-in-block key ----
+  int cnt[16];
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) cnt[cc] = 0;
+  for (int c0 = 0; c0 < nblk; c0 += 64) {
+    load_chunk(c0, 4);
+    __syncthreads();
+    const int blk = c0 + lane;
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      const int o = 16 * w + cc;
+      const int r = r0 + o;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const unsigned k = tl[pl][lane * 65 + o];
+        const bool pass = __uint_as_float(k & ~127u) <= theta[cc] && k != 0x7F800000u;
+        const unsigned long long mask = __ballot(pass);
+        if (mask) {                                                       // wave-uniform
+          const int pos = cnt[cc] + __popcll(mask & ((1ull << lane) - 1ull));
+          if (pass && pos < 64 && r < R) cand[(size_t)r * 64 + pos] = (int64_t)blk * bw + (int)(k & 127u);
+          cnt[cc] += __popcll(mask);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // smallest fourth-in-block key per owner: the threads' running minima -> bmin[slice][owner] -> min over the slices
+  if (vec) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bmin[sub][og + e] = bq[e];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bmin[w + 4 * q][lane] = q == 0 ? bq[0] : INF;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) {
+    const int o = 16 * w + cc, r = r0 + o;
+    if (r < R && lane == 0) {
+      float bound = INF;
+      for (int sl = 0; sl < 16; ++sl) bound = fminf(bound, bmin[sl][o]);
+      // strict: an outside entry AT theta could tie with a true neighbour
+      cand_n[r] = (cnt[cc] <= 64 && bound > theta[cc]) ? cnt[cc] : -1;
+    }
+  }
+}
+
 // ---- VTC_SWEEP_EXACT ------------------------------------------------------------------------------------
 // fp64 squared distance sum_k (q_k - g_k)^2 of one (query, gallery) pair by the whole wave (lanes stride over k)
 __device__ __forceinline__ double wave_dist64(const float *__restrict__ q, const float *__restrict__ g, int d, int lane) {
@@ -369,22 +522,26 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
                                                            int ng, int d, const int64_t *__restrict__ cand, const float *__restrict__ cand_d,
                                                            int cdepth, int depth, const float *__restrict__ qn, const float *__restrict__ gmax,
                                                            float kappa, int64_t *__restrict__ ids, float *__restrict__ dists,
-                                                           int *__restrict__ flags) {   // flags[0] = count, flags[1..] = rows
+                                                           int *__restrict__ flags,      // flags[0] = count, flags[1..] = rows
+                                                           const int *__restrict__ cand_n) {    // block-minima path: the row's list holds cand_n[r] entries
+                                                                                                 // and is ALREADY certified complete (< 0: it is not); else nullptr
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= nq) return;
   const float *q = queries + (size_t)r * d;
-  const int64_t my = lane < cdepth ? cand[(size_t)r * cdepth + lane] : -1;
+  const int n_list = cand_n ? cand_n[r] : cdepth;
+  const int64_t my = lane < n_list ? cand[(size_t)r * cdepth + lane] : -1;
   double md = INFINITY;
   // Four candidates at a time: their row pieces are all requested before the first is used and the four xor
   // butterflies interleave (one candidate at a time the kernel was a chain of 32 dependent gather latencies).
   // Per candidate the arithmetic and its order are exactly wave_dist64's, so the fallback kernel forms the same doubles.
-  for (int c0 = 0; c0 < cdepth; c0 += 4) {
+  const int n_loop = cand_n ? (n_list > 0 ? n_list : 0) : cdepth;      // wave-uniform
+  for (int c0 = 0; c0 < n_loop; c0 += 4) {
     long long jj[4];
     double sacc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      jj[u] = c0 + u < cdepth ? __shfl((long long)my, c0 + u, 64) : -1;      // wave-uniform
+      jj[u] = c0 + u < n_loop ? __shfl((long long)my, c0 + u, 64) : -1;      // wave-uniform
       sacc[u] = 0.0;
     }
     for (int c = lane * 4; c < d; c += 256) {
@@ -411,7 +568,7 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
   }
   // rank among the candidates by (fp64 distance, index); absent slots sort last
   int rank = 0;
-  for (int c = 0; c < cdepth; ++c) {
+  for (int c = 0; c < n_loop; ++c) {
     const double od = __shfl(md, c, 64);
     const long long oi = __shfl((long long)my, c, 64);
     if (oi >= 0 && (od < md || (od == md && oi < (long long)my))) ++rank;
@@ -420,11 +577,16 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
     ids[(size_t)r * depth + rank] = my;
     if (dists) dists[(size_t)r * depth + rank] = (float)md;
   }
+  const int n_valid = __popcll(__ballot(my >= 0));
   if (lane == 0) {
-    bool sure = ng <= cdepth;                             // the list IS the gallery
-    if (!sure) {
+    bool sure = n_valid >= ng;                            // the list IS the gallery
+    if (cand_n) {
+      sure = sure || n_valid >= depth;                    // certified by minsel_kernel (n_list < 0 -> n_valid == 0)
+    } else if (!sure && n_valid >= depth) {
       const float eps = kappa * (qn[r] + *gmax);
-      sure = cand_d[(size_t)r * cdepth + cdepth - 1] > cand_d[(size_t)r * cdepth + depth - 1] + 2.0f * eps;
+      // everything outside the list is at least as far (approx) as its last entry
+      const float outside = n_valid >= cdepth ? cand_d[(size_t)r * cdepth + cdepth - 1] : INFINITY;
+      sure = outside > cand_d[(size_t)r * cdepth + depth - 1] + 2.0f * eps;
     }
     if (!sure) flags[1 + atomicAdd(flags, 1)] = r;
   }
@@ -434,12 +596,12 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
 // workgroup per row, a sorted (distance, index) list per wave (one entry per lane), merged by wave 0.
 __global__ __launch_bounds__(256) void exact_fallback_kernel(const float *__restrict__ queries, const float *__restrict__ gallery, int ng,
                                                              int d, int depth, const int *__restrict__ flags, int64_t *__restrict__ ids,
-                                                             float *__restrict__ dists) {
+                                                             float *__restrict__ dists, int f_first) {
   __shared__ double sd[4][64];
   __shared__ int si[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_flagged = flags[0];
-  for (int f = blockIdx.x; f < n_flagged; f += gridDim.x) {   // uniform for the workgroup; normally zero trips
+  for (int f = f_first + blockIdx.x; f < n_flagged; f += gridDim.x) {   // uniform for the workgroup; normally zero trips
   const int r = flags[1 + f];
   const float *q = queries + (size_t)r * d;
   double bd = INFINITY;
@@ -469,6 +631,124 @@ __global__ __launch_bounds__(256) void exact_fallback_kernel(const float *__rest
     }
   }
   __syncthreads();                                         // sd / si are reused by the next flagged row
+  }
+}
+
+// The same brute force spread over FB_CHUNKS workgroups per flagged row (the first FB_ROWS flagged rows; a row is a chain of
+// dependent gather latencies, so one workgroup per row takes ~10 ms at 50k): workgroup (x, y) scans gallery slice y for the
+// flagged rows x, x + gridDim.x, ... and leaves its slice's best `depth` in part_*; fallback_merge_kernel merges the slices.
+constexpr int FB_CHUNKS = 128, FB_ROWS = 256;
+__global__ __launch_bounds__(256) void exact_fallback_chunk_kernel(const float *__restrict__ queries, const float *__restrict__ gallery, int ng,
+                                                                   int d, int depth, const int *__restrict__ flags, double *__restrict__ part_d,
+                                                                   int *__restrict__ part_i) {
+  __shared__ double sd[4][64];
+  __shared__ int si[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_flagged = min(flags[0], FB_ROWS);
+  const int chunk = blockIdx.y;
+  const int per = (ng + FB_CHUNKS - 1) / FB_CHUNKS;
+  const int j_lo = chunk * per, j_hi = min(ng, j_lo + per);
+  for (int f = blockIdx.x; f < n_flagged; f += gridDim.x) {   // uniform for the workgroup; normally zero trips
+    const int r = flags[1 + f];
+    const float *q = queries + (size_t)r * d;
+    double bd = INFINITY;
+    int bi = 0x7fffffff;
+    auto offer = [&](double cv, int ci) {                   // wave-uniform candidate
+      const double tau = __shfl(bd, depth - 1, 64);
+      const int tau_i = __shfl(bi, depth - 1, 64);
+      if (!(cv < tau || (cv == tau && ci < tau_i))) return;
+      const bool less = bd < cv || (bd == cv && bi < ci);
+      const int pos = __popcll(__ballot(less));
+      const double ud = __shfl_up(bd, 1, 64);
+      const int ui = __shfl_up(bi, 1, 64);
+      if (lane > pos) { bd = ud; bi = ui; }
+      if (lane == pos) { bd = cv; bi = ci; }
+    };
+    // four gallery rows per step: their loads are all in flight before the first butterfly (same arithmetic and order as
+    // wave_dist64 per row, so a distance has the same bits whichever kernel forms it)
+    for (int j0 = j_lo + 4 * wave; j0 < j_hi; j0 += 16) {
+      double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int c = lane * 4; c < d; c += 256) {
+        const float4 a = *reinterpret_cast<const float4 *>(q + c);
+        float4 b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const float4 *>(gallery + (size_t)min(j0 + u, j_hi - 1) * d + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double e0 = (double)a.x - (double)b[u].x, e1 = (double)a.y - (double)b[u].y, e2 = (double)a.z - (double)b[u].z,
+                       e3 = (double)a.w - (double)b[u].w;
+          sacc[u] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o, 64);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + u < j_hi) offer(sacc[u], j0 + u);
+    }
+    sd[wave][lane] = bd;
+    si[wave][lane] = bi;
+    __syncthreads();
+    if (wave == 0) {
+      for (int w = 1; w < 4; ++w)
+        for (int e = 0; e < depth; ++e)
+          if (si[w][e] != 0x7fffffff) offer(sd[w][e], si[w][e]);
+      if (lane < depth) {
+        part_d[((size_t)f * FB_CHUNKS + chunk) * 64 + lane] = bd;
+        part_i[((size_t)f * FB_CHUNKS + chunk) * 64 + lane] = bi;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// one wave per flagged row (the first FB_ROWS): merge the FB_CHUNKS slice lists -- 64 candidates per step, screened against the
+// running depth-th best, the few survivors inserted one by one
+__global__ __launch_bounds__(256) void exact_fallback_merge_kernel(int depth, const int *__restrict__ flags, const double *__restrict__ part_d,
+                                                                   const int *__restrict__ part_i, int64_t *__restrict__ ids,
+                                                                   float *__restrict__ dists) {
+  const int lane = threadIdx.x & 63;
+  const int n_flagged = min(flags[0], FB_ROWS);
+  const int total = FB_CHUNKS * depth;
+  for (int f = blockIdx.x * 4 + (threadIdx.x >> 6); f < n_flagged; f += gridDim.x * 4) {
+    const int r = flags[1 + f];
+    double bd = INFINITY;
+    int bi = 0x7fffffff;
+    for (int base = 0; base < total; base += 64) {
+      const int k = base + lane;
+      const int c = k / depth, e = k - c * depth;
+      double cv = INFINITY;
+      int ci = 0x7fffffff;
+      if (k < total) {
+        cv = part_d[((size_t)f * FB_CHUNKS + c) * 64 + e];
+        ci = part_i[((size_t)f * FB_CHUNKS + c) * 64 + e];
+      }
+      const double tau0 = __shfl(bd, depth - 1, 64);
+      const int tau0_i = __shfl(bi, depth - 1, 64);
+      unsigned long long mask = __ballot(ci != 0x7fffffff && (cv < tau0 || (cv == tau0 && ci < tau0_i)));
+      while (mask) {
+        const int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const double xv = __shfl(cv, l, 64);
+        const int xi = __shfl(ci, l, 64);
+        const double tau = __shfl(bd, depth - 1, 64);
+        const int tau_i = __shfl(bi, depth - 1, 64);
+        if (!(xv < tau || (xv == tau && xi < tau_i))) continue;
+        const bool less = bd < xv || (bd == xv && bi < xi);
+        const int pos = __popcll(__ballot(less));
+        const double ud = __shfl_up(bd, 1, 64);
+        const int ui = __shfl_up(bi, 1, 64);
+        if (lane > pos) { bd = ud; bi = ui; }
+        if (lane == pos) { bd = xv; bi = xi; }
+      }
+    }
+    if (lane < depth) {
+      ids[(size_t)r * depth + lane] = bi == 0x7fffffff ? -1 : (int64_t)bi;
+      if (dists) dists[(size_t)r * depth + lane] = (float)bd;
+    }
   }
 }
 
@@ -610,8 +890,126 @@ SweepWs plan(char *ws, int ng, int nq, int d, int precision, int rows_per_block,
 
 }  // namespace
 
+struct FallbackWs {       // scratch of the chunked fp64 brute force (exact_fallback_chunk_kernel)
+  double *part_d;
+  int *part_i;
+};
+static int exact_finish(const float *gallery, const float *queries, int ng, int nq, int d, int depth, int cdepth, const int64_t *cand,
+                        const float *cand_d, const float *qn, const float *gn, float *gmax, int *flags, int64_t *ids, float *dists,
+                        hipStream_t stream, const int *cand_n, const FallbackWs *fb);
+
+// ---- VTC_SWEEP_EXACT, block-minima path ("v2") -----------------------------------------------------------------------
+// ONE plain-bf16 distance GEMM whose epilogue keeps, per (query, block of 64 gallery rows), the three smallest distances and
+// the fourth as a bound (gemm.hip, EPI_L2MIN) -- and, for vtc_l2_topk_bidir, the same per (gallery row, block of RB queries)
+// from the same accumulators; no N x N matrix is written or read.  minsel_kernel turns the block minima into a candidate set
+// that PROVABLY contains the query's true top-k (or says that it cannot), exact_rerank_kernel orders it by fp64 distances,
+// the uncertified queries are recomputed by fp64 brute force.
+namespace {
+int exact2_variant() {        // 0: 256 x 256 phased tiles (row blocks of 128); 1: 128 x 128 tiles, two workgroups per CU (row blocks of 64)
+  static const int v = [] { const char *e = getenv("VTC_SWEEP_MIN_TILE"); return e ? atoi(e) : 0; }();
+  return v;
+}
+bool exact2_enabled(int ng, int nq, int depth) {
+  static const bool off = [] { const char *e = getenv("VTC_SWEEP_EXACT_V1"); return e && e[0] == '1'; }();
+  return !off && depth <= 32 && ng >= 1024 && nq >= 1;
+}
+constexpr int CD2 = 64;       // capacity of a candidate list of the block-minima path
+// worst-case |approx - exact| of a key's distance, relative to |q|^2 + max|g|^2: two bf16 operand roundings, 2^-8 (1 + 2^-10)
+// on |q||g| <= (|q|^2 + |g|^2) / 2, i.e. on the distance; fp32 accumulation of d products and the two norms; the 7 index
+// bits of the key (2^-16 relative); the epilogue's roundings
+float exact2_kappa(int d) { return 1.0f / 256.0f * (1.0f + 1.0f / 1024.0f) + 2.0f * d / 16777216.0f + 1.0f / 65536.0f + 1e-6f; }
+
+struct Sweep2Ws {
+  float *qn, *gn, *gmax, *qmax;
+  bf16_t *qb, *gb;
+  unsigned *rowk, *colk;
+  int nblk_c, nblk_r, rb;
+  int64_t *cand, *cand2;
+  int *cand_n, *cand2_n;
+  int *flags;
+  FallbackWs fb;
+  size_t total;
+};
+Sweep2Ws plan2(char *ws, int ng, int nq, int d, bool bidir) {
+  Sweep2Ws s;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return ws ? ws + o : (char *)nullptr; };
+  s.rb = exact2_variant() == 0 ? 128 : 64;
+  s.nblk_c = cdiv(ng, 64);
+  s.nblk_r = cdiv(nq, s.rb);
+  s.qn = (float *)take((size_t)nq * 4);
+  s.gn = (float *)take((size_t)ng * 4);
+  s.gmax = (float *)take(256);
+  s.qmax = (float *)take(256);
+  s.qb = (bf16_t *)take((size_t)nq * d * 2);
+  s.gb = (bf16_t *)take((size_t)ng * d * 2);
+  s.rowk = (unsigned *)take((size_t)L2MIN_PLANES * s.nblk_c * nq * 4);
+  s.colk = bidir ? (unsigned *)take((size_t)L2MIN_PLANES * s.nblk_r * ng * 4) : nullptr;
+  s.cand = (int64_t *)take((size_t)nq * CD2 * 8);
+  s.cand_n = (int *)take((size_t)nq * 4);
+  s.cand2 = nullptr; s.cand2_n = nullptr;
+  if (bidir) {
+    s.cand2 = (int64_t *)take((size_t)ng * CD2 * 8);
+    s.cand2_n = (int *)take((size_t)ng * 4);
+  }
+  s.flags = (int *)take((size_t)(std::max(nq, bidir ? ng : 0) + 1) * 4);
+  s.fb.part_d = (double *)take((size_t)FB_ROWS * FB_CHUNKS * 64 * 8);
+  s.fb.part_i = (int *)take((size_t)FB_ROWS * FB_CHUNKS * 64 * 4);
+  s.total = off;
+  return s;
+}
+
+// gallery a [na], queries b [nb]; ids_a2b != nullptr: also the transposed direction
+int exact2_impl(const float *a, const float *b, int na, int nb, int d, int depth, int64_t *ids_b2a, float *dists_b2a, int64_t *ids_a2b,
+                float *dists_a2b, const Sweep2Ws &s, hipStream_t stream) {
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(nb, 4)), dim3(256), 0, stream, b, s.qn, nb, d);
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(na, 4)), dim3(256), 0, stream, a, s.gn, na, d);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)(((size_t)nb * d + 255) / 256)), dim3(256), 0, stream, b, s.qb, nb, d, 1, 0);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)(((size_t)na * d + 255) / 256)), dim3(256), 0, stream, a, s.gb, na, d, 1, 1);
+  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, s.gn, na, s.gmax);
+  if (ids_a2b) hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, s.qn, nb, s.qmax);
+  VTC_LAUNCH_CHECK("l2_topk prologue");
+  GemmEpi e;
+  e.mode = EPI_L2MIN; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
+  e.rowk = s.rowk; e.colk = ids_a2b ? s.colk : nullptr; e.nblk_c = s.nblk_c; e.nblk_r = s.nblk_r; e.rb = s.rb;
+  if (int rc = launch_gemm(s.qb, s.gb, nullptr, nullptr, nb, na, d, VTC_BF16, e, stream)) return rc;
+  const float kappa = exact2_kappa(d);
+  {
+    ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * s.nblk_c * nb * 4, stream);
+    hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(nb, 64)), dim3(256), 0, stream, s.rowk, nb, s.nblk_c, 64, na, depth, s.qn, s.gmax, kappa, s.cand,
+                       s.cand_n);
+  }
+  VTC_LAUNCH_CHECK("minsel");
+  if (int rc = exact_finish(a, b, na, nb, d, depth, CD2, s.cand, nullptr, s.qn, s.gn, s.gmax, s.flags, ids_b2a, dists_b2a, stream, s.cand_n, &s.fb))
+    return rc;
+  if (ids_a2b) {
+    {
+      ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * s.nblk_r * na * 4, stream);
+      hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(na, 64)), dim3(256), 0, stream, s.colk, na, s.nblk_r, s.rb, nb, depth, s.gn, s.qmax, kappa,
+                         s.cand2, s.cand2_n);
+    }
+    VTC_LAUNCH_CHECK("minsel cols");
+    return exact_finish(b, a, nb, na, d, depth, CD2, s.cand2, nullptr, s.gn, s.qn, s.qmax, s.flags, ids_a2b, dists_a2b, stream, s.cand2_n, &s.fb);
+  }
+  return 0;
+}
+}  // namespace
+
+// diagnostics (tools/sweep_v2_debug.py; not part of the public header): the raw block-minima planes of one distance GEMM.
+// qb [nb, d], gb [na, d] bf16; qn, gn fp32 squared norms; rowk [4, ceil(na / 64), nb], colk [4, ceil(nb / rb), na] (or NULL)
+extern "C" int vtc_debug_l2min(const void *qb, const void *gb, const float *qn, const float *gn, int nb, int na, int d, int rb,
+                               unsigned *rowk, unsigned *colk, void *stream) {
+  GemmEpi e;
+  e.mode = EPI_L2MIN; e.out_dtype = VTC_F32; e.rown = qn; e.coln = gn;
+  e.rowk = rowk; e.colk = colk; e.nblk_c = cdiv(na, 64); e.nblk_r = cdiv(nb, rb); e.rb = rb;
+  return launch_gemm(qb, gb, nullptr, nullptr, nb, na, d, VTC_BF16, e, (hipStream_t)stream);
+}
+
 extern "C" size_t vtc_l2_topk_workspace_bytes(int n_gallery, int n_queries, int d, int precision, int rows_per_block) {
-  return plan(nullptr, n_gallery, n_queries, d, precision, rows_per_block).total;
+  const size_t v1 = plan(nullptr, n_gallery, n_queries, d, precision, rows_per_block).total;
+  if (precision == VTC_SWEEP_EXACT && exact2_enabled(n_gallery, n_queries, 1))
+    return std::max(v1, plan2(nullptr, n_gallery, n_queries, d, false).total);     // the depth decides at call time
+  return v1;
 }
 
 // col_ids != nullptr: also the transposed direction (for every gallery row its nearest query rows), read off the same
@@ -672,18 +1070,33 @@ static int l2_topk_impl(const float *gallery, const float *queries, int ng, int 
 // top-k, recompute the others by fp64 brute force.  qn / gn: fp32 squared norms of the queries / gallery rows.
 static int exact_finish(const float *gallery, const float *queries, int ng, int nq, int d, int depth, int cdepth, const int64_t *cand,
                         const float *cand_d, const float *qn, const float *gn, float *gmax, int *flags, int64_t *ids, float *dists,
-                        hipStream_t stream) {
-  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, gn, ng, gmax);
-  // worst-case error of a split-bf16 distance, relative to |q|^2 + max|g|^2: dropped lo.lo products and the second
-  // bf16 rounding of both operands (3 * 2^-18), fp32 accumulation of 3 d products (3 d * 2^-24), fp32 row norms
-  // (d * 2^-24), the epilogue's three roundings
+                        hipStream_t stream, const int *cand_n, const FallbackWs *fb) {
+  if (!cand_n) hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, gn, ng, gmax);
+  // split-bf16 candidate lists (cand_n == nullptr): worst-case error of a split-bf16 distance, relative to |q|^2 + max|g|^2:
+  // dropped lo.lo products and the second bf16 rounding of both operands (3 * 2^-18), fp32 accumulation of 3 d products
+  // (3 d * 2^-24), fp32 row norms (d * 2^-24), the epilogue's three roundings.  (Block-minima lists arrive certified.)
   const float kappa = 3.0f / 262144.0f + 4.0f * d / 16777216.0f + 1e-6f;
   (void)hipMemsetAsync(flags, 0, sizeof(int), stream);
   hipLaunchKernelGGL(exact_rerank_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, queries, gallery, nq, ng, d, cand, cand_d, cdepth,
-                     depth, qn, gmax, kappa, ids, dists, flags);
+                     depth, qn, gmax, kappa, ids, dists, flags, cand_n);
+  int f_first = 0;
+  if (fb) {     // the first FB_ROWS uncertified rows: every row spread over FB_CHUNKS workgroups
+    hipLaunchKernelGGL(exact_fallback_chunk_kernel, dim3(64, FB_CHUNKS), dim3(256), 0, stream, queries, gallery, ng, d, depth, flags, fb->part_d,
+                       fb->part_i);
+    hipLaunchKernelGGL(exact_fallback_merge_kernel, dim3(64), dim3(256), 0, stream, depth, flags, fb->part_d, fb->part_i, ids, dists);
+    f_first = FB_ROWS;
+  }
   hipLaunchKernelGGL(exact_fallback_kernel, dim3(std::min(nq, 2048)), dim3(256), 0, stream, queries, gallery, ng, d, depth, flags, ids,
-                     dists);
+                     dists, f_first);
   VTC_LAUNCH_CHECK("l2_topk exact");
+  static const bool dbg = [] { const char *e = getenv("VTC_SWEEP_DEBUG"); return e && e[0] == '1'; }();
+  if (dbg) {   // diagnostics only: synchronises
+    int n_flagged = -1;
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(&n_flagged, flags, sizeof(int), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[sweep] exact_finish nq=%d ng=%d cdepth=%d %s: %d rows not certified -> fp64 brute force\n", nq, ng, cdepth,
+            cand_n ? "block-minima" : "split-bf16", n_flagged);
+  }
   return 0;
 }
 
@@ -697,10 +1110,15 @@ extern "C" int vtc_l2_topk(const float *gallery, const float *queries, int ng, i
   SweepWs s = plan((char *)ws, ng, nq, d, precision, rows_per_block);
   VTC_CHECK(ws && ws_bytes >= s.total, "l2_topk: workspace too small (%zu < %zu)", ws_bytes, s.total);
   if (precision != VTC_SWEEP_EXACT) return l2_topk_impl(gallery, queries, ng, nq, d, depth, precision, ids, dists, s, stream);
+  if (exact2_enabled(ng, nq, depth) && rows_per_block <= 0) {
+    Sweep2Ws s2 = plan2((char *)ws, ng, nq, d, false);
+    VTC_CHECK(ws_bytes >= s2.total, "l2_topk: workspace too small (%zu < %zu)", ws_bytes, s2.total);
+    return exact2_impl(gallery, queries, ng, nq, d, depth, ids, dists, nullptr, nullptr, s2, stream);
+  }
   // EXACT: BF16X3 candidate lists, fp64 re-rank, verified superset property, fp64 brute force for the rest
   const int cdepth = exact_cdepth(depth, ng);
   if (int rc = l2_topk_impl(gallery, queries, ng, nq, d, cdepth, VTC_SWEEP_BF16X3, s.cand, s.cand_d, s, stream)) return rc;
-  return exact_finish(gallery, queries, ng, nq, d, depth, cdepth, s.cand, s.cand_d, s.qn, s.gn, s.gmax, s.flags, ids, dists, stream);
+  return exact_finish(gallery, queries, ng, nq, d, depth, cdepth, s.cand, s.cand_d, s.qn, s.gn, s.gmax, s.flags, ids, dists, stream, nullptr, nullptr);
 }
 
 // Both retrieval directions of RecallAtK (a -> b and b -> a, evaluation/eval.py:117-127) from ONE distance matrix
@@ -708,7 +1126,10 @@ extern "C" int vtc_l2_topk(const float *gallery, const float *queries, int ng, i
 // queries = b) returns); columns give, for every a row, its nearest b rows (ids_a2b = vtc_l2_topk(gallery = b,
 // queries = a)).  Same precisions; EXACT re-ranks both candidate sets in fp64.
 extern "C" size_t vtc_l2_topk_bidir_workspace_bytes(int n_a, int n_b, int d, int precision, int rows_per_block) {
-  return plan(nullptr, n_a, n_b, d, precision, rows_per_block, true).total;
+  const size_t v1 = plan(nullptr, n_a, n_b, d, precision, rows_per_block, true).total;
+  if (precision == VTC_SWEEP_EXACT && exact2_enabled(n_a, n_b, 1) && exact2_enabled(n_b, n_a, 1))
+    return std::max(v1, plan2(nullptr, n_a, n_b, d, true).total);
+  return v1;
 }
 
 extern "C" int vtc_l2_topk_bidir(const float *a, const float *b, int n_a, int n_b, int d, int depth, int precision,
@@ -724,11 +1145,16 @@ extern "C" int vtc_l2_topk_bidir(const float *a, const float *b, int n_a, int n_
   VTC_CHECK(ws && ws_bytes >= s.total, "l2_topk_bidir: workspace too small (%zu < %zu)", ws_bytes, s.total);
   if (precision != VTC_SWEEP_EXACT)
     return l2_topk_impl(a, b, n_a, n_b, d, depth, precision, ids_b2a, dists_b2a, s, stream, ids_a2b, dists_a2b);
+  if (exact2_enabled(n_a, n_b, depth) && exact2_enabled(n_b, n_a, depth) && rows_per_block <= 0) {
+    Sweep2Ws s2 = plan2((char *)ws, n_a, n_b, d, true);
+    VTC_CHECK(ws_bytes >= s2.total, "l2_topk_bidir: workspace too small (%zu < %zu)", ws_bytes, s2.total);
+    return exact2_impl(a, b, n_a, n_b, d, depth, ids_b2a, dists_b2a, ids_a2b, dists_a2b, s2, stream);
+  }
   const int cdepth = std::min(exact_cdepth(depth, n_a), exact_cdepth(depth, n_b));
   if (int rc = l2_topk_impl(a, b, n_a, n_b, d, cdepth, VTC_SWEEP_BF16X3, s.cand, s.cand_d, s, stream, s.cand2, s.cand2_d)) return rc;
-  if (int rc = exact_finish(a, b, n_a, n_b, d, depth, cdepth, s.cand, s.cand_d, s.qn, s.gn, s.gmax, s.flags, ids_b2a, dists_b2a, stream))
+  if (int rc = exact_finish(a, b, n_a, n_b, d, depth, cdepth, s.cand, s.cand_d, s.qn, s.gn, s.gmax, s.flags, ids_b2a, dists_b2a, stream, nullptr, nullptr))
     return rc;
-  return exact_finish(b, a, n_b, n_a, d, depth, cdepth, s.cand2, s.cand2_d, s.gn, s.qn, s.qmax, s.flags, ids_a2b, dists_a2b, stream);
+  return exact_finish(b, a, n_b, n_a, d, depth, cdepth, s.cand2, s.cand2_d, s.gn, s.qn, s.qmax, s.flags, ids_a2b, dists_a2b, stream, nullptr, nullptr);
 }
 
 extern "C" int vtc_recall_hits(const int64_t *ids, int nq, int depth, int64_t target_offset, const int *k_vals, int nk,

@@ -1,6 +1,6 @@
 """Turn rocprofv3 output directories into the small summaries committed under profiles/.
 
-usage: python tools/summarize_profile.py <stats_dir> <fetch_dir> <write_dir> <out_prefix> [steps_in_stats_run]
+usage: python tools/summarize_profile.py <stats_dir> <fetch_dir> <write_dir> <out_prefix> [steps_in_stats_run] [workload_tag] [commit]
 
   <stats_dir>  rocprofv3 --kernel-trace --stats --output-format csv
   <fetch_dir>  rocprofv3 --pmc FETCH_SIZE   (separate pass)
@@ -26,16 +26,19 @@ def short(name):
     return name.replace("unsigned short", "bf16")
 
 
-BF16 = "bf16 GEMM (gemm_phased_kernel + gemm_kernel<bf16,...>)"
+BF16 = "16-bit-operand GEMM (gemm_phased_kernel + gemm_kernel<bf16 | f16_t,...> + qkv_attn_kernel)"
 
 
 def is_bf16_gemm(n):
-    return n.startswith("gemm_phased_kernel") or n.startswith("gemm_kernel<bf16")
+    return n.startswith("gemm_phased_kernel") or n.startswith("gemm_kernel<bf16") or n.startswith("gemm_kernel<f16_t") or \
+        n.startswith("qkv_attn_kernel")
 
 
 def main():
     stats_dir, fetch_dir, write_dir, out = sys.argv[1:5]
     steps = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    workload = sys.argv[6] if len(sys.argv) > 6 else None
+    commit = sys.argv[7] if len(sys.argv) > 7 else None
     rows = list(csv.DictReader(open(find(stats_dir, "*kernel_stats.csv"))))
     total = sum(int(r["TotalDurationNs"]) for r in rows)
     lines = ["# rocprofv3 --kernel-trace --stats summary", "",
@@ -81,8 +84,9 @@ def main():
         # bench.py reads this file for roofline.traffic (bytes per launch of the dominant kernel class)
         import json
         json.dump({"kernel": k, "launches": c, "read_bytes_per_launch": rd / c, "write_bytes_per_launch": wt / c,
-                   "traffic_bytes_per_launch": (rd + wt) / c,
-                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --no-extra --no-cpu`; "
+                   "traffic_bytes_per_launch": (rd + wt) / c, "workload": workload, "commit": commit,
+                   "date": __import__("datetime").datetime.utcnow().strftime("%Y-%m-%d"), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes",
+                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --no-extra --no-cpu --no-sweep`; "
                              "reads = 2 x FETCH_SIZE KiB (gfx950 correction), writes = WRITE_SIZE KiB"},
                   open(out + "_traffic.json", "w"), indent=1)
     open(out + ".md", "w").write("\n".join(lines) + "\n")

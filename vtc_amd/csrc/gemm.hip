@@ -198,6 +198,13 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
 template <typename T, int MODE, typename OutT, int WM, int WN, int TM, int TN, int SCRATCH_PER_WAVE>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmParams &p, int m0, int n0, unsigned scratch_off) {
   if constexpr (MODE == EPI_L2MIN) {
+    if (p.exp_arg & 1) {      // diagnostics (VTC_GEMM_EXP=1): the K loop alone -- the accumulators stay live, nothing is reduced or stored
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+      return;
+    }
     if constexpr (TN == 4) l2min_epilogue<WM, WN, TM, TN>(acc, p, m0, n0);
     return;
   }

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void exact_fallback_kernel(const float *__rest
 // The same brute force spread over FB_CHUNKS workgroups per flagged row (the first FB_ROWS flagged rows; a row is a chain of
 // dependent gather latencies, so one workgroup per row takes ~10 ms at 50k): workgroup (x, y) scans gallery slice y for the
 // flagged rows x, x + gridDim.x, ... and leaves its slice's best `depth` in part_*; fallback_merge_kernel merges the slices.
-constexpr int FB_CHUNKS = 128, FB_ROWS = 256;
+constexpr int FB_CHUNKS = 512, FB_ROWS = 256, FB_SLOT = 32;   // FB_SLOT >= the largest depth of the block-minima path
 __global__ __launch_bounds__(256) void exact_fallback_chunk_kernel(const float *__restrict__ queries, const float *__restrict__ gallery, int ng,
                                                                    int d, int depth, const int *__restrict__ flags, double *__restrict__ part_d,
                                                                    int *__restrict__ part_i) {
@@ -697,8 +697,8 @@ __global__ __launch_bounds__(256) void exact_fallback_chunk_kernel(const float *
         for (int e = 0; e < depth; ++e)
           if (si[w][e] != 0x7fffffff) offer(sd[w][e], si[w][e]);
       if (lane < depth) {
-        part_d[((size_t)f * FB_CHUNKS + chunk) * 64 + lane] = bd;
-        part_i[((size_t)f * FB_CHUNKS + chunk) * 64 + lane] = bi;
+        part_d[((size_t)f * FB_CHUNKS + chunk) * FB_SLOT + lane] = bd;
+        part_i[((size_t)f * FB_CHUNKS + chunk) * FB_SLOT + lane] = bi;
       }
     }
     __syncthreads();
@@ -723,8 +723,8 @@ __global__ __launch_bounds__(256) void exact_fallback_merge_kernel(int depth, co
       double cv = INFINITY;
       int ci = 0x7fffffff;
       if (k < total) {
-        cv = part_d[((size_t)f * FB_CHUNKS + c) * 64 + e];
-        ci = part_i[((size_t)f * FB_CHUNKS + c) * 64 + e];
+        cv = part_d[((size_t)f * FB_CHUNKS + c) * FB_SLOT + e];
+        ci = part_i[((size_t)f * FB_CHUNKS + c) * FB_SLOT + e];
       }
       const double tau0 = __shfl(bd, depth - 1, 64);
       const int tau0_i = __shfl(bi, depth - 1, 64);
@@ -953,8 +953,8 @@ Sweep2Ws plan2(char *ws, int ng, int nq, int d, bool bidir) {
     s.cand2_n = (int *)take((size_t)ng * 4);
   }
   s.flags = (int *)take((size_t)(std::max(nq, bidir ? ng : 0) + 1) * 4);
-  s.fb.part_d = (double *)take((size_t)FB_ROWS * FB_CHUNKS * 64 * 8);
-  s.fb.part_i = (int *)take((size_t)FB_ROWS * FB_CHUNKS * 64 * 4);
+  s.fb.part_d = (double *)take((size_t)FB_ROWS * FB_CHUNKS * FB_SLOT * 8);
+  s.fb.part_i = (int *)take((size_t)FB_ROWS * FB_CHUNKS * FB_SLOT * 4);
   s.total = off;
   return s;
 }
@@ -1081,7 +1081,7 @@ static int exact_finish(const float *gallery, const float *queries, int ng, int 
                      depth, qn, gmax, kappa, ids, dists, flags, cand_n);
   int f_first = 0;
   if (fb) {     // the first FB_ROWS uncertified rows: every row spread over FB_CHUNKS workgroups
-    hipLaunchKernelGGL(exact_fallback_chunk_kernel, dim3(64, FB_CHUNKS), dim3(256), 0, stream, queries, gallery, ng, d, depth, flags, fb->part_d,
+    hipLaunchKernelGGL(exact_fallback_chunk_kernel, dim3(16, FB_CHUNKS), dim3(256), 0, stream, queries, gallery, ng, d, depth, flags, fb->part_d,
                        fb->part_i);
     hipLaunchKernelGGL(exact_fallback_merge_kernel, dim3(64), dim3(256), 0, stream, depth, flags, fb->part_d, fb->part_i, ids, dists);
     f_first = FB_ROWS;

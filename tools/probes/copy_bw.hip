@@ -79,6 +79,14 @@ int main() {
     snprintf(nm, 96, "chunked U=4, %d blocks/CU", bpc);
     run(nm, [&] { hipLaunchKernelGGL((copy_chunk_kernel<4>), dim3(blocks), dim3(256), 0, 0, src, dst, n); }, bytes);
   }
-  // read-only and write-only rates
+  // a smaller working set (two 256 MiB buffers) and simple one-float4-per-thread copies, as most published probes are
+  for (size_t mb : {256, 1024}) {
+    const size_t nb = mb << 20, nn = nb / 16;
+    char nm[96];
+    snprintf(nm, 96, "one float4 per thread, %zu MiB buffers", mb);
+    run(nm, [&] { hipLaunchKernelGGL((copy_kernel<1, false, false>), dim3((unsigned)(nn / 256)), dim3(256), 0, 0, src, dst, nn); }, nb);
+    snprintf(nm, 96, "hipMemcpyDtoD, %zu MiB", mb);
+    run(nm, [&] { (void)hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, 0); }, nb);
+  }
   return 0;
 }

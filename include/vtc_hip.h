@@ -185,6 +185,16 @@ enum { VTC_EPI_STORE = 0,   /* out = acc + bias                      (out dtype 
 /* out[M,N] = epi(A[M,K] @ W[N,K]^T + bias).  A, W in `dtype`; K % 64 == 0 (bf16) / % 32 (fp32). */
 int vtc_gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype,
              int epilogue, int out_dtype, int skip_mod, void *stream);
+/* Residual GEMM + the LayerNorm that follows it, one launch (16-bit operand formats; N a multiple of 256, <= 1024; problems
+ * large enough for the 256 x 256 kernel -- ask vtc_gemm_resid_layernorm_supported):  out(fp32) += A W^T + bias with rows
+ * m % skip_mod == 0 untouched, then ln_out[M,N] (operand format) = LayerNorm(out) * ln_g + ln_b.  Bit-identical to
+ * vtc_gemm(VTC_EPI_RESID) + vtc_layernorm.  Replaces e.g. `x = x + attn(...)` followed by `ln_2(x)`
+ * (model/timesformer_clip_alt.py:173-174).  ln_out may alias A (a row block's A rows are dead when its LayerNorm runs). */
+size_t vtc_gemm_resid_layernorm_workspace_bytes(int M);
+int vtc_gemm_resid_layernorm_supported(int M, int N, int K, int dtype);
+int vtc_gemm_resid_layernorm(const void *A, const void *W, const float *bias, float *out, int M, int N, int K, int dtype,
+                             int skip_mod, const float *ln_g, const float *ln_b, void *ln_out, void *ws, size_t ws_bytes,
+                             void *stream);
 /* y[r,:] = LN(x[row(r),:]) * g + b, row(r) = row_index ? row_index[r] : r * row_mul; out dtype selectable */
 int vtc_layernorm(const float *x, const float *g, const float *b, void *y, int rows, int width, int out_dtype,
                   const int *row_index, int row_mul, void *stream);

@@ -356,3 +356,37 @@ def test_fused_qkv_attention_equals_gemm_plus_attention(dtype, heads):
     h = torch.randn(B * T, W, generator=g).cuda().to(dtype)
     got, want, _, _ = both(h, B * P, F, s2=P, a0=1, a1=T, a2=F, a3=0, pstride=1)
     assert torch.equal(got.reshape(B, T, W)[:, 1:], want.reshape(B, T, W)[:, 1:])
+
+
+# ---- residual GEMM + the following LayerNorm in one launch (EPI_RESID_LN) ------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,skip", [(100608, 768, 768, 393), (100608, 768, 3072, 0), (118272, 512, 512, 0), (56789, 512, 2048, 0),
+                                        (70001, 1024, 256, 7)])
+def test_gemm_resid_layernorm_equals_two_launches(dtype, M, N, K, skip):
+    """vtc_gemm_resid_layernorm == vtc_gemm(RESID) then vtc_layernorm, BIT FOR BIT, on the tower shapes (W = 768: three
+    column tiles per row block; W = 512: two; 1024: four), ragged M, the cls-row skip of the temporal branch.  The LayerNorm is
+    done by whichever column tile of a 256-row block finishes last, reading the block back through write-through stores and
+    L1-bypassing loads: run several times (different arrival orders) and with the consumer's caches warm (the residual rows
+    are read by plain loads just before: Guideline 16, Pitfall 3)."""
+    L, ops = _ops()
+    g = torch.Generator().manual_seed(M % 1000 + N)
+    a = torch.randn(M, K, generator=g).cuda().to(dtype)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda().to(dtype)
+    b = torch.randn(N, generator=g).cuda()
+    ln_g, ln_b = torch.randn(N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+    x0 = (torch.randn(M, N, generator=g) * 2).cuda()
+    x_ref = x0.clone()
+    ops.gemm(a, w, b, epilogue=L.EPI_RESID, out=x_ref, skip_mod=skip)
+    h_ref = ops.layernorm(x_ref, ln_g, ln_b, out_dtype=dtype)
+    for rep in range(4):
+        x = x0.clone()
+        warm = float(x.sum())                                  # plain loads of every line first
+        h = ops.gemm_resid_layernorm(a, w, b, x, ln_g, ln_b, skip_mod=skip)
+        assert torch.equal(x, x_ref), (rep, float((x - x_ref).abs().max()))
+        assert torch.equal(h, h_ref), (rep, int((h != h_ref).sum()), float((h.float() - h_ref.float()).abs().max()))
+    # in place: ln_out aliases the A operand (what the towers do)
+    x = x0.clone()
+    a2 = a.clone() if K == N else None
+    if a2 is not None:
+        ops.gemm_resid_layernorm(a2, w, b, x, ln_g, ln_b, skip_mod=skip, ln_out=a2)
+        assert torch.equal(x, x_ref) and torch.equal(a2, h_ref)

@@ -77,6 +77,9 @@ SIGNATURES = {
     "vtc_l2_topk_bidir": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, fp, ip, fp, vp, C.c_size_t, vp]),
     "vtc_recall_hits": (C.c_int, [ip, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int), C.c_int, vp, vp]),
     "vtc_gemm": (C.c_int, [vp, vp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "vtc_gemm_resid_layernorm_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "vtc_gemm_resid_layernorm_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vtc_gemm_resid_layernorm": (C.c_int, [vp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, vp, vp, C.c_size_t, vp]),
     "vtc_layernorm": (C.c_int, [fp, fp, fp, vp, C.c_int, C.c_int, C.c_int, ip, C.c_int, vp]),
     "vtc_prof_begin": (C.c_int, []),
     "vtc_prof_end": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),

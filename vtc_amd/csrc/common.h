@@ -173,12 +173,19 @@ struct GemmEpi {
   // key = (bits(max(d, 0)) & ~127) | index in block: a non-negative float, compared as an unsigned integer.
   unsigned *rowk = nullptr, *colk = nullptr;
   int nblk_c = 0, nblk_r = 0, rb = 0;
+  // internal: residual epilogue + the FOLLOWING LayerNorm (mode 7; 16-bit operands, N a multiple of 256, N <= 1024): the column
+  // tile that finishes a 256-row block last normalises the block's rows (LN(out) * ln_g + ln_b -> ln_out, operand format).
+  // ln_cnt: one arrival counter per row block, zeroed by the launcher.
+  const float *ln_g = nullptr, *ln_b = nullptr;
+  void *ln_out = nullptr;
+  int *ln_cnt = nullptr;
 };
-enum { EPI_PATCH = 3, EPI_L2DIST = 4, EPI_SCALE = 5, EPI_L2MIN = 6 };
+enum { EPI_PATCH = 3, EPI_L2DIST = 4, EPI_SCALE = 5, EPI_L2MIN = 6, EPI_RESID_LN = 7 };
 #define L2MIN_PLANES 4
 
 int launch_gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype,
                 const GemmEpi &epi, hipStream_t stream);
+bool gemm_resid_ln_supported(int M, int N, int K, int dtype);
 int launch_layernorm(const float *x, const float *g, const float *b, void *y, int rows, int width, int out_dtype,
                      const int *row_index, int row_mul, bool no_norm, hipStream_t stream);
 int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2,

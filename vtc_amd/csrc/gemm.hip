@@ -33,6 +33,7 @@
 //     1024 output rows x all columns, so the weight panels and the activation panels in flight stay
 //     resident in that XCD's 4 MiB L2.
 #include "gemm_common.h"
+#include "ln_row.h"
 
 using namespace vtcgemm;
 
@@ -223,7 +224,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
 #ifndef VTC_NT_MASK
 #define VTC_NT_MASK 3
 #endif
-  constexpr bool nt_out = (VTC_NT_MASK >> (MODE == EPI_L2DIST ? 0 : MODE == VTC_EPI_RESID ? 2 : sizeof(OutT) == 2 ? 1 : 3)) & 1;
+  constexpr bool nt_out = (VTC_NT_MASK >> (MODE == EPI_L2DIST ? 0 : (MODE == VTC_EPI_RESID || MODE == EPI_RESID_LN) ? 2 : sizeof(OutT) == 2 ? 1 : 3)) & 1;
   // Interior tiles (every tile of the towers) take the transposed fast epilogue; edge tiles the generic one.
   const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && vec_ok;
   // ---- epilogue: lane holds out[m][n..n+3], m = m0 + 16 (wr TM + i) + (lane & 15),
@@ -291,6 +292,14 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       return;
     }
   }
+  // residual modes store through a wave-uniform descriptor of this tile's rows (base = row m0: 32-bit offsets whatever M)
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t out_rsrc;
+  [[maybe_unused]] const int m0u = __builtin_amdgcn_readfirstlane(m0);
+  if constexpr (MODE == EPI_RESID_LN || MODE == VTC_EPI_RESID) {
+    const size_t rem = (size_t)(p.M - m0u) * ldo * 4;
+    out_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float *>(p.out) + (size_t)m0u * ldo, 0,
+                                                 (int)(rem < 0xFFFFFFF0u ? rem : 0xFFFFFFF0u), 0x00020000);
+  }
   if (interior) {
     // Fast path (every tile of the towers).  The write path of a CU retires roughly one distinct
     // cache line per 5-8 cycles whatever its fill, so storing straight from the MFMA layout
@@ -338,6 +347,9 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       const int m = m0 + (wr * TM + pp / H) * 16 + (lane >> 4) + 4 * k;
       return reinterpret_cast<float *>(p.out) + (size_t)m * ldo + ncol0 + 64 * (pp % H) + l15 * 4;
     };
+#ifndef VTC_RESID_AUX
+#define VTC_RESID_AUX 16    // cache policy of the residual stores: 16 = sc1 (write-through)
+#endif
 #ifndef VTC_RESID_DEPTH
 #define VTC_RESID_DEPTH 2
 #endif
@@ -346,7 +358,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     // 4.35 TB/s -- the copy rate of the chip -- at depth 2, 3 and 4 alike (3 = +14 VGPRs, 4 spills)
     constexpr int XD = VTC_RESID_DEPTH;
     float4 xr[XD][4];
-    if (MODE == VTC_EPI_RESID) {
+    if (MODE == VTC_EPI_RESID || MODE == EPI_RESID_LN) {
 #pragma unroll
       for (int a = 0; a < XD - 1; ++a)
 #pragma unroll
@@ -365,7 +377,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     for (int pp = 0; pp < NP; ++pp) {
       const int i = pp / H, hh = pp % H;
       const int ncolh = ncol0 + 64 * hh;
-      if (MODE == VTC_EPI_RESID && pp + XD - 1 < NP) {
+      if ((MODE == VTC_EPI_RESID || MODE == EPI_RESID_LN) && pp + XD - 1 < NP) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) xr[(pp + XD - 1) % XD][k] = *reinterpret_cast<const float4 *>(x_ptr(pp + XD - 1, k));
       }
@@ -391,7 +403,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
           v.x = fin(v.x, cadd[hh][0]); v.y = fin(v.y, cadd[hh][1]); v.z = fin(v.z, cadd[hh][2]); v.w = fin(v.w, cadd[hh][3]);
           size_t orow = (size_t)m;
           bool live = true;
-          if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && (m % p.epi.skip_mod) == 0) live = false;
+          if ((MODE == VTC_EPI_RESID || MODE == EPI_RESID_LN) && p.epi.skip_mod > 0 && (m % p.epi.skip_mod) == 0) live = false;
           if (MODE == EPI_PATCH) {
             const int np = m % p.epi.P, ft = m / p.epi.P;
             const int tt = ft % p.epi.F, item = ft / p.epi.F;
@@ -405,12 +417,19 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
             }
           }
           float *o = reinterpret_cast<float *>(p.out) + orow * ldo + ncolh + cc;
-          if (MODE == VTC_EPI_RESID) {
+          if (MODE == EPI_RESID_LN || MODE == VTC_EPI_RESID) {
             // skipped rows are written back unchanged (a select, not a branch: an exec-masked store makes hipcc
-            // re-wait on the x prefetch after every store, which throttles the store stream)
+            // re-wait on the x prefetch after every store, which throttles the store stream).  The stores are
+            // WRITE-THROUGH (sc1) buffer stores: measured 8-10 % faster than plain global stores on the residual GEMMs of
+            // the towers (tools/resid_ln_bench.py), and what makes the rows visible to the column tile that
+            // completes the row block in EPI_RESID_LN without a release fence (MI355X_MICROARCH "Valid forms",
+            // cdna_hip_programming Guideline 16 R1)
             const float4 x = xr[pp % XD][k];
-            store16<nt_out>(o, make_float4(live ? x.x + v.x : x.x, live ? x.y + v.y : x.y, live ? x.z + v.z : x.z,
-                                           live ? x.w + v.w : x.w));
+            typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+            const float4 y = make_float4(live ? x.x + v.x : x.x, live ? x.y + v.y : x.y, live ? x.z + v.z : x.z, live ? x.w + v.w : x.w);
+            const v4u_t yy = {__float_as_uint(y.x), __float_as_uint(y.y), __float_as_uint(y.z), __float_as_uint(y.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(yy, out_rsrc, (int)((((size_t)m - m0u) * ldo + ncolh + cc) * 4), 0,
+                                                   MODE == EPI_RESID_LN ? 16 : VTC_RESID_AUX);
           } else {
             store16<nt_out>(o, v);
           }
@@ -442,7 +461,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     for (int i = 0; i < TM; ++i) {
       const int m = m0 + (wr * TM + i) * 16 + (lane & 15);
       bool live = m < p.M;
-      if (MODE == VTC_EPI_RESID && p.epi.skip_mod > 0 && live && (m % p.epi.skip_mod) == 0) live = false;
+      if ((MODE == VTC_EPI_RESID || MODE == EPI_RESID_LN) && p.epi.skip_mod > 0 && live && (m % p.epi.skip_mod) == 0) live = false;
       if (live) {
         size_t orow = (size_t)m;
         const float *posrow = nullptr, *temprow = nullptr;
@@ -469,7 +488,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
               if (MODE == EPI_PATCH) x += posrow[n + e] + (temprow ? temprow[n + e] : 0.f);
               if (MODE == EPI_L2DIST) x = (rn - 2.0f * x) + p.epi.coln[n + e];   // same rounding sequence as the interior path
               if (MODE == EPI_SCALE) x *= scale;
-              if (MODE == VTC_EPI_RESID) reinterpret_cast<float *>(o)[e] += x;
+              if (MODE == VTC_EPI_RESID || MODE == EPI_RESID_LN) reinterpret_cast<float *>(o)[e] += x;
               else ElemOps<OutT>::store(o + e, x);
             }
           }
@@ -628,6 +647,48 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(const GemmParams p
   }
 }
 
+
+// ---- EPI_RESID_LN tail: the LayerNorm that follows a residual GEMM, done by the LAST column tile of a 256-row block ---------
+// Hand-off without fences (cdna_hip_programming.md Guideline 16 R1; MI355X_MICROARCH "Valid forms", first table row): every
+// tile stores its part of the residual stream WRITE-THROUGH (sc1); each storing wave drains (vmcnt(0)), the workgroup meets at
+// a barrier, one lane adds 1 to the row block's agent-scope counter; the workgroup whose add returns NT - 1 knows that every
+// column tile of the block is stored and drained, and reads the rows back with sc1 loads ONLY (they bypass this CU's L1, the one
+// cache that can hold stale copies; no line of x is shared between column tiles: 256 columns = 8 whole lines per row).
+// Nothing waits on anything: the other tiles just leave.  Rows come 8 at a time per wave (up to 32 16-byte loads in flight).
+// (noinline: its registers are allocated apart from the K loop's, which has none to spare)
+template <typename T16>
+__device__ __attribute__((noinline)) void fused_ln_rows(const float *out, int M, int N, int m0, const float *ln_g, const float *ln_b,
+                                                        T16 *ln_out) {
+  typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(out), 0, (int)((size_t)M * N * 4), 0x00020000);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int width = N;
+  const int rows = min(256, M - m0);
+  constexpr int RB = 8;
+  for (int r0 = wave; r0 < rows; r0 += 8 * RB) {
+    // all loads of the batch are issued before the first is used: no control flow around them (rows / chunks that do not exist
+    // re-read an existing one and are dropped at the compute step)
+    float4 v[RB][LN_MAXV][2];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const int r = min(r0 + 8 * b, rows - 1);
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = min((lane + 64 * i) * 8, width - 8);
+        const int off = (int)(((size_t)(m0 + r) * width + c) * 4);
+        const v4u_t a = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 16);        // aux 16 = sc1
+        const v4u_t b4 = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off + 16, 0, 16);
+        v[b][i][0] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+        v[b][i][1] = make_float4(__uint_as_float(b4.x), __uint_as_float(b4.y), __uint_as_float(b4.z), __uint_as_float(b4.w));
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const int r = r0 + 8 * b;
+      if (r < rows) ln_row_compute<T16, false>(v[b], ln_g, ln_b, ln_out + (size_t)(m0 + r) * width, width, lane);
+    }
+  }
+}
 
 // =====================================================================================================
 // Phased 256x256 bf16 kernel -- the tower shapes (every problem that fills the chip with 256x256 tiles).
@@ -865,6 +926,15 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
 #endif
 
     tile_epilogue<T, MODE, OutT, WM, WN, TM, TN, STAGE / NW>(acc, p, m0, n0, (cur ^ 1) * STAGE);
+    if constexpr (MODE == EPI_RESID_LN) {
+      int *ticket = reinterpret_cast<int *>(lds + 2 * STAGE);       // one word behind the two stages (run_phased asks for it)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // EVERY storing wave drains its write-through stores ...
+      __syncthreads();                                             // ... before the one lane that signals for all of them
+      if (tid == 0) *ticket = __hip_atomic_fetch_add(p.epi.ln_cnt + m0 / BM, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();                                             // the add has returned before any wave loads
+      if (*ticket == p.NT - 1 && !(p.exp_arg & 2))                 // uniform: this tile completed the row block  (VTC_GEMM_EXP=2: timing without it)
+        fused_ln_rows<T>(reinterpret_cast<const float *>(p.out), p.M, p.N, m0, p.epi.ln_g, p.epi.ln_b, reinterpret_cast<T *>(p.epi.ln_out));
+    }
 #ifdef VTC_GEMM_STAMPS
     { const unsigned long long t = stamp(); ph[2] += t - tsp; tsp = t; ph[5] += 1; }   // epilogue issue
     if (!has_next && lane == 0 && p.dbg) {
@@ -872,7 +942,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
     }
 #endif
     if (!has_next) break;
-    relax_first = MODE != EPI_L2MIN && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 3) == 0);   // the tile just stored took a fast path
+    relax_first = MODE != EPI_L2MIN && MODE != EPI_RESID_LN && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 3) == 0);   // the tile just stored took a fast path
     __builtin_amdgcn_s_barrier();          // the transposition area is the next K-tile's DMA target
 #ifdef VTC_GEMM_STAMPS
     { const unsigned long long t = stamp(); ph[3] += t - tsp; tsp = t; }       // post-epilogue barrier
@@ -920,7 +990,7 @@ template <int MODE, typename OutT, typename T>
 int run_phased(GemmParams p, hipStream_t stream) {
   p.MT = cdiv(p.M, 256); p.NT = cdiv(p.N, 256);
   const int ntiles = p.MT * p.NT;
-  const size_t shmem = (size_t)2 * 512 * ROWB;          // 128 KiB: one workgroup per CU
+  const size_t shmem = (size_t)2 * 512 * ROWB + (MODE == EPI_RESID_LN ? 16 : 0);   // 128 KiB: one workgroup per CU (+ the ticket word)
   const int grid = min(ntiles, num_cus());
   static PerDeviceOnce attr;
   if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&gemm_phased_kernel<MODE, OutT, T>), (int)shmem, "gemm_phased")) return 1;
@@ -986,7 +1056,7 @@ int run_l2min(const GemmParams &p, hipStream_t stream) {
 }
 
 template <typename T>
-int dispatch(const GemmParams &p, hipStream_t stream) {
+int dispatch(GemmParams p, hipStream_t stream) {
   const bool out_f32 = p.epi.out_dtype == VTC_F32;
   using Out16 = std::conditional_t<sizeof(T) == 2, T, bf16_t>;   // 16-bit outputs are in the operand format (fp32 operands: bf16)
   switch (p.epi.mode) {
@@ -1003,12 +1073,30 @@ int dispatch(const GemmParams &p, hipStream_t stream) {
     case EPI_L2MIN:
       if constexpr (sizeof(T) == 2 && !std::is_same<T, f16_t>::value) return run_l2min(p, stream);
       break;
+    case EPI_RESID_LN:
+      if constexpr (sizeof(T) == 2) {
+        p.MT = cdiv(p.M, 256);
+        (void)hipMemsetAsync(p.epi.ln_cnt, 0, align_up((size_t)p.MT * 4, 16), stream);   // arrival counters, zeroed every launch
+        return run_phased<EPI_RESID_LN, float, T>(p, stream);
+      }
+      break;
   }
   vtc_set_error("gemm: unknown epilogue %d", p.epi.mode);
   return 1;
 }
 
 }  // namespace
+
+// The residual GEMM can take the FOLLOWING LayerNorm along (EPI_RESID_LN) when the phased 256 x 256 kernel runs it, a row
+// is a whole number of column tiles and fits ln_row.h, and the output is addressable by one buffer descriptor.
+bool gemm_resid_ln_supported(int M, int N, int K, int dtype) {
+  if (dtype != VTC_BF16 && dtype != VTC_F16) return false;
+  if (N % 256 != 0 || N > 512 * LN_MAXV || K % 64 != 0) return false;
+  if ((size_t)M * N * 4 >= ((size_t)1 << 32)) return false;
+  const long tb = (long)cdiv(M, 256) * cdiv(N, 256), ts = (long)cdiv(M, 128) * cdiv(N, 128);
+  const long rb = (tb + num_cus() - 1) / num_cus(), rs = (ts + 2 * num_cus() - 1) / (2 * num_cus());
+  return rb * 100 <= rs * 65;          // the tile heuristic of run_cfg picks the phased kernel
+}
 
 int launch_gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype,
                 const GemmEpi &epi, hipStream_t stream) {
@@ -1022,6 +1110,10 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
   VTC_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: operands must be 16-byte aligned");
   VTC_CHECK(!(epi.out_dtype != VTC_F32 && (epi.mode == VTC_EPI_RESID || epi.mode >= EPI_PATCH)),
             "gemm: epilogue %d writes fp32 only", epi.mode);
+  if (epi.mode == EPI_RESID_LN) {
+    VTC_CHECK(gemm_resid_ln_supported(M, N, K, dtype), "gemm: fused residual + LayerNorm does not cover M=%d N=%d K=%d dtype=%d", M, N, K, dtype);
+    VTC_CHECK(epi.ln_g && epi.ln_b && epi.ln_out && epi.ln_cnt && (epi.ldo == 0 || epi.ldo == N), "gemm: fused LayerNorm arguments");
+  }
   // diagnostics knobs, read once (C++11 static initialisation is thread-safe; never written afterwards)
   struct Env { int tile = 0, exp_arg = 0, sg = 0, st = 0; };
   static const Env env = [] {
@@ -1053,3 +1145,17 @@ extern "C" int vtc_gemm(const void *A, const void *W, const float *bias, void *o
   e.mode = epilogue; e.out_dtype = epilogue == VTC_EPI_RESID ? VTC_F32 : out_dtype; e.skip_mod = skip_mod;
   return launch_gemm(A, W, bias, out, M, N, K, dtype, e, (hipStream_t)stream);
 }
+
+// out(fp32 [M,N]) += A W^T + bias (rows with m % skip_mod == 0 untouched), then ln_out[M,N] (operand format) =
+// LayerNorm(out) * ln_g + ln_b -- one launch; bit-identical to vtc_gemm(VTC_EPI_RESID) followed by vtc_layernorm.
+extern "C" size_t vtc_gemm_resid_layernorm_workspace_bytes(int M) { return align_up((size_t)cdiv(M, 256) * 4, 256); }
+extern "C" int vtc_gemm_resid_layernorm(const void *A, const void *W, const float *bias, float *out, int M, int N, int K, int dtype,
+                                        int skip_mod, const float *ln_g, const float *ln_b, void *ln_out, void *ws, size_t ws_bytes,
+                                        void *stream) {
+  VTC_CHECK(ws && ws_bytes >= vtc_gemm_resid_layernorm_workspace_bytes(M), "gemm_resid_layernorm: workspace too small");
+  GemmEpi e;
+  e.mode = EPI_RESID_LN; e.out_dtype = VTC_F32; e.skip_mod = skip_mod;
+  e.ln_g = ln_g; e.ln_b = ln_b; e.ln_out = ln_out; e.ln_cnt = (int *)ws;
+  return launch_gemm(A, W, bias, out, M, N, K, dtype, e, (hipStream_t)stream);
+}
+extern "C" int vtc_gemm_resid_layernorm_supported(int M, int N, int K, int dtype) { return gemm_resid_ln_supported(M, N, K, dtype) ? 1 : 0; }

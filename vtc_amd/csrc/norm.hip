@@ -4,13 +4,13 @@
 // Replaces LayerNorm (model/timesformer_clip_alt.py:22-28, upstream LayerNorm),
 // normalize (model/model.py:26-27) and the frame / title+comment means (:338, :357-362).
 #include "common.h"
+#include "ln_row.h"
 
 namespace {
 
-constexpr int MAXV = 2;  // up to 2 chunks of 8 floats per lane => width <= 1024
-
 // One wave per row; a lane owns chunks of EIGHT consecutive columns (two 16-byte loads, and for bf16 output one
-// 16-byte store: 8-byte stores run at 0.54-0.70 of the 16-byte rate on this memory system).
+// 16-byte store: 8-byte stores run at 0.54-0.70 of the 16-byte rate on this memory system).  The arithmetic lives in
+// ln_row.h: the residual GEMM's fused LayerNorm (gemm.hip, EPI_RESID_LN) must produce the same bits.
 template <typename OutT, bool NO_NORM>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, OutT *y, int rows,
@@ -20,61 +20,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, const fl
   if (r >= rows) return;
   const size_t src = row_index ? (size_t)row_index[r] : (size_t)r * row_mul;
   const float *xr = x + src * width;
-  float4 v[MAXV][2];
-  float s = 0.f;
+  float4 v[LN_MAXV][2];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < LN_MAXV; ++i) {
     const int c = (lane + 64 * i) * 8;
     if (c < width) {
       v[i][0] = *reinterpret_cast<const float4 *>(xr + c);
       v[i][1] = *reinterpret_cast<const float4 *>(xr + c + 4);
-      s += ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
     }
   }
-  float mean = 0.f, rstd = 1.f;
-  if (!NO_NORM) {
-    mean = wave_sum(s) / width;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = (lane + 64 * i) * 8;
-      if (c < width) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const float a = v[i][h].x - mean, b = v[i][h].y - mean, cc = v[i][h].z - mean, d = v[i][h].w - mean;
-          q += (a * a + b * b) + (cc * cc + d * d);
-        }
-      }
-    }
-    rstd = 1.0f / sqrtf(wave_sum(q) / width + 1e-5f);  // nn.LayerNorm default eps, biased variance
-  }
-  OutT *yr = y + (size_t)r * width;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = (lane + 64 * i) * 8;
-    if (c < width) {
-      float o[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
-      if (!NO_NORM) {
-        const float4 g0 = *reinterpret_cast<const float4 *>(gamma + c), g1 = *reinterpret_cast<const float4 *>(gamma + c + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(beta + c), b1 = *reinterpret_cast<const float4 *>(beta + c + 4);
-        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (o[e] - mean) * rstd * gm[e] + bt[e];
-      }
-      if constexpr (sizeof(OutT) == 2) {
-        uint4 pk;
-        pk.x = (unsigned)cvt16<OutT>(o[0]) | ((unsigned)cvt16<OutT>(o[1]) << 16);
-        pk.y = (unsigned)cvt16<OutT>(o[2]) | ((unsigned)cvt16<OutT>(o[3]) << 16);
-        pk.z = (unsigned)cvt16<OutT>(o[4]) | ((unsigned)cvt16<OutT>(o[5]) << 16);
-        pk.w = (unsigned)cvt16<OutT>(o[6]) | ((unsigned)cvt16<OutT>(o[7]) << 16);
-        *reinterpret_cast<uint4 *>(yr + c) = pk;
-      } else {
-        ElemOps<OutT>::store4(yr + c, o[0], o[1], o[2], o[3]);
-        ElemOps<OutT>::store4(yr + c + 4, o[4], o[5], o[6], o[7]);
-      }
-    }
-  }
+  ln_row_compute<OutT, NO_NORM>(v, gamma, beta, y + (size_t)r * width, width, lane);
 }
 
 __global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict__ x, float *__restrict__ out, int n, int d) {
@@ -123,7 +78,7 @@ extern "C" int vtc_segment_mean(const float *x, const int *offsets, float *out, 
 int launch_layernorm(const float *x, const float *g, const float *b, void *y, int rows, int width, int out_dtype,
                      const int *row_index, int row_mul, bool no_norm, hipStream_t stream) {
   VTC_CHECK(rows > 0, "layernorm: rows=%d", rows);
-  VTC_CHECK(width % 8 == 0 && width <= 512 * MAXV, "layernorm: width=%d unsupported (multiple of 8, <= 1024)", width);
+  VTC_CHECK(width % 8 == 0 && width <= 512 * LN_MAXV, "layernorm: width=%d unsupported (multiple of 8, <= 1024)", width);
   const dim3 grid(cdiv(rows, 4)), block(256);
   ProfScope prof(VTC_PROF_NORM, (double)rows * width * (4 + (out_dtype != VTC_F32 ? 2 : 4)), stream);
   if (out_dtype == VTC_F16) {

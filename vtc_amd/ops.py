@@ -85,6 +85,26 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
 
 
 @on_device
+def gemm_resid_layernorm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, ln_g: torch.Tensor,
+                         ln_b: torch.Tensor, skip_mod: int = 0, ln_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out (fp32, in place) += a @ w^T + bias; returns LayerNorm(out) * ln_g + ln_b in a's dtype -- one launch."""
+    a, w = _gpu(a, name="a"), _gpu(w, a.dtype, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    assert out.dtype == torch.float32 and out.shape == (M, N) and out.is_contiguous()
+    lib = L.lib()
+    if not lib.vtc_gemm_resid_layernorm_supported(M, N, K, _TDT[a.dtype]):
+        raise ValueError(f"gemm_resid_layernorm: unsupported problem M={M} N={N} K={K} {a.dtype}")
+    if ln_out is None:
+        ln_out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    ws = workspace(lib.vtc_gemm_resid_layernorm_workspace_bytes(M), a.device)
+    L.check(lib.vtc_gemm_resid_layernorm(a.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), M, N, K,
+                                         _TDT[a.dtype], skip_mod, _gpu(ln_g, torch.float32).data_ptr(), _gpu(ln_b, torch.float32).data_ptr(),
+                                         ln_out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "vtc_gemm_resid_layernorm")
+    return ln_out
+
+
+@on_device
 def layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, out_dtype=torch.float32, rows: Optional[int] = None,
               row_index: Optional[torch.Tensor] = None, row_mul: int = 1) -> torch.Tensor:
     x = _gpu(x, torch.float32, "x")

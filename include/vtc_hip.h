@@ -174,6 +174,27 @@ size_t vtc_l2_topk_bidir_workspace_bytes(int n_a, int n_b, int d, int precision,
 int vtc_l2_topk_bidir(const float *a, const float *b, int n_a, int n_b, int d, int depth, int precision, int rows_per_block,
                       int64_t *ids_b2a, float *dists_b2a, int64_t *ids_a2b, float *dists_a2b, void *ws, size_t ws_bytes,
                       void *stream);
+/* Sharded sweep (one process per GPU; the reference is single-GPU, evaluation/eval.py:117-127 -> model/metric.py:137-146):
+ * rank r holds rows [lo_r, hi_r) of both embedding sets and the all-gathered sets, and runs ONE distance GEMM
+ * D_r[i][j] = |b_(lo_r + i) - a_j|^2, i < n_local, j < n_total, for BOTH directions:
+ *   vtc_l2_sweep_shard_rows   ids [n_local, depth] = vtc_l2_topk(gallery = a_all, queries = b_local) -- complete, the rank
+ *                             holds whole rows -- and col_planes [4, nblk_pad, n_total] (uint32): per column j and per block of
+ *                             vtc_l2_sweep_row_block() local rows, the three smallest distance keys and the fourth as a bound
+ *                             (blocks past the rank's rows: +inf).  nblk_pad = ceil(largest shard / row block), equal on all ranks.
+ *   (host) all-to-all: rank r sends col_planes[:, :, lo_s:hi_s] to rank s
+ *   vtc_l2_sweep_shard_cols   planes [n_src, 4, nblk_pad, n_local] = what the n_src ranks sent for this rank's columns, in
+ *                             rank order; src_base[n_src] (device int32) = lo_r of each source.  ids [n_local, depth] =
+ *                             vtc_l2_topk(gallery = b_all, queries = a_local), bit-identical to the single-GPU search
+ *                             (certified candidates re-ranked in fp64, uncertified columns by fp64 brute force).
+ * VTC_SWEEP_EXACT only; d % 64 == 0; vtc_l2_sweep_shard_supported tells whether the shape is covered (else: two vtc_l2_topk). */
+int vtc_l2_sweep_row_block(void);
+int vtc_l2_sweep_shard_supported(int n_total, int n_local, int depth);
+size_t vtc_l2_sweep_shard_workspace_bytes(int n_total, int n_local, int d);
+int vtc_l2_sweep_shard_rows(const float *a_all, const float *b_local, int n_total, int n_local, int d, int depth, int64_t *ids,
+                            float *dists, unsigned *col_planes, int nblk_pad, void *ws, size_t ws_bytes, void *stream);
+int vtc_l2_sweep_shard_cols(const float *b_all, const float *a_local, int n_total, int n_local, int d, int depth,
+                            const unsigned *planes, int n_src, int nblk_pad, const int *src_base, int64_t *ids, float *dists,
+                            void *ws, size_t ws_bytes, void *stream);
 /* hits[j] += #{ i : (target_offset + i) in ids[i, :k_vals[j]] }   (hits: int64 device) */
 int vtc_recall_hits(const int64_t *ids, int n_queries, int depth, int64_t target_offset, const int *k_vals_host,
                     int nk, long long *hits, void *stream);

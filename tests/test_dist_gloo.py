@@ -1,6 +1,7 @@
-"""CPU, world_size 2, gloo: the sharded-sweep bookkeeping of vtc_amd/dist.py (shard bounds, ragged
-all-gather, target offsets, counter all-reduce) against the oracle's unsharded Recall@K.
-The search itself is injected (oracle's CPU search); on the GPU box the HIP sweep takes its place."""
+"""CPU, world_size 2 and 3, gloo: the sharded-sweep bookkeeping of vtc_amd/dist.py (shard bounds, ragged
+all-gather, target offsets, counter all-reduce; the one-GEMM-per-rank path's column-plane exchange with
+per-source row bases and padded blocks) against the oracle's unsharded Recall@K and top-k ids.
+The searches themselves are injected (oracle CPU stand-ins); on the GPU box the HIP sweep takes their place."""
 import os
 import socket
 
@@ -44,6 +45,72 @@ def _worker(rank, world, port, n, out):
         ref_ba = dict(E.recall_at_k(b, a, [1, 5, 10]))
         out.put((r_ab == ref_ab, r_ba == ref_ba, r_ab, ref_ab))
     dist.destroy_process_group()
+
+
+RB = 8      # row block of the stand-ins (the HIP epilogue: 128)
+
+
+def _shard_ops():
+    from oracle import sweep_planes as SP
+    stats = {}
+
+    def rows_fn(a_all, b_loc, depth, nbp):
+        ids, planes = SP.shard_rows(a_all.numpy(), b_loc.numpy(), depth, nbp, RB)
+        return torch.from_numpy(ids), torch.from_numpy(planes)
+
+    def cols_fn(b_all, a_loc, depth, planes, src_base):
+        return torch.from_numpy(SP.shard_cols(b_all.numpy(), a_loc.numpy(), depth, planes.numpy(), src_base.numpy(), RB, stats))
+    return (rows_fn, cols_fn, RB), stats
+
+
+def _worker_one_matrix(rank, world, port, n, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from vtc_amd import dist as vdist
+    vdist.init_from_env(backend="gloo")
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((n, 32)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = a + 0.7 * rng.standard_normal((n, 32)).astype(np.float32)
+    b[: n // 2] /= np.linalg.norm(b[: n // 2], axis=1, keepdims=True)       # second half left un-normalised
+    lo, hi = vdist.shard_bounds(n, rank, world)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    ops3, stats = _shard_ops()
+    r_ab, r_ba = vdist.sharded_recall(ta[lo:hi], tb[lo:hi], n, [1, 5, 10], rank, world, shard_ops=ops3)
+    # the exchange by hand: ids of this rank's columns against the unsharded search
+    depth = 11
+    bounds = [vdist.shard_bounds(n, r, world) for r in range(world)]
+    nbp = -(-max(h - l for l, h in bounds) // RB)
+    i1, planes = ops3[0](ta, tb[lo:hi], depth, nbp)
+    recv = vdist.exchange_column_planes(planes, n, rank, world)
+    assert recv.shape == (world, 4, nbp, hi - lo)
+    i2 = ops3[1](tb, ta[lo:hi], depth, recv, torch.tensor([l for l, _ in bounds], dtype=torch.int32))
+    ok_ids = torch.equal(i2, _cpu_topk(tb, ta[lo:hi], depth)) and torch.equal(i1, _cpu_topk(ta, tb[lo:hi], depth))
+    flags = torch.tensor([int(ok_ids), stats.get("brute", 0), hi - lo])
+    allf = [torch.zeros_like(flags) for _ in range(world)]
+    dist.all_gather(allf, flags)
+    if rank == 0:
+        ref_ab = dict(E.recall_at_k(a, b, [1, 5, 10]))
+        ref_ba = dict(E.recall_at_k(b, a, [1, 5, 10]))
+        out.put((r_ab == ref_ab and r_ba == ref_ba, all(int(f[0]) for f in allf), sum(int(f[1]) for f in allf), (r_ab, ref_ab, r_ba, ref_ba)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(3, 601), (2, 400), (3, 101)])       # ragged shards, padded blocks (601 = 201 + 200 + 200 rows)
+def test_one_matrix_sharded_sweep_exchange(world, n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_one_matrix, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok_recall, ok_ids, brute, detail = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok_recall, detail
+    assert ok_ids
+    if n >= 400:                   # enough blocks for the certificate to hold: the exchanged planes are what was searched
+        assert brute < n // 2
 
 
 @pytest.mark.parametrize("n", [64, 101])          # even and ragged shards

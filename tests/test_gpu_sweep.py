@@ -285,3 +285,38 @@ def test_exact_block_minima_path_on_unnormalised_and_clustered_data(scale):
     assert np.array_equal(j1.cpu().numpy(), r1) and np.array_equal(j2.cpu().numpy(), r2)
     s, _ = ops.l2_topk(ta, ta, 5, precision=L.SWEEP_EXACT)
     assert np.array_equal(s.cpu().numpy(), E.l2_topk(a, a, 5, np.float64)[0])
+
+
+@pytest.mark.parametrize("n,world,d,scale", [(4099, 3, 512, 1.0), (10000, 8, 512, 1.0), (6000, 2, 128, 25.0), (50000, 8, 512, 1.0)])
+def test_sharded_one_matrix_sweep_equals_single_gpu_search(n, world, d, scale):
+    """The one-GEMM-per-rank sweep (vtc_l2_sweep_shard_rows -> exchange -> vtc_l2_sweep_shard_cols, include/vtc_hip.h),
+    the ranks played one after the other on this card with the exchange of vtc_amd/dist.py done by slicing: ids of BOTH
+    directions bit-identical to the single-GPU EXACT search (which test_stress_size... pins to the fp64 oracle)."""
+    from vtc_amd import _lib as L
+    from vtc_amd import dist as vdist
+    from vtc_amd import ops
+    a, b = planted(n, d, seed=n + world)
+    if scale != 1.0:       # un-normalised, clustered: norms differ by rows, so the per-column error bound matters
+        rng = np.random.default_rng(5)
+        a = (a * rng.uniform(0.5, scale, (n, 1))).astype(np.float32)
+        b = (b * rng.uniform(0.5, scale, (n, 1))).astype(np.float32)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    depth = 11
+    bounds = [vdist.shard_bounds(n, r, world) for r in range(world)]
+    assert all(ops.sweep_shard_supported(n, hi - lo, depth) for lo, hi in bounds)
+    rb = ops.sweep_row_block()
+    nbp = -(-max(hi - lo for lo, hi in bounds) // rb)
+    rows, planes = [], []
+    for lo, hi in bounds:
+        i1, pl = ops.sweep_shard_rows(ta, tb[lo:hi], depth, nbp)
+        rows.append(i1)
+        planes.append(pl)
+    src_base = torch.tensor([lo for lo, _ in bounds], dtype=torch.int32, device="cuda")
+    cols = []
+    for lo, hi in bounds:
+        recv = torch.stack([pl[:, :, lo:hi] for pl in planes]).contiguous()          # what the all-to-all delivers to this rank
+        cols.append(ops.sweep_shard_cols(tb, ta[lo:hi], depth, recv, src_base))
+    ref_b2a = ops.l2_topk(ta, tb, depth, precision=L.SWEEP_EXACT, return_dists=False)[0]
+    ref_a2b = ops.l2_topk(tb, ta, depth, precision=L.SWEEP_EXACT, return_dists=False)[0]
+    assert torch.equal(torch.cat(rows), ref_b2a)
+    assert torch.equal(torch.cat(cols), ref_a2b)

@@ -359,14 +359,22 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
 // One workgroup per 64 owners; blocks of 64 x 64 keys are transposed through LDS (coalesced 256-byte reads in, one
 // owner's 64 keys per wave read out).  Pass 1 reads plane 0 only (u is taken over block minima: still depth distinct
 // entries, a valid if slightly larger u); pass 2 reads all four planes and emits C_r with ballot compaction.
-__global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict__ keys, int R, int nblk, int bw, int n_gallery, int depth,
+// Key layout: keys[src][plane][block-of-src][owner] with `nbs` blocks per source (one source: the planes of a local GEMM,
+// nbs == nblk; several: the column planes every rank sent for this rank's columns, stacked in rank order) -- block `blk`
+// holds entries src_base[blk / nbs] + (blk % nbs) * bw + (key & 127) of the other side (src_base == NULL: 0).
+__global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict__ keys, int R, int nblk, int bw, int nbs,
+                                                     const int *__restrict__ src_base, int depth,
                                                      const float *__restrict__ own_norm, const float *__restrict__ other_max, float kappa,
                                                      int64_t *__restrict__ cand, int *__restrict__ cand_n) {
   __shared__ unsigned tl[3][64 * 65];
   __shared__ float bmin[16][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int r0 = blockIdx.x * 64;
-  const size_t plane = (size_t)nblk * R;
+  const size_t plane = (size_t)nbs * R;                       // one plane of one source
+  auto blk_off = [&](int blk) -> size_t {                      // offset of (plane 0, blk, owner 0)
+    const int src = blk / nbs;
+    return ((size_t)src * (L2MIN_PLANES - 1) * nbs + blk) * R;   // = ((src * 4) * nbs + blk % nbs) * R
+  };
   const bool rv = r0 + lane < R;
   const float INF = __builtin_bit_cast(float, 0x7F800000u);
   // ---- pass 1: per owner, the two smallest block minima each lane has seen ----
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
       for (int it = 0; it < 4; ++it) {
         const int blk = c0 + sub + 16 * it;
         const bool ok = blk < nblk && r0 + og < R;
-        const size_t o = (size_t)blk * R + r0 + og;
+        const size_t o = (ok ? blk_off(blk) : 0) + r0 + og;
 #pragma unroll
         for (int pl = 0; pl < 4; ++pl)
           if (pl < npl) v[it][pl] = ok ? *reinterpret_cast<const uint4 *>(keys + pl * plane + o) : make_uint4(0x7F800000u, 0x7F800000u, 0x7F800000u, 0x7F800000u);
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
       for (int q = 0; q < 16; ++q) {
         const int bl = w + 4 * q, blk = c0 + bl;
         const bool ok = blk < nblk && rv;
-        const size_t o = (size_t)blk * R + r0 + lane;
+        const size_t o = (ok ? blk_off(blk) : 0) + r0 + lane;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
           if (pl < npl) tl[pl][bl * 65 + lane] = ok ? keys[pl * plane + o] : 0x7F800000u;
@@ -459,6 +467,7 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
     load_chunk(c0, 4);
     __syncthreads();
     const int blk = c0 + lane;
+    const int64_t base = blk < nblk ? (int64_t)(src_base ? src_base[blk / nbs] : 0) + (int64_t)(blk % nbs) * bw : 0;
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) {
       const int o = 16 * w + cc;
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
         const unsigned long long mask = __ballot(pass);
         if (mask) {                                                       // wave-uniform
           const int pos = cnt[cc] + __popcll(mask & ((1ull << lane) - 1ull));
-          if (pass && pos < 64 && r < R) cand[(size_t)r * 64 + pos] = (int64_t)blk * bw + (int)(k & 127u);
+          if (pass && pos < 64 && r < R) cand[(size_t)r * 64 + pos] = base + (int)(k & 127u);
           cnt[cc] += __popcll(mask);
         }
       }
@@ -960,8 +969,10 @@ Sweep2Ws plan2(char *ws, int ng, int nq, int d, bool bidir) {
 }
 
 // gallery a [na], queries b [nb]; ids_a2b != nullptr: also the transposed direction
+// colk_out != NULL (sharded sweep, rank-local rows): the column planes go to the caller's [4, nblk_r_pad, na] buffer and the
+// column direction is NOT finished here (vtc_l2_sweep_shard_cols does, after the exchange)
 int exact2_impl(const float *a, const float *b, int na, int nb, int d, int depth, int64_t *ids_b2a, float *dists_b2a, int64_t *ids_a2b,
-                float *dists_a2b, const Sweep2Ws &s, hipStream_t stream) {
+                float *dists_a2b, const Sweep2Ws &s, hipStream_t stream, unsigned *colk_out = nullptr, int nblk_r_pad = 0) {
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(nb, 4)), dim3(256), 0, stream, b, s.qn, nb, d);
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(na, 4)), dim3(256), 0, stream, a, s.gn, na, d);
   hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)(((size_t)nb * d + 255) / 256)), dim3(256), 0, stream, b, s.qb, nb, d, 1, 0);
@@ -972,12 +983,19 @@ int exact2_impl(const float *a, const float *b, int na, int nb, int d, int depth
   GemmEpi e;
   e.mode = EPI_L2MIN; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
   e.rowk = s.rowk; e.colk = ids_a2b ? s.colk : nullptr; e.nblk_c = s.nblk_c; e.nblk_r = s.nblk_r; e.rb = s.rb;
+  if (colk_out) {
+    e.colk = colk_out; e.nblk_r = nblk_r_pad;
+    // blocks this rank has no rows for (shards differ by a row): +inf keys
+    for (int pl = 0; pl < L2MIN_PLANES && nblk_r_pad > s.nblk_r; ++pl)
+      (void)hipMemsetD32Async((hipDeviceptr_t)(colk_out + ((size_t)pl * nblk_r_pad + s.nblk_r) * na), 0x7F800000,
+                              (size_t)(nblk_r_pad - s.nblk_r) * na, stream);
+  }
   if (int rc = launch_gemm(s.qb, s.gb, nullptr, nullptr, nb, na, d, VTC_BF16, e, stream)) return rc;
   const float kappa = exact2_kappa(d);
   {
     ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * s.nblk_c * nb * 4, stream);
-    hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(nb, 64)), dim3(256), 0, stream, s.rowk, nb, s.nblk_c, 64, na, depth, s.qn, s.gmax, kappa, s.cand,
-                       s.cand_n);
+    hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(nb, 64)), dim3(256), 0, stream, s.rowk, nb, s.nblk_c, 64, s.nblk_c, (const int *)nullptr, depth, s.qn, s.gmax,
+                       kappa, s.cand, s.cand_n);
   }
   VTC_LAUNCH_CHECK("minsel");
   if (int rc = exact_finish(a, b, na, nb, d, depth, CD2, s.cand, nullptr, s.qn, s.gn, s.gmax, s.flags, ids_b2a, dists_b2a, stream, s.cand_n, &s.fb))
@@ -985,8 +1003,8 @@ int exact2_impl(const float *a, const float *b, int na, int nb, int d, int depth
   if (ids_a2b) {
     {
       ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * s.nblk_r * na * 4, stream);
-      hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(na, 64)), dim3(256), 0, stream, s.colk, na, s.nblk_r, s.rb, nb, depth, s.gn, s.qmax, kappa,
-                         s.cand2, s.cand2_n);
+      hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(na, 64)), dim3(256), 0, stream, s.colk, na, s.nblk_r, s.rb, s.nblk_r, (const int *)nullptr, depth, s.gn, s.qmax,
+                         kappa, s.cand2, s.cand2_n);
     }
     VTC_LAUNCH_CHECK("minsel cols");
     return exact_finish(b, a, nb, na, d, depth, CD2, s.cand2, nullptr, s.gn, s.qn, s.qmax, s.flags, ids_a2b, dists_a2b, stream, s.cand2_n, &s.fb);
@@ -994,6 +1012,59 @@ int exact2_impl(const float *a, const float *b, int na, int nb, int d, int depth
   return 0;
 }
 }  // namespace
+
+// ---- sharded sweep: ONE [N/G, N] distance GEMM per rank for both directions (include/vtc_hip.h) ---------------------------
+extern "C" int vtc_l2_sweep_row_block(void) { return exact2_variant() == 0 ? 128 : 64; }
+
+extern "C" int vtc_l2_sweep_shard_supported(int n_total, int n_local, int depth) {
+  return exact2_enabled(n_total, n_local, depth) && n_local >= 1 && depth <= n_total;
+}
+
+extern "C" size_t vtc_l2_sweep_shard_workspace_bytes(int n_total, int n_local, int d) {
+  // rows phase: plan2 of (gallery n_total, queries n_local); cols phase: norms of both sides + candidates of n_local queries
+  const size_t rows = plan2(nullptr, n_total, n_local, d, false).total;
+  return rows + align_up((size_t)n_total * 4, 256) + 512;
+}
+
+extern "C" int vtc_l2_sweep_shard_rows(const float *a_all, const float *b_local, int n_total, int n_local, int d, int depth,
+                                       int64_t *ids, float *dists, unsigned *col_planes, int nblk_pad, void *ws, size_t ws_bytes,
+                                       void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VTC_CHECK(a_all && b_local && ids && col_planes && ws, "l2_sweep_shard_rows: null argument");
+  VTC_CHECK(d > 0 && d % 64 == 0, "l2_sweep_shard_rows: d=%d must be a positive multiple of 64", d);
+  VTC_CHECK(vtc_l2_sweep_shard_supported(n_total, n_local, depth), "l2_sweep_shard_rows: unsupported shape (n_total=%d n_local=%d depth=%d)",
+            n_total, n_local, depth);
+  Sweep2Ws s2 = plan2((char *)ws, n_total, n_local, d, false);
+  VTC_CHECK(nblk_pad >= s2.nblk_r, "l2_sweep_shard_rows: nblk_pad=%d < %d row blocks", nblk_pad, s2.nblk_r);
+  VTC_CHECK(ws_bytes >= vtc_l2_sweep_shard_workspace_bytes(n_total, n_local, d), "l2_sweep_shard_rows: workspace too small");
+  return exact2_impl(a_all, b_local, n_total, n_local, d, depth, ids, dists, nullptr, nullptr, s2, stream, col_planes, nblk_pad);
+}
+
+extern "C" int vtc_l2_sweep_shard_cols(const float *b_all, const float *a_local, int n_total, int n_local, int d, int depth,
+                                       const unsigned *planes, int n_src, int nblk_pad, const int *src_base, int64_t *ids,
+                                       float *dists, void *ws, size_t ws_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VTC_CHECK(b_all && a_local && planes && src_base && ids && ws, "l2_sweep_shard_cols: null argument");
+  VTC_CHECK(d > 0 && d % 64 == 0, "l2_sweep_shard_cols: d=%d must be a positive multiple of 64", d);
+  VTC_CHECK(vtc_l2_sweep_shard_supported(n_total, n_local, depth) && n_src >= 1 && nblk_pad >= 1,
+            "l2_sweep_shard_cols: unsupported shape (n_total=%d n_local=%d depth=%d n_src=%d)", n_total, n_local, depth, n_src);
+  VTC_CHECK(ws_bytes >= vtc_l2_sweep_shard_workspace_bytes(n_total, n_local, d), "l2_sweep_shard_cols: workspace too small");
+  // gallery = b_all (n_total), queries = a_local (n_local): the plan's qn/gn/cand/flags/fallback areas fit as they are
+  Sweep2Ws s = plan2((char *)ws, n_total, n_local, d, false);
+  const int rb = vtc_l2_sweep_row_block();
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(n_local, 4)), dim3(256), 0, stream, a_local, s.qn, n_local, d);
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(n_total, 4)), dim3(256), 0, stream, b_all, s.gn, n_total, d);
+  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, s.gn, n_total, s.gmax);
+  const float kappa = exact2_kappa(d);
+  {
+    ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * n_src * nblk_pad * n_local * 4, stream);
+    hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(n_local, 64)), dim3(256), 0, stream, planes, n_local, n_src * nblk_pad, rb, nblk_pad, src_base,
+                       depth, s.qn, s.gmax, kappa, s.cand, s.cand_n);
+  }
+  VTC_LAUNCH_CHECK("minsel shard cols");
+  return exact_finish(b_all, a_local, n_total, n_local, d, depth, CD2, s.cand, nullptr, s.qn, s.gn, s.gmax, s.flags, ids, dists, stream,
+                      s.cand_n, &s.fb);
+}
 
 // diagnostics (tools/sweep_v2_debug.py; not part of the public header): the raw block-minima planes of one distance GEMM.
 // qb [nb, d], gb [na, d] bf16; qn, gn fp32 squared norms; rowk [4, ceil(na / 64), nb], colk [4, ceil(nb / rb), na] (or NULL)

@@ -9,8 +9,17 @@ encodes its shard, no collective -- and the N x N sweep has exactly one exchange
     rank r sweeps its own query rows against the full gallery, both directions
     all_reduce(sum) of the 2 x len(k) int64 hit counters
 
-No cross-rank top-k merge is needed because a rank owns whole query rows.  Works with "gloo"
-on CPU tensors for the collectives' bookkeeping (tests), the sweep itself is HIP-only.
+No cross-rank top-k merge is needed there because a rank owns whole query rows -- at the price of two
+[N/G, N] distance GEMMs per rank.  With VTC_SWEEP_EXACT the ranks instead run ONE GEMM each (rank r: its
+b rows x all a columns): the row direction is complete locally, and for the column direction every rank
+keeps, per column and per block of 128 of its rows, the three smallest distance keys + a bound
+(include/vtc_hip.h, vtc_l2_sweep_shard_rows), sends each column owner its slice
+
+    all_to_all(col_planes[:, :, lo_s:hi_s])   4 x ceil(N/G/128) x N/G uint32 per rank pair (4.9 MB at 50k, G=8)
+
+and the owner certifies + re-ranks in fp64 across all sources (vtc_l2_sweep_shard_cols): the same ids as the
+single-GPU search, bit for bit.  Works with "gloo" on CPU tensors for the collectives' bookkeeping
+(tests inject CPU stand-ins for the two kernels), the sweep itself is HIP-only.
 """
 from __future__ import annotations
 
@@ -67,9 +76,48 @@ BIDIR_MIN_ROWS = 14336      # as host/metric.py RecallAtK.bidir_min_rows
 BIDIR_MIN_ROWS_F32 = 4096
 
 
-def sweep_path(n_total: int, precision: int, world: int) -> str:
-    one = world == 1 and n_total >= (BIDIR_MIN_ROWS_F32 if precision == 0 else BIDIR_MIN_ROWS)
+def one_matrix_sharded(n_total: int, precision: int, world: int, depth: int) -> bool:
+    """True when world > 1 ranks take the one-GEMM-per-rank path (VTC_SWEEP_EXACT, shapes the block-minima sweep covers;
+    VTC_SWEEP_SHARD_TWO=1 forces the two-search path)."""
+    if world <= 1 or precision != 3 or os.environ.get("VTC_SWEEP_SHARD_TWO") == "1":
+        return False
+    from . import ops
+    return all(ops.sweep_shard_supported(n_total, hi - lo, depth)
+               for lo, hi in (shard_bounds(n_total, r, world) for r in range(world)))
+
+
+def sweep_path(n_total: int, precision: int, world: int, depth: int = 11) -> str:
+    if world > 1:
+        return ("one [N/G, N] distance GEMM per rank, column block minima exchanged (all-to-all)"
+                if one_matrix_sharded(n_total, precision, world, depth) else "two searches per rank ([N/G, N] blocks)")
+    one = n_total >= (BIDIR_MIN_ROWS_F32 if precision == 0 else BIDIR_MIN_ROWS)
     return "one distance matrix, row + column top-k" if one else "two searches per rank ([N/G, N] blocks)"
+
+
+def exchange_column_planes(planes: torch.Tensor, n_total: int, rank: int, world: int) -> torch.Tensor:
+    """planes [4, nblk_pad, n_total] of this rank's rows -> [world, 4, nblk_pad, n_local]: what every rank (in rank order)
+    holds for THIS rank's columns.  RCCL: one all_to_all; gloo (tests): point-to-point sends."""
+    bounds = [shard_bounds(n_total, r, world) for r in range(world)]
+    lo, hi = bounds[rank]
+    send = [planes[:, :, a:b].contiguous() for a, b in bounds]
+    recv = planes.new_empty(world, planes.shape[0], planes.shape[1], hi - lo)
+    if dist.get_backend() == "nccl":
+        dist.all_to_all(list(recv.unbind(0)), send)
+    else:
+        # gloo has no all_to_all and no device-memory send/recv: point-to-point, staged through host memory (tests, rehearsals)
+        host = [t.cpu() for t in send]
+        got = [torch.empty(recv.shape[1:], dtype=recv.dtype) for _ in range(world)]
+        ops_ = []
+        for r in range(world):
+            if r != rank:
+                ops_.append(dist.P2POp(dist.isend, host[r], r))
+                ops_.append(dist.P2POp(dist.irecv, got[r], r))
+        for w in dist.batch_isend_irecv(ops_):
+            w.wait()
+        got[rank] = host[rank]
+        for r in range(world):
+            recv[r].copy_(got[r])
+    return recv
 
 
 def sweep_workspace_bytes(n_total: int, n_local: int, d: int, precision: int, world: int) -> int:
@@ -79,6 +127,8 @@ def sweep_workspace_bytes(n_total: int, n_local: int, d: int, precision: int, wo
     need = lib.vtc_l2_topk_workspace_bytes(n_total, n_local, d, precision, 0)
     if world == 1:
         need = max(need, lib.vtc_l2_topk_bidir_workspace_bytes(n_total, n_total, d, precision, 0))
+    elif precision == 3:
+        need = max(need, lib.vtc_l2_sweep_shard_workspace_bytes(n_total, n_local, d))
     return int(need)
 
 
@@ -86,13 +136,15 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
                    rank: int, world: int,
                    topk: Optional[Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor]] = None,
                    precision: int = 3,    # _lib.SWEEP_EXACT
-                   ws: Optional[torch.Tensor] = None):
+                   ws: Optional[torch.Tensor] = None,
+                   shard_ops: Optional[tuple] = None):
     """R@K both directions for row-sharded embeddings.
 
     Returns ({k: recall b_from_a-direction as RecallAtK.compute(a, b)}, {k: compute(b, a)}).
     ``topk(gallery, queries, depth) -> ids`` defaults to the HIP sweep; tests inject a CPU one to
     exercise the sharding logic under gloo.  ``ws``: a caller-owned uint8 workspace reused across calls (grown by the
-    ops layer when too small)."""
+    ops layer when too small).  ``shard_ops = (rows_fn, cols_fn, row_block)``: stand-ins for ops.sweep_shard_rows /
+    ops.sweep_shard_cols (tests: the one-GEMM-per-rank exchange under gloo)."""
     lo, hi = shard_bounds(n_total, rank, world)
     assert feats_a_local.shape[0] == hi - lo and feats_b_local.shape[0] == hi - lo
     if world > 1 and feats_a_local.shape[1] == feats_b_local.shape[1] and feats_a_local.dtype == feats_b_local.dtype:
@@ -120,6 +172,20 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
         # ranks each direction's [N/G, N] block is a different matrix and the two searches stay separate
         from . import ops
         i1, _, i2, _ = ops.l2_topk_bidir(a_all, b_all, depth, precision=precision, return_dists=False, ws=ws)
+        both = (i1, i2)
+    if both is None and world > 1 and (shard_ops is not None or (hip_sweep and one_matrix_sharded(n_total, precision, world, depth))):
+        # one [N/G, N] GEMM per rank: rows finished locally, column block minima to the column owners
+        if shard_ops is None:
+            from . import ops
+            shard_ops = (lambda a_, b_, d_, nbp: ops.sweep_shard_rows(a_, b_, d_, nbp, ws=ws),
+                         lambda b_, a_, d_, pl, sb: ops.sweep_shard_cols(b_, a_, d_, pl, sb, ws=ws), ops.sweep_row_block())
+        rows_fn, cols_fn, rb = shard_ops
+        bounds = [shard_bounds(n_total, r, world) for r in range(world)]
+        nblk_pad = -(-max(h - l for l, h in bounds) // rb)
+        i1, planes = rows_fn(a_all, feats_b_local, depth, nblk_pad)          # gallery a, queries b: this rank's b rows
+        recv = exchange_column_planes(planes, n_total, rank, world)
+        src_base = torch.tensor([l for l, _ in bounds], dtype=torch.int32, device=planes.device)
+        i2 = cols_fn(b_all, feats_a_local, depth, recv, src_base)            # gallery b, queries a: this rank's a rows
         both = (i1, i2)
     # compute(a, b): gallery a, queries b (model/metric.py:137-146); this rank owns query rows [lo, hi)
     for d_, (gal, qry) in enumerate(((a_all, feats_b_local), (b_all, feats_a_local))):

@@ -245,6 +245,54 @@ def l2_topk_bidir(a: torch.Tensor, b: torch.Tensor, depth: int, precision: int =
     return ids1, d1, ids2, d2
 
 
+def sweep_shard_supported(n_total: int, n_local: int, depth: int) -> bool:
+    return bool(L.lib().vtc_l2_sweep_shard_supported(int(n_total), int(n_local), int(depth)))
+
+
+def sweep_row_block() -> int:
+    return int(L.lib().vtc_l2_sweep_row_block())
+
+
+@on_device
+def sweep_shard_rows(a_all: torch.Tensor, b_local: torch.Tensor, depth: int, nblk_pad: int, ws: Optional[torch.Tensor] = None):
+    """Rank-local half of the sharded sweep: (ids [n_local, depth] = l2_topk(gallery=a_all, queries=b_local),
+    col_planes [4, nblk_pad, n_total] uint32 (as int32 tensor) for the exchange).  include/vtc_hip.h."""
+    a_all, b_local = _gpu(a_all, torch.float32, "a_all"), _gpu(b_local, torch.float32, "b_local")
+    n, d = a_all.shape
+    nl = b_local.shape[0]
+    need = L.lib().vtc_l2_sweep_shard_workspace_bytes(n, nl, d)
+    if ws is None or ws.numel() < need:
+        ws = workspace(need, a_all.device)
+    ids = torch.empty(nl, depth, dtype=torch.int64, device=a_all.device)
+    planes = torch.empty(4, nblk_pad, n, dtype=torch.int32, device=a_all.device)
+    L.check(L.lib().vtc_l2_sweep_shard_rows(a_all.data_ptr(), b_local.data_ptr(), n, nl, d, depth, ids.data_ptr(), None,
+                                            planes.data_ptr(), nblk_pad, ws.data_ptr(), ws.numel(), _stream()),
+            "vtc_l2_sweep_shard_rows")
+    return ids, planes
+
+
+@on_device
+def sweep_shard_cols(b_all: torch.Tensor, a_local: torch.Tensor, depth: int, planes: torch.Tensor, src_base: torch.Tensor,
+                     ws: Optional[torch.Tensor] = None):
+    """Second half, after the exchange: planes [n_src, 4, nblk_pad, n_local] int32, src_base [n_src] int32 ->
+    ids [n_local, depth] = l2_topk(gallery=b_all, queries=a_local)."""
+    b_all, a_local = _gpu(b_all, torch.float32, "b_all"), _gpu(a_local, torch.float32, "a_local")
+    planes, src_base = _gpu(planes, torch.int32, "planes"), _gpu(src_base, torch.int32, "src_base")
+    n, d = b_all.shape
+    nl = a_local.shape[0]
+    n_src, four, nblk_pad, nl2 = planes.shape
+    if four != 4 or nl2 != nl or src_base.numel() != n_src:
+        raise ValueError(f"sweep_shard_cols: planes {tuple(planes.shape)} / src_base {tuple(src_base.shape)} do not match n_local={nl}")
+    need = L.lib().vtc_l2_sweep_shard_workspace_bytes(n, nl, d)
+    if ws is None or ws.numel() < need:
+        ws = workspace(need, b_all.device)
+    ids = torch.empty(nl, depth, dtype=torch.int64, device=b_all.device)
+    L.check(L.lib().vtc_l2_sweep_shard_cols(b_all.data_ptr(), a_local.data_ptr(), n, nl, d, depth, planes.data_ptr(), n_src,
+                                            nblk_pad, src_base.data_ptr(), ids.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                            _stream()), "vtc_l2_sweep_shard_cols")
+    return ids
+
+
 @on_device
 def recall_hits(ids: torch.Tensor, k_vals: Sequence[int], target_offset: int = 0,
                 hits: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -416,3 +416,24 @@ def test_towers_with_fused_qkv_attention_are_bit_identical():
                 lib.vtc_set_fused_attention(0)
         for x, y in zip(*runs):
             assert torch.isfinite(x).all() and torch.equal(x, y)
+
+
+def test_patch_gather_equals_im2row_path():
+    """bf16 pixels take the im2row-free patch GEMM (the LDS-DMA gathers conv1's patches from the pixel tensor,
+    timesformer_clip_alt.py:262-274); the same pixels handed over as fp32 go through the im2row matrix.  Same operands,
+    same kernel schedule (sizes at which the im2row path runs on the phased kernel too): bit-identical embeddings.
+    Covers a tail row tile (15 680 patches = 61.25 tiles), the image tower and the v1 token order; a small batch, where
+    the im2row path runs on the 128 x 128 kernel, agrees within bf16 rounding."""
+    from vtc_amd import towers
+    a = A.VIT_B32
+    for nframes, variant, B in ((8, 0, 40), (0, 0, 320), (8, 1, 40), (8, 0, 3)):
+        sd = A.synth_visual(a, 91 + nframes, nframes=nframes, prefix="v.", variant="v1" if variant else "alt")
+        pv = towers.PackedVision(cuda_sd(sd), "v.", torch.bfloat16)
+        shape = (B, nframes, 3, 224, 224) if nframes else (B, 3, 224, 224)
+        px = A.synth_pixels(shape, 94).bfloat16()
+        got = pv.forward(px.cuda())
+        ref = pv.forward(px.float().cuda())
+        if B >= 40:
+            assert torch.equal(got, ref), (nframes, variant, (got - ref).abs().max().item())
+        else:
+            report("patch gather vs im2row, small batch", np.abs(unit(got.cpu().numpy()) - unit(ref.cpu().numpy())).max(), 1e-3)

@@ -161,6 +161,10 @@ struct GemmEpi {
   const float *temporal = nullptr;
   int P = 0, F = 0, T = 0;
   int frames_major = 0;      // 0: row item*T + 1 + n*F + t (timesformer_clip_alt.py:271-274); 1: item*T + 1 + t*P + n (timesformer_clip.py:392)
+  // mode 3, gather = 1: A is the 16-bit PIXEL tensor [frames, 3, res, res] itself -- row m = patch (frame m / P, m % P), column
+  // k = (c, i, j) of conv1's kernel (model/timesformer_clip_alt.py:262-263 `self.conv1(x)`, stride = kernel = patch) -- read in
+  // place by the LDS-DMA source addressing: no im2row matrix.  patch in {16, 32}; the tensor is < 4 GiB.
+  int gather = 0, grid = 0, res = 0, patch = 0;
   // internal: squared-L2 epilogue (mode 4): out = rown[m] + coln[n] - 2 acc
   const float *rown = nullptr;
   const float *coln = nullptr;
@@ -186,6 +190,7 @@ enum { EPI_PATCH = 3, EPI_L2DIST = 4, EPI_SCALE = 5, EPI_L2MIN = 6, EPI_RESID_LN
 int launch_gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype,
                 const GemmEpi &epi, hipStream_t stream);
 bool gemm_resid_ln_supported(int M, int N, int K, int dtype);
+bool gemm_patch_gather_supported(int n_frames, int grid, int patch, int res, int pixel_dtype, int dtype);
 int launch_layernorm(const float *x, const float *g, const float *b, void *y, int rows, int width, int out_dtype,
                      const int *row_index, int row_mul, bool no_norm, hipStream_t stream);
 int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2,

@@ -799,10 +799,55 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
       }
     }
   };
+  // ---- patch gather (EPI_PATCH with epi.gather): activation rows are patches of the pixel tensor, read in place ----
+  // Per lane, the byte offsets of its four (piece, row) sources of the tile being staged (quarter A0 / A1 x two pieces):
+  // patch origin + the 16-byte chunk's place inside the patch's two (patch 32) or four (patch 16) pixel rows of this K-tile.
+  constexpr bool CAN_GATHER = MODE == EPI_PATCH && sizeof(T) == 2;
+  const bool gather = CAN_GATHER && p.epi.gather;
+  [[maybe_unused]] unsigned gvo[4] = {0, 0, 0, 0};
+  [[maybe_unused]] const int g_cs = p.epi.patch == 32 ? 2 : 1;                  // log2(16-byte chunks per pixel row of a patch)
+  auto gather_offsets = [&](int sm) __attribute__((always_inline)) {
+    if constexpr (CAN_GATHER) {
+      const int P = p.epi.P, G = p.epi.grid, res = p.epi.res, ps = p.epi.patch;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int m = min(sm + (ga0 + 8 * h + q) * 8 + (lane >> 3), p.M - 1);   // tail rows re-read a valid patch, never stored
+          const int f = m / P, np = m - f * P;
+          const int gy = np / G, gx = np - gy * G;
+          const int c = ((lane & 7) ^ (lane >> 4)) ^ (q << 2);                   // the piece's swizzled chunk (odd groups: ^ 4)
+          const unsigned origin = (unsigned)(((f * 3) * res + gy * ps) * res + gx * ps) * 2u;
+          gvo[2 * h + q] = origin + (unsigned)((c >> g_cs) * res * 2 + ((c & ((1 << g_cs) - 1)) << 4));
+        }
+    }
+  };
+  // uniform byte offset of K-tile kk (64 consecutive k = (c, i, j..j+63)): channel plane + first pixel row
+  auto gather_kbase = [&](int kk) -> size_t {
+    const int k = kk * 64, pp = p.epi.patch * p.epi.patch;
+    const int c = k / pp, i = (k - c * pp) / p.epi.patch;
+    return ((size_t)c * p.epi.res + i) * p.epi.res * 2;
+  };
   // quarter qi (0 = A0, 1 = W0, 2 = W1, 3 = A1) of K-tile kk of the tile at (sm, sn) into stage st
   auto stage_quarter = [&](int qi, int sm, int sn, int kk, unsigned st, bool fastA, bool fastW) __attribute__((always_inline)) {
     if (qi == 0 || qi == 3) {
       const int grp = ga0 + (qi == 3 ? 8 : 0);
+      if constexpr (CAN_GATHER) {
+        if (gather) {
+          const char *sb0 = reinterpret_cast<const char *>(p.A) + gather_kbase(kk);
+          const char *sb1 = sb0 - 1024;
+          const int h = qi == 3 ? 1 : 0;
+          asm volatile(
+              "s_mov_b32 m0, %4\n\t"
+              "s_nop 0\n\t"
+              "global_load_lds_dwordx4 %0, %2\n\t"
+              "global_load_lds_dwordx4 %1, %3 offset:1024"
+              :
+              : "v"(gvo[2 * h]), "v"(gvo[2 * h + 1]), "s"(sb0), "s"(sb1), "s"(st + grp * 1024)
+              : "memory");
+          return;
+        }
+      }
       stage2(p.A, sm, p.M, p.lda_bytes, a_vo, grp, kk * ROWB, st + grp * 1024, fastA);
     } else {
       const int grp = gw0 + (qi == 2 ? 4 : 0);
@@ -813,6 +858,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
   int cur = 0;
   {   // prologue: the whole first K-tile
     const bool fa = m0 + BM <= p.M, fw = n0 + BN <= p.N;
+    if (gather) gather_offsets(m0);
 #pragma unroll
     for (int qi = 0; qi < 4; ++qi) stage_quarter(qi, m0, n0, 0, lds_base, fa, fw);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -850,6 +896,9 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
       const bool to_next = kn == ksteps && has_next;
       const int sm = to_next ? m0n : m0, sn = to_next ? n0n : n0, kk = kn < ksteps ? kn : 0;
       const bool fastA = sm + BM <= p.M, fastW = sn + BN <= p.N;
+      if constexpr (CAN_GATHER) {
+        if (gather && to_next) gather_offsets(m0n);     // from here on the next tile's K-tile 0 streams in
+      }
       static_for<4>([&](auto ph_c) __attribute__((always_inline)) {
         constexpr int ph = decltype(ph_c)::value;
         constexpr int qm = ph >> 1, qn = (ph == 1 || ph == 2) ? 1 : 0;
@@ -1067,7 +1116,11 @@ int dispatch(GemmParams p, hipStream_t stream) {
       if (out_f32) return run_cfg<T, VTC_EPI_GELU, float>(p, stream);
       return run_cfg<T, VTC_EPI_GELU, Out16>(p, stream);
     case VTC_EPI_RESID: return run_cfg<T, VTC_EPI_RESID, float>(p, stream);
-    case EPI_PATCH: return run_cfg<T, EPI_PATCH, float>(p, stream);
+    case EPI_PATCH:
+      if constexpr (sizeof(T) == 2) {
+        if (p.epi.gather) return run_phased<EPI_PATCH, float, T>(p, stream);     // only the phased kernel addresses patches in place
+      }
+      return run_cfg<T, EPI_PATCH, float>(p, stream);
     case EPI_L2DIST: return run_cfg<T, EPI_L2DIST, float>(p, stream);
     case EPI_SCALE: return run_cfg<T, EPI_SCALE, float>(p, stream);
     case EPI_L2MIN:
@@ -1086,6 +1139,14 @@ int dispatch(GemmParams p, hipStream_t stream) {
 }
 
 }  // namespace
+
+// Patch embedding without the im2row matrix: 16-bit pixels in the operand format, conv1's kernel = stride = 16 or 32 (a
+// K-tile of 64 is then whole pixel rows of one channel), 16-byte aligned pixel rows, 32-bit byte offsets.
+bool gemm_patch_gather_supported(int n_frames, int grid, int patch, int res, int pixel_dtype, int dtype) {
+  static const bool off = [] { const char *e = getenv("VTC_PATCH_IM2ROW"); return e && e[0] == '1'; }();
+  return !off && pixel_dtype == dtype && (dtype == VTC_BF16 || dtype == VTC_F16) && (patch == 16 || patch == 32) && res == grid * patch &&
+         (size_t)n_frames * 3 * res * res * 2 < (1ull << 32);
+}
 
 // The residual GEMM can take the FOLLOWING LayerNorm along (EPI_RESID_LN) when the phased 256 x 256 kernel runs it, a row
 // is a whole number of column tiles and fits ln_row.h, and the output is addressable by one buffer descriptor.

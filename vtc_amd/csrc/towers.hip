@@ -198,12 +198,19 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
 
   // patch embedding (+pos, +temporal) scattered into the reference's token order, cls rows, ln_pre
   VTC_CHECK(pixel_dtype == VTC_F32 || pixel_dtype == VTC_BF16 || pixel_dtype == VTC_U8, "vision_forward: bad pixel dtype %d", pixel_dtype);
-  RUN(launch_im2row(pixels, pixel_dtype, v.big, dtype, n_items * F, w->grid, w->patch, res, w->pix_mean, w->pix_std, s));
   {
     GemmEpi e;
     e.mode = EPI_PATCH; e.out_dtype = VTC_F32; e.pos = w->pos; e.temporal = tsf ? w->temporal : nullptr;
     e.P = P; e.F = F; e.T = T; e.ldo = W; e.frames_major = w->variant == 1;
-    RUN(launch_gemm(v.big, w->conv_w, nullptr, v.x, n_items * F * P, W, 3 * w->patch * w->patch, dtype, e, s));
+    const void *act = v.big;
+    if (gemm_patch_gather_supported(n_items * F, w->grid, w->patch, res, pixel_dtype, dtype) && ((size_t)pixels & 15) == 0) {
+      // pixels already in the operand format: the GEMM's LDS-DMA reads the patches where they lie (no im2row matrix)
+      e.gather = 1; e.grid = w->grid; e.res = res; e.patch = w->patch;
+      act = pixels;
+    } else {
+      RUN(launch_im2row(pixels, pixel_dtype, v.big, dtype, n_items * F, w->grid, w->patch, res, w->pix_mean, w->pix_std, s));
+    }
+    RUN(launch_gemm(act, w->conv_w, nullptr, v.x, n_items * F * P, W, 3 * w->patch * w->patch, dtype, e, s));
   }
   RUN(launch_cls_rows(v.x, w->class_embedding, w->pos, n_items, T, W, s));
   RUN(launch_layernorm(v.x, w->ln_pre_g, w->ln_pre_b, v.x, rows, W, VTC_F32, nullptr, 1, false, s));

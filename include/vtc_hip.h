@@ -60,6 +60,13 @@ typedef struct {
   const void  *tout_w; const float *tout_b;  /* timeattn.out_proj; NULL => tfc_* holds the
                                                 pre-multiplied map temporal_fc o out_proj */
   const void  *tfc_w;  const float *tfc_b;   /* temporal_fc                  [W,W],[W]   */
+  /* Folded LayerNorm (optional; all NULL => the LayerNorm kernels run).  16-bit modes only: the LayerNorm in front of a
+   * projection is applied by that projection's epilogue,  LN(x) W^T + b = rstd_m (x W'^T - mean_m s_n) + c_n,  with
+   * W' = (gamma . W) in the block's operand format, s[n] = sum_k W'[n][k] (of the rounded W'), c[n] = b[n] + sum_k beta[k] W[n][k]:
+   * the GEMM reads x itself (a 16-bit copy the residual GEMM in front writes next to the fp32 stream, with the row statistics). */
+  const void  *qkv_wf;  const float *qkv_s,  *qkv_c;    /* ln_1    -> attn.in_proj     */
+  const void  *fc_wf;   const float *fc_s,   *fc_c;     /* ln_2    -> mlp.c_fc         */
+  const void  *tqkv_wf; const float *tqkv_s, *tqkv_c;   /* ln_time -> timeattn.in_proj */
 } vtc_block_w;
 
 /* Vision tower: upstream VisionTransformer (nframes == 0) or
@@ -235,6 +242,12 @@ int vtc_qkv_attention(const void *h, const void *w_qkv, const float *b_qkv, void
 /* Which attention branches of the towers use vtc_qkv_attention instead of vtc_gemm + vtc_attention (same results): bit 0 =
  * contiguous sequences + time branch, bit 1 = space branch.  Default 0 (or env VTC_FUSED_ATTN); process-wide. */
 int vtc_set_fused_attention(int mask);
+
+/* Folded LayerNorm of the towers' 16-bit modes (vtc_block_w: *_wf, *_s, *_c): 1 (default, or env VTC_LN_FOLD) = the residual
+ * GEMM writes the operand-format copy + row statistics and the next projection applies them; 0 = the LayerNorm kernels run
+ * (as they do whenever a block has no folded weights, the width is not a multiple of 256, or fused attention is on).
+ * Process-wide. */
+int vtc_set_ln_fold(int on);
 
 /* ---- adapter-only training step: backward + optimizer primitives, fp32 -------------------
  * Replace, for PretrainedCLIP_finaltf with frozen towers (configs/pretrained_clip_comments_attn_frozen.jsonc), what

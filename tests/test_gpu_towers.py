@@ -389,7 +389,8 @@ def test_text_tower_half_layers_statistics():
 def test_towers_with_fused_qkv_attention_are_bit_identical():
     """vtc_set_fused_attention(3): the towers take QKV projection + attention core as ONE kernel per branch (qkv_attn.hip)
     -- ViT, dense text (causal), TimeSformer time and space branches, 8 and 16 frames.  Same roundings in the same places
-    as the two-kernel path, so the embeddings must be bit-identical to it (which the goldens / oracle pin)."""
+    as the two-kernel path WITH the LayerNorm kernels (the fused kernel takes LayerNorm'd rows, so it switches the folded
+    LayerNorm off), so the embeddings must be bit-identical to that path (which the goldens / oracle pin)."""
     from vtc_amd import _lib as L
     from vtc_amd import towers
     lib = L.lib()
@@ -406,6 +407,7 @@ def test_towers_with_fused_qkv_attention_are_bit_identical():
         runs = []
         for mask in (0, 3):
             L.check(lib.vtc_set_fused_attention(mask), "vtc_set_fused_attention")
+            L.check(lib.vtc_set_ln_fold(0), "vtc_set_ln_fold")
             try:
                 outs = [towers.PackedVision(sdv, "v.", dtype).forward(vid), towers.PackedVision(sd16, "v.", dtype).forward(vid16),
                         towers.PackedVision(sdi, "v.", dtype).forward(img),
@@ -414,6 +416,7 @@ def test_towers_with_fused_qkv_attention_are_bit_identical():
                 runs.append([o.clone() for o in outs])
             finally:
                 lib.vtc_set_fused_attention(0)
+                lib.vtc_set_ln_fold(1)
         for x, y in zip(*runs):
             assert torch.isfinite(x).all() and torch.equal(x, y)
 
@@ -437,3 +440,53 @@ def test_patch_gather_equals_im2row_path():
             assert torch.equal(got, ref), (nframes, variant, (got - ref).abs().max().item())
         else:
             report("patch gather vs im2row, small batch", np.abs(unit(got.cpu().numpy()) - unit(ref.cpu().numpy())).max(), 1e-3)
+
+
+def test_folded_layernorm_and_layernorm_kernels_agree_with_the_oracle():
+    """16-bit modes fold each LayerNorm into the projection behind it (include/vtc_hip.h vtc_block_w *_wf/_s/_c;
+    LN(x) W^T + b = rstd (x (g.W)^T - mean s) + c; model/timesformer_clip_alt.py:142-175 ln_time / ln_1 / ln_2).  Both
+    switch positions stay within the bf16 tolerance of the fp32 oracle, for the alt and v1 video towers, the image tower
+    and the (ragged and dense) text tower; odd batch sizes exercise the padded rows."""
+    from vtc_amd import _lib as L
+    from vtc_amd import towers
+    a = A.VIT_B32
+    lib = L.lib()
+    sd_alt = A.synth_visual(a, 101, nframes=8, prefix="v.")
+    for k in list(sd_alt):
+        if k.endswith("temporal_fc.weight"):
+            sd_alt[k] = torch.randn(sd_alt[k].shape, generator=torch.Generator().manual_seed(102)) * 0.02
+    sd_v1 = A.synth_visual(a, 103, nframes=8, prefix="v.", variant="v1")
+    sd_img = A.synth_visual(a, 104, prefix="v.")
+    sd_txt = A.synth_text(a, 105, prefix="t.")
+    vid = A.synth_pixels((3, 8, 3, 224, 224), 106)
+    img = A.synth_pixels((5, 3, 224, 224), 107)
+    txt = A.synth_tokens(7, a, 108, empty_frac=0.2)
+    refs = {
+        "alt": T.timesformer_alt(vid, sd_alt, a, "v.").numpy(),
+        "v1": T.timesformer_v1(vid, sd_v1, a, "v.").numpy(),
+        "img": CR.encode_image(img, sd_img, a, "v.").numpy(),
+        "txt": CR.encode_text(txt, sd_txt, a, "t.").numpy(),
+    }
+    packed = {
+        "alt": (towers.PackedVision(cuda_sd(sd_alt), "v.", torch.bfloat16), vid),
+        "v1": (towers.PackedVision(cuda_sd(sd_v1), "v.", torch.bfloat16), vid),
+        "img": (towers.PackedVision(cuda_sd(sd_img), "v.", torch.bfloat16), img),
+        "txt": (towers.PackedText(cuda_sd(sd_txt), "t.", torch.bfloat16, heads=a.transformer_heads), txt),
+    }
+    outs = {}
+    try:
+        for on in (1, 0):
+            L.check(lib.vtc_set_ln_fold(on), "vtc_set_ln_fold")
+            for name, (pk, x) in packed.items():
+                outs[(name, on)] = pk.forward(x.cuda()).cpu().numpy()
+                if name == "txt":
+                    outs[("txt_dense", on)] = pk.forward(x.cuda(), ragged=False).cpu().numpy()
+    finally:
+        lib.vtc_set_ln_fold(1)
+    for (name, on), got in outs.items():
+        ref = refs.get(name.split("_")[0])
+        if ref is not None:
+            report(f"{name} fold={on} vs oracle", np.abs(unit(got) - unit(ref)).max(), 1e-3)
+    for name in ("alt", "v1", "img", "txt", "txt_dense"):
+        d = np.abs(unit(outs[(name, 1)]) - unit(outs[(name, 0)])).max()
+        assert 0 < d < 1e-3, (name, d)          # two rounding regimes of the same tower: different bits, same embedding

@@ -27,7 +27,8 @@ vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as int
 class BlockW(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "ln1_g", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_g", "ln2_b", "fc_w", "fc_b", "proj_w", "proj_b",
-        "lnt_g", "lnt_b", "tqkv_w", "tqkv_b", "tout_w", "tout_b", "tfc_w", "tfc_b")]
+        "lnt_g", "lnt_b", "tqkv_w", "tqkv_b", "tout_w", "tout_b", "tfc_w", "tfc_b",
+        "qkv_wf", "qkv_s", "qkv_c", "fc_wf", "fc_s", "fc_c", "tqkv_wf", "tqkv_s", "tqkv_c")]
 
 
 class VisionW(C.Structure):
@@ -95,6 +96,7 @@ SIGNATURES = {
     "vtc_qkv_attention": (C.c_int, [vp, vp, fp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_longlong, C.c_int, vp]),
     "vtc_set_fused_attention": (C.c_int, [C.c_int]),
+    "vtc_set_ln_fold": (C.c_int, [C.c_int]),
     # adapter-only training step (backward + optimizer primitives)
     "vtc_transpose_f32": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),
     "vtc_colsum_f32": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),

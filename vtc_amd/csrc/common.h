@@ -183,8 +183,18 @@ struct GemmEpi {
   const float *ln_g = nullptr, *ln_b = nullptr;
   void *ln_out = nullptr;
   int *ln_cnt = nullptr;
+  // LayerNorm folded into the GEMM that consumes it (16-bit operands; towers.hip "folded LayerNorm"):
+  //   LN(x) W^T + b = rstd_m (x (g . W)^T - mean_m s_n) + c_n,   s_n = sum_k (g . W)_nk,   c_n = b_n + sum_k beta_k W_nk
+  // producer (mode 2, the residual GEMM that writes x): y16 = x in the operand format [M, N] and fold_part[N / 64][M] =
+  //   (sum, sum of squares) of the row's 64 columns of this wave -- every tile interior (M % 256 == 0, N % 256 == 0);
+  // consumer (modes 0 / 1, 16-bit output): A = y16, W = (g . W) rounded, bias = c, fold_stat[M] = (mean, rstd), fold_s = s.
+  void *y16 = nullptr;
+  float *fold_part = nullptr;
+  const float *fold_stat = nullptr, *fold_s = nullptr;
 };
-enum { EPI_PATCH = 3, EPI_L2DIST = 4, EPI_SCALE = 5, EPI_L2MIN = 6, EPI_RESID_LN = 7 };
+enum { EPI_PATCH = 3, EPI_L2DIST = 4, EPI_SCALE = 5, EPI_L2MIN = 6, EPI_RESID_LN = 7,
+       // modes 0 / 1 / 2 with the folded LayerNorm (fold_* fields), as instantiations of their own: chosen by launch_gemm
+       EPI_FOLD_BASE = 8, EPI_STORE_FOLD = 8, EPI_GELU_FOLD = 9, EPI_RESID_FOLD = 10 };
 #define L2MIN_PLANES 4
 
 int launch_gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype,
@@ -193,5 +203,7 @@ bool gemm_resid_ln_supported(int M, int N, int K, int dtype);
 bool gemm_patch_gather_supported(int n_frames, int grid, int patch, int res, int pixel_dtype, int dtype);
 int launch_layernorm(const float *x, const float *g, const float *b, void *y, int rows, int width, int out_dtype,
                      const int *row_index, int row_mul, bool no_norm, hipStream_t stream);
+int launch_fold_stats(const float *part, int nb, int rows, float *stat, hipStream_t stream);
+int launch_cast_rowstats(const float *x, void *y16, float *stat, int rows, int width, int dtype, hipStream_t stream);
 int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2,
                      int a0, int a1, int a2, int a3, int pstride, int dtype, hipStream_t stream);

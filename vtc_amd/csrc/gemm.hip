@@ -39,6 +39,12 @@ using namespace vtcgemm;
 
 namespace {
 
+// x of the lane the DPP control selects (row-local permutations: quad_perm, row_half_mirror 0x141, row_mirror 0x140)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+
 // 16-byte global store, optionally non-temporal (streamed past L2: the store is acknowledged sooner, and the
 // in-order vmcnt queue of the next tile's first K-tiles drains sooner behind it)
 template <bool NT>
@@ -196,8 +202,11 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
   }
 }
 
-template <typename T, int MODE, typename OutT, int WM, int WN, int TM, int TN, int SCRATCH_PER_WAVE>
+template <typename T, int MODE_T, typename OutT, int WM, int WN, int TM, int TN, int SCRATCH_PER_WAVE>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmParams &p, int m0, int n0, unsigned scratch_off) {
+  // EPI_*_FOLD = the base epilogue + the folded LayerNorm, compiled apart so that the plain kernels keep their registers
+  constexpr bool FOLD = MODE_T >= EPI_FOLD_BASE;
+  constexpr int MODE = FOLD ? MODE_T - EPI_FOLD_BASE : MODE_T;
   if constexpr (MODE == EPI_L2MIN) {
     if (p.exp_arg & 1) {      // diagnostics (VTC_GEMM_EXP=1): the K loop alone -- the accumulators stay live, nothing is reduced or stored
 #pragma unroll
@@ -245,6 +254,25 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         b4[j] = p.bias ? *reinterpret_cast<const float4 *>(p.bias + ncol0 + 16 * j + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // folded LayerNorm (GemmEpi::fold_stat): v = rstd_m (acc - mean_m s_n) + c_n, the row statistics in the MFMA layout
+      // (row = lane & 15 of fragment row i), fetched before the first store of the tile
+      // The wave's TM * 16 rows of (mean, rstd) and TN * 16 columns of s wait in the wave's LDS scratch behind the two
+      // transposition buffers (32 + 16 registers less than holding them: the K loop leaves none to spare).
+      [[maybe_unused]] float *fold_rs = reinterpret_cast<float *>(trb + 2 * 16 * TSB);
+      [[maybe_unused]] float *fold_sc = fold_rs + 2 * TM * 16;
+      if constexpr (FOLD) {
+        static_assert(2 * 16 * TSB + (2 * TM * 16 + TN * 16) * 4 <= SCRATCH_PER_WAVE, "folded LayerNorm: row statistics + s in the wave's scratch");
+#pragma unroll
+        for (int q = 0; q < (TM * 16 + 63) / 64; ++q) {
+          const int r = lane + 64 * q;
+          if (TM * 16 % 64 == 0 || r < TM * 16)
+            *reinterpret_cast<float2 *>(fold_rs + 2 * r) = *reinterpret_cast<const float2 *>(p.epi.fold_stat + 2 * (size_t)(m0 + wr * TM * 16 + r));
+        }
+        if (lane < TN * 4) *reinterpret_cast<float4 *>(fold_sc + 4 * lane) = *reinterpret_cast<const float4 *>(p.epi.fold_s + ncol0 + 4 * lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
       // two buffers per wave, software-pipelined: fragment row i+1 is finalised and written while the read-back of
       // row i is in flight (a wave's LDS operations execute in order, so a buffer is rewritten only after the
       // reads of it have been issued)
@@ -252,7 +280,16 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
         char *buf = trb + (i & 1) * (16 * TSB);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          float v0 = acc[i][j][0] + b4[j].x, v1 = acc[i][j][1] + b4[j].y, v2 = acc[i][j][2] + b4[j].z, v3 = acc[i][j][3] + b4[j].w;
+          float v0, v1, v2, v3;
+          if constexpr (FOLD) {
+            const float2 st = *reinterpret_cast<const float2 *>(fold_rs + 2 * (i * 16 + l15));
+            const float4 sj = *reinterpret_cast<const float4 *>(fold_sc + 16 * j + 4 * g);
+            const float mu = st.x, rstd = st.y;
+            v0 = rstd * (acc[i][j][0] - mu * sj.x) + b4[j].x; v1 = rstd * (acc[i][j][1] - mu * sj.y) + b4[j].y;
+            v2 = rstd * (acc[i][j][2] - mu * sj.z) + b4[j].z; v3 = rstd * (acc[i][j][3] - mu * sj.w) + b4[j].w;
+          } else {
+            v0 = acc[i][j][0] + b4[j].x; v1 = acc[i][j][1] + b4[j].y; v2 = acc[i][j][2] + b4[j].z; v3 = acc[i][j][3] + b4[j].w;
+          }
           if (MODE == VTC_EPI_GELU) {
             v0 = quick_gelu<sizeof(T) == 4>(v0); v1 = quick_gelu<sizeof(T) == 4>(v1);
             v2 = quick_gelu<sizeof(T) == 4>(v2); v3 = quick_gelu<sizeof(T) == 4>(v3);
@@ -430,6 +467,24 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
             const v4u_t yy = {__float_as_uint(y.x), __float_as_uint(y.y), __float_as_uint(y.z), __float_as_uint(y.w)};
             __builtin_amdgcn_raw_buffer_store_b128(yy, out_rsrc, (int)((((size_t)m - m0u) * ldo + ncolh + cc) * 4), 0,
                                                    MODE == EPI_RESID_LN ? 16 : VTC_RESID_AUX);
+            if constexpr (FOLD && MODE == VTC_EPI_RESID && sizeof(T) == 2) {
+              {                     // folded LayerNorm, producer side: the row in the operand format + this wave's partial statistics
+                uint2 pk;
+                pk.x = (unsigned)cvt16<T>(y.x) | ((unsigned)cvt16<T>(y.y) << 16);
+                pk.y = (unsigned)cvt16<T>(y.z) | ((unsigned)cvt16<T>(y.w) << 16);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(p.epi.y16) + (size_t)m * ldo + ncolh + cc) = pk;
+                // (sum, sum of squared deviations from the 64-column mean): merged exactly like a two-pass variance
+                // (fold_stats_kernel).  Over the 16 lanes of the row: xor 1, 2 in the quad, then half-row and row mirrors.
+                float s1 = (y.x + y.y) + (y.z + y.w);
+                s1 += dpp_f<0xB1>(s1); s1 += dpp_f<0x4E>(s1); s1 += dpp_f<0x141>(s1); s1 += dpp_f<0x140>(s1);
+                const float mp = s1 * (1.0f / 64.0f);
+                const float d0 = y.x - mp, d1 = y.y - mp, d2 = y.z - mp, d3 = y.w - mp;
+                float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                q += dpp_f<0xB1>(q); q += dpp_f<0x4E>(q); q += dpp_f<0x141>(q); q += dpp_f<0x140>(q);
+                if (l15 == 0)
+                  *reinterpret_cast<float2 *>(p.epi.fold_part + 2 * ((size_t)(ncolh >> 6) * p.M + m)) = make_float2(s1, q);
+              }
+            }
           } else {
             store16<nt_out>(o, v);
           }
@@ -1111,11 +1166,21 @@ int dispatch(GemmParams p, hipStream_t stream) {
   switch (p.epi.mode) {
     case VTC_EPI_STORE:
       if (out_f32) return run_cfg<T, VTC_EPI_STORE, float>(p, stream);
+      if constexpr (sizeof(T) == 2) {
+        if (p.epi.fold_stat) return run_cfg<T, EPI_STORE_FOLD, Out16>(p, stream);
+      }
       return run_cfg<T, VTC_EPI_STORE, Out16>(p, stream);
     case VTC_EPI_GELU:
       if (out_f32) return run_cfg<T, VTC_EPI_GELU, float>(p, stream);
+      if constexpr (sizeof(T) == 2) {
+        if (p.epi.fold_stat) return run_cfg<T, EPI_GELU_FOLD, Out16>(p, stream);
+      }
       return run_cfg<T, VTC_EPI_GELU, Out16>(p, stream);
-    case VTC_EPI_RESID: return run_cfg<T, VTC_EPI_RESID, float>(p, stream);
+    case VTC_EPI_RESID:
+      if constexpr (sizeof(T) == 2) {
+        if (p.epi.y16) return run_cfg<T, EPI_RESID_FOLD, float>(p, stream);
+      }
+      return run_cfg<T, VTC_EPI_RESID, float>(p, stream);
     case EPI_PATCH:
       if constexpr (sizeof(T) == 2) {
         if (p.epi.gather) return run_phased<EPI_PATCH, float, T>(p, stream);     // only the phased kernel addresses patches in place
@@ -1174,6 +1239,13 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
   if (epi.mode == EPI_RESID_LN) {
     VTC_CHECK(gemm_resid_ln_supported(M, N, K, dtype), "gemm: fused residual + LayerNorm does not cover M=%d N=%d K=%d dtype=%d", M, N, K, dtype);
     VTC_CHECK(epi.ln_g && epi.ln_b && epi.ln_out && epi.ln_cnt && (epi.ldo == 0 || epi.ldo == N), "gemm: fused LayerNorm arguments");
+  }
+  if (epi.y16 || epi.fold_stat) {     // folded LayerNorm: only the interior fast epilogues carry it
+    VTC_CHECK(esz == 2 && M % 256 == 0 && N % 256 == 0 && (epi.ldo == 0 || epi.ldo == N),
+              "gemm: folded LayerNorm needs 16-bit operands and M, N multiples of 256 (M=%d N=%d dtype=%d)", M, N, dtype);
+    VTC_CHECK(epi.y16 ? (epi.mode == VTC_EPI_RESID && epi.fold_part != nullptr)
+                      : ((epi.mode == VTC_EPI_STORE || epi.mode == VTC_EPI_GELU) && epi.out_dtype != VTC_F32 && epi.fold_s != nullptr),
+              "gemm: folded LayerNorm arguments do not go with epilogue %d", epi.mode);
   }
   // diagnostics knobs, read once (C++11 static initialisation is thread-safe; never written afterwards)
   struct Env { int tile = 0, exp_arg = 0, sg = 0, st = 0; };

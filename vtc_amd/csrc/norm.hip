@@ -32,6 +32,66 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, const fl
   ln_row_compute<OutT, NO_NORM>(v, gamma, beta, y + (size_t)r * width, width, lane);
 }
 
+// ---- folded LayerNorm (GemmEpi::fold_*): the row statistics a consuming GEMM's epilogue applies -----------------------------
+// stat[r] = (mean, rstd) of row r from the residual GEMM's per-(64 columns, row) partials (sum, squared deviations from the
+// partial mean), merged as a two-pass variance would be: M2 = sum_p M2_p + 64 (mean_p - mean)^2.  One thread per row.
+__global__ __launch_bounds__(256) void fold_stats_kernel(const float2 *__restrict__ part, int nb, int rows, float2 *__restrict__ stat) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int p = 0; p < nb; ++p) s += part[(size_t)p * rows + r].x;
+  const float mean = s / (64.0f * nb);
+  float m2 = 0.f;
+  for (int p = 0; p < nb; ++p) {
+    const float2 v = part[(size_t)p * rows + r];
+    const float d = v.x * (1.0f / 64.0f) - mean;
+    m2 += v.y + 64.0f * d * d;
+  }
+  stat[r] = make_float2(mean, 1.0f / sqrtf(m2 / (64.0f * nb) + 1e-5f));
+}
+
+// Layer 0 has no residual GEMM in front of it: y16 = x in the operand format, stat = (mean, rstd) as LayerNorm computes them.
+template <typename OutT>
+__global__ __launch_bounds__(256) void cast_rowstats_kernel(const float *__restrict__ x, OutT *__restrict__ y, float2 *__restrict__ stat,
+                                                            int rows, int width) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float *xr = x + (size_t)r * width;
+  float4 v[LN_MAXV][2];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < width) {
+      v[i][0] = *reinterpret_cast<const float4 *>(xr + c);
+      v[i][1] = *reinterpret_cast<const float4 *>(xr + c + 4);
+      s += ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
+    }
+  }
+  const float mean = wave_sum(s) / width;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < width) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float a = v[i][h].x - mean, b = v[i][h].y - mean, cc = v[i][h].z - mean, d = v[i][h].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+      uint4 pk;
+      pk.x = (unsigned)cvt16<OutT>(v[i][0].x) | ((unsigned)cvt16<OutT>(v[i][0].y) << 16);
+      pk.y = (unsigned)cvt16<OutT>(v[i][0].z) | ((unsigned)cvt16<OutT>(v[i][0].w) << 16);
+      pk.z = (unsigned)cvt16<OutT>(v[i][1].x) | ((unsigned)cvt16<OutT>(v[i][1].y) << 16);
+      pk.w = (unsigned)cvt16<OutT>(v[i][1].z) | ((unsigned)cvt16<OutT>(v[i][1].w) << 16);
+      *reinterpret_cast<uint4 *>(y + (size_t)r * width + c) = pk;
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / width + 1e-5f);
+  if (lane == 0) stat[r] = make_float2(mean, rstd);
+}
+
 __global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict__ x, float *__restrict__ out, int n, int d) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -92,6 +152,24 @@ int launch_layernorm(const float *x, const float *g, const float *b, void *y, in
     else hipLaunchKernelGGL((layernorm_kernel<float, false>), grid, block, 0, stream, x, g, b, (float *)y, rows, width, row_index, row_mul);
   }
   VTC_LAUNCH_CHECK("layernorm");
+  return 0;
+}
+
+int launch_fold_stats(const float *part, int nb, int rows, float *stat, hipStream_t stream) {
+  ProfScope prof(VTC_PROF_NORM, (double)rows * 8 * (nb + 1), stream);
+  hipLaunchKernelGGL(fold_stats_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, (const float2 *)part, nb, rows, (float2 *)stat);
+  VTC_LAUNCH_CHECK("fold_stats");
+  return 0;
+}
+
+int launch_cast_rowstats(const float *x, void *y16, float *stat, int rows, int width, int dtype, hipStream_t stream) {
+  VTC_CHECK(width % 8 == 0 && width <= 512 * LN_MAXV && (dtype == VTC_BF16 || dtype == VTC_F16), "cast_rowstats: width=%d dtype=%d", width, dtype);
+  ProfScope prof(VTC_PROF_NORM, (double)rows * width * 6, stream);
+  if (dtype == VTC_F16)
+    hipLaunchKernelGGL((cast_rowstats_kernel<f16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, (f16_t *)y16, (float2 *)stat, rows, width);
+  else
+    hipLaunchKernelGGL((cast_rowstats_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, (bf16_t *)y16, (float2 *)stat, rows, width);
+  VTC_LAUNCH_CHECK("cast_rowstats");
   return 0;
 }
 

@@ -31,8 +31,12 @@ void vtc_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 extern "C" const char *vtc_last_error(void) { return g_err; }
-extern "C" int vtc_abi_version(void) { return 3; }
-namespace { extern std::atomic<int> g_fused_attn; }
+extern "C" int vtc_abi_version(void) { return 4; }
+namespace { extern std::atomic<int> g_fused_attn; extern std::atomic<int> g_ln_fold; }
+extern "C" int vtc_set_ln_fold(int on) {
+  g_ln_fold.store(on != 0);
+  return 0;
+}
 extern "C" int vtc_set_fused_attention(int mask) {
   VTC_CHECK(mask >= 0 && mask <= 3, "set_fused_attention: mask %d outside [0, 3]", mask);
   g_fused_attn.store(mask);
@@ -99,29 +103,90 @@ int gemm(const void *A, const void *W, const float *bias, void *out, int M, int 
   return launch_gemm(A, W, bias, out, M, N, K, dtype, e, s);
 }
 
+// ---- folded LayerNorm (include/vtc_hip.h vtc_block_w; GemmEpi::fold_*) ---------------------------------------------------
+// The three LayerNorms of a block each sit between a residual GEMM (which has the updated row in registers) and a projection.
+// Folded: the residual GEMM also writes the row in the operand format (`xb`) and per-(row, 64 columns) statistics; the
+// projection reads xb against gamma-scaled weights and applies mean / rstd in its epilogue.  The LayerNorm kernels' 1.2 GB
+// read + 0.6 GB write per launch (config 3, 1 024 videos) become a 0.6 GB write in the residual epilogue.  Needs every tile
+// interior: rows padded to 256 (the pad rows hold garbage that no kernel outside the GEMMs reads), W a multiple of 256.
+// VTC_LN_FOLD=0 / vtc_set_ln_fold(0): the LayerNorm kernels.
+std::atomic<int> g_ln_fold{-1};
+bool ln_fold_enabled() {
+  int m = g_ln_fold.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char *e = getenv("VTC_LN_FOLD");
+    m = e ? (atoi(e) != 0) : 1;
+    g_ln_fold.store(m, std::memory_order_relaxed);
+  }
+  return m != 0;
+}
+struct Fold {
+  bool on = false;
+  void *xb = nullptr;       // [rows_pad, W] operand format: the residual stream as the projections read it
+  float *part = nullptr;    // [W / 64][rows_pad] (sum, squared deviations)
+  float *stat = nullptr;    // [rows_pad] (mean, rstd)
+  int rows_pad = 0;
+  int fmt = -1;             // operand format xb / stat currently hold (-1: stale)
+};
+inline int pad256(int rows) { return (rows + 255) / 256 * 256; }
+bool fold_usable(const vtc_block_w *blocks, int layers, int W, int dtype, bool timesformer) {
+  if (!ln_fold_enabled() || dtype == VTC_F32 || W % 256 != 0 || fused_attn_mask()) return false;
+  for (int l = 0; l < layers; ++l)
+    if (!blocks[l].qkv_wf || !blocks[l].fc_wf || (timesformer && !blocks[l].tqkv_wf)) return false;
+  return true;
+}
+
+// out = epi(LN(x; g, bt) w^T + bias)
+int ln_proj(Fold &f, const float *x, const float *g, const float *bt, const void *w, const float *bias, const void *wf, const float *fs,
+            const float *fc, void *h, void *out, int rows, int N, int W, int dtype, int mode, hipStream_t s) {
+  if (f.on) {
+    if (f.fmt != dtype) {       // no residual GEMM of this format in front (layer 0, a format boundary)
+      RUN(launch_cast_rowstats(x, f.xb, f.stat, rows, W, dtype, s));
+      f.fmt = dtype;
+    }
+    GemmEpi e;
+    e.mode = mode; e.out_dtype = dtype; e.fold_stat = f.stat; e.fold_s = fs;
+    return launch_gemm(f.xb, wf, fc, out, f.rows_pad, N, W, dtype, e, s);
+  }
+  RUN(launch_layernorm(x, g, bt, h, rows, W, dtype, nullptr, 1, false, s));
+  return gemm(h, w, bias, out, rows, N, W, dtype, mode, dtype, 0, s);
+}
+
+// x += A w^T + bias  (rows with m % skip_mod == 0 untouched)
+int resid_proj(Fold &f, const void *A, const void *w, const float *bias, float *x, int rows, int W, int K, int dtype, int skip_mod,
+               hipStream_t s) {
+  if (f.on) {
+    GemmEpi e;
+    e.mode = VTC_EPI_RESID; e.out_dtype = VTC_F32; e.skip_mod = skip_mod; e.y16 = f.xb; e.fold_part = f.part;
+    RUN(launch_gemm(A, w, bias, x, f.rows_pad, W, K, dtype, e, s));
+    f.fmt = dtype;
+    return launch_fold_stats(f.part, W / 64, f.rows_pad, f.stat, s);
+  }
+  return gemm(A, w, bias, x, rows, W, K, dtype, VTC_EPI_RESID, VTC_F32, skip_mod, s);
+}
+
 // x += MLP(ln_2 x)   (timesformer_clip_alt.py:174 / upstream block)
-int mlp_part(const vtc_block_w &b, float *x, void *h, void *big, int rows, int W, int dtype, hipStream_t s) {
+int mlp_part(Fold &f, const vtc_block_w &b, float *x, void *h, void *big, int rows, int W, int dtype, hipStream_t s) {
   ProfRegion region(VTC_PROF_REGION_MLP);
-  RUN(launch_layernorm(x, b.ln2_g, b.ln2_b, h, rows, W, dtype, nullptr, 1, false, s));
-  RUN(gemm(h, b.fc_w, b.fc_b, big, rows, 4 * W, W, dtype, VTC_EPI_GELU, dtype, 0, s));
-  RUN(gemm(big, b.proj_w, b.proj_b, x, rows, W, 4 * W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+  RUN(ln_proj(f, x, b.ln2_g, b.ln2_b, b.fc_w, b.fc_b, b.fc_wf, b.fc_s, b.fc_c, h, big, rows, 4 * W, W, dtype, VTC_EPI_GELU, s));
+  RUN(resid_proj(f, big, b.proj_w, b.proj_b, x, rows, W, 4 * W, dtype, 0, s));
   return 0;
 }
 
 // x += MHA(ln_1 x) over n_seq contiguous sequences of L tokens
-int attn_part_contig(const vtc_block_w &b, float *x, void *h, void *big, int n_seq, int L, int W, int heads, int causal, int dtype,
-                     hipStream_t s) {
+int attn_part_contig(Fold &f, const vtc_block_w &b, float *x, void *h, void *big, int n_seq, int L, int W, int heads, int causal,
+                     int dtype, hipStream_t s) {
   const int rows = n_seq * L;
   ProfRegion region(VTC_PROF_REGION_ATTN);
-  RUN(launch_layernorm(x, b.ln1_g, b.ln1_b, h, rows, W, dtype, nullptr, 1, false, s));
-  if (fused_attn_enabled() && qkv_attention_supported(L, heads, W, dtype, (size_t)rows)) {
+  if (!f.on && fused_attn_enabled() && qkv_attention_supported(L, heads, W, dtype, (size_t)rows)) {
+    RUN(launch_layernorm(x, b.ln1_g, b.ln1_b, h, rows, W, dtype, nullptr, 1, false, s));
     RUN(launch_qkv_attention(h, b.qkv_w, b.qkv_b, big, nullptr, n_seq, L, heads, causal, 1, 0, L, 0, 0, 1, (size_t)rows, dtype, s));
     RUN(gemm(big, b.out_w, b.out_b, x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
     return 0;
   }
-  RUN(gemm(h, b.qkv_w, b.qkv_b, big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+  RUN(ln_proj(f, x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, h, big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));
   RUN(launch_attention(big, h, nullptr, n_seq, L, heads, causal, 1, 0, L, 0, 0, 1, dtype, s));
-  RUN(gemm(h, b.out_w, b.out_b, x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+  RUN(resid_proj(f, h, b.out_w, b.out_b, x, rows, W, W, dtype, 0, s));
   return 0;
 }
 
@@ -133,6 +198,7 @@ inline int layer_dtype(const vtc_text_w *w, int l, int dtype) {
 struct VisionWs {
   float *x, *cls_tmp;
   void *h, *big, *lnp;
+  Fold fold;
   size_t total;
 };
 
@@ -140,7 +206,7 @@ VisionWs plan_vision(const vtc_vision_w *w, int n_items, int F, int dtype, void 
   Bump b(ws);
   VisionWs v;
   const int P = w->grid * w->grid, T = 1 + P * F, W = w->width;
-  const size_t rows = (size_t)n_items * T;
+  const size_t rows = (size_t)pad256(n_items * T);      // padded: the folded-LayerNorm GEMMs run whole 256-row tiles
   const size_t patch_elems = (size_t)n_items * F * P * 3 * w->patch * w->patch;
   size_t big_elems = rows * 4 * W;
   if (patch_elems > big_elems) big_elems = patch_elems;
@@ -149,6 +215,12 @@ VisionWs plan_vision(const vtc_vision_w *w, int n_items, int F, int dtype, void 
   v.big = b.take(big_elems * esz(dtype));
   v.cls_tmp = (float *)b.take((size_t)n_items * (F > P ? F : P) * W * 4);
   v.lnp = b.take((size_t)n_items * W * 4);
+  if (dtype != VTC_F32) {
+    v.fold.rows_pad = (int)rows;
+    v.fold.xb = b.take(rows * W * 2);
+    v.fold.part = (float *)b.take((size_t)(W / 64 + 1) * rows * 8);
+    v.fold.stat = (float *)b.take(rows * 8);
+  }
   v.total = b.off;
   return v;
 }
@@ -157,17 +229,25 @@ struct TextWs {
   float *x;
   void *h, *big, *lnp;
   int *eot;
+  Fold fold;
   size_t total;
 };
 
-TextWs plan_text(int rows, int n_seq, int W, int dtype, void *ws) {
+TextWs plan_text(int rows_, int n_seq, int W, int dtype, void *ws) {
   Bump b(ws);
   TextWs t;
-  t.x = (float *)b.take((size_t)rows * W * 4);
-  t.h = b.take((size_t)rows * W * esz(dtype));
-  t.big = b.take((size_t)rows * 4 * W * esz(dtype));
+  const size_t rows = (size_t)pad256(rows_);
+  t.x = (float *)b.take(rows * W * 4);
+  t.h = b.take(rows * W * esz(dtype));
+  t.big = b.take(rows * 4 * W * esz(dtype));
   t.lnp = b.take((size_t)n_seq * W * 4);
   t.eot = (int *)b.take((size_t)n_seq * 4);
+  if (dtype != VTC_F32) {
+    t.fold.rows_pad = (int)rows;
+    t.fold.xb = b.take(rows * W * 2);
+    t.fold.part = (float *)b.take((size_t)(W / 64 + 1) * rows * 8);
+    t.fold.stat = (float *)b.take(rows * 8);
+  }
   t.total = b.off;
   return t;
 }
@@ -215,6 +295,8 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
   RUN(launch_cls_rows(v.x, w->class_embedding, w->pos, n_items, T, W, s));
   RUN(launch_layernorm(v.x, w->ln_pre_g, w->ln_pre_b, v.x, rows, W, VTC_F32, nullptr, 1, false, s));
 
+  Fold &fold = v.fold;
+  fold.on = fold_usable(w->blocks, w->layers, W, dtype, tsf);
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
     {
@@ -225,16 +307,14 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
       // attends to every token (:81,:158) -- cls_global_attention -- and a patch query to cls + its
       // same-position frames (time, :161-185) or cls + its same-frame patches (space, :84-108): the
       // generic kernel over [cls, ...] sequences whose own cls output is discarded into cls_tmp.
-      RUN(launch_layernorm(v.x, b.lnt_g, b.lnt_b, v.h, rows, W, dtype, nullptr, 1, false, s));
-      RUN(gemm(v.h, b.tqkv_w, b.tqkv_b, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+      RUN(ln_proj(fold, v.x, b.lnt_g, b.lnt_b, b.tqkv_w, b.tqkv_b, b.tqkv_wf, b.tqkv_s, b.tqkv_c, v.h, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));
       RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * P, 1 + F, w->heads, 0, P, 0, T, 0, 1, P, dtype, s));
       RUN(launch_cls_global_attention(v.big, v.h, n_items, T, w->heads, dtype, s));
-      RUN(gemm(v.h, b.tout_w, b.tout_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
-      RUN(launch_layernorm(v.x, b.ln1_g, b.ln1_b, v.h, rows, W, dtype, nullptr, 1, false, s));
-      RUN(gemm(v.h, b.qkv_w, b.qkv_b, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+      RUN(resid_proj(fold, v.h, b.tout_w, b.tout_b, v.x, rows, W, W, dtype, 0, s));
+      RUN(ln_proj(fold, v.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, v.h, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));
       RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, P, 1, dtype, s));
       RUN(launch_cls_global_attention(v.big, v.h, n_items, T, w->heads, dtype, s));
-      RUN(gemm(v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+      RUN(resid_proj(fold, v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, 0, s));
     } else if (tsf && fused_attn_enabled() && qkv_attention_supported(1 + P, w->heads, W, dtype, (size_t)rows)) {
       // Same two branches with QKV + attention core in one kernel each (qkv_attn.hip): the attention output lands in
       // `big` (as [rows, W]); the packed qkv matrix never exists.
@@ -259,26 +339,24 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
       }
     } else if (tsf) {
       // temporal branch (timesformer_clip_alt.py:142-149): sequences = the F frames of one (item, patch)
-      RUN(launch_layernorm(v.x, b.lnt_g, b.lnt_b, v.h, rows, W, dtype, nullptr, 1, false, s));
-      RUN(gemm(v.h, b.tqkv_w, b.tqkv_b, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+      RUN(ln_proj(fold, v.x, b.lnt_g, b.lnt_b, b.tqkv_w, b.tqkv_b, b.tqkv_wf, b.tqkv_s, b.tqkv_c, v.h, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));
       RUN(launch_attention(v.big, v.h, nullptr, n_items * P, F, w->heads, 0, P, 1, T, F, 0, 1, dtype, s));
       if (b.tout_w) {
-        RUN(gemm(v.h, b.tout_w, b.tout_b, v.big, rows, W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
-        RUN(gemm(v.big, b.tfc_w, b.tfc_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, T, s));
+        RUN(gemm(v.h, b.tout_w, b.tout_b, v.big, fold.on ? fold.rows_pad : rows, W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+        RUN(resid_proj(fold, v.big, b.tfc_w, b.tfc_b, v.x, rows, W, W, dtype, T, s));
       } else {  // temporal_fc o out_proj pre-multiplied on the host
-        RUN(gemm(v.h, b.tfc_w, b.tfc_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, T, s));
+        RUN(resid_proj(fold, v.h, b.tfc_w, b.tfc_b, v.x, rows, W, W, dtype, T, s));
       }
       // spatial branch (:152-168): sequences = (item, frame): [cls, the P patches of that frame]
-      RUN(launch_layernorm(v.x, b.ln1_g, b.ln1_b, v.h, rows, W, dtype, nullptr, 1, false, s));
-      RUN(gemm(v.h, b.qkv_w, b.qkv_b, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
+      RUN(ln_proj(fold, v.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, v.h, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));
       RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, 1, F, dtype, s));
       RUN(launch_cls_mean(v.cls_tmp, v.h, dtype, n_items, F, T, W, s));
-      RUN(gemm(v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+      RUN(resid_proj(fold, v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, 0, s));
     } else {
-      RUN(attn_part_contig(b, v.x, v.h, v.big, n_items, T, W, w->heads, 0, dtype, s));
+      RUN(attn_part_contig(fold, b, v.x, v.h, v.big, n_items, T, W, w->heads, 0, dtype, s));
     }
     }
-    RUN(mlp_part(b, v.x, v.h, v.big, rows, W, dtype, s));
+    RUN(mlp_part(fold, b, v.x, v.h, v.big, rows, W, dtype, s));
   }
   // ln_post(x[:,0]) @ proj -- always fp32 (n_items rows only): the embedding the sweep ranks on
   // does not pick up a last bf16 rounding
@@ -304,11 +382,13 @@ extern "C" int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_s
   TextWs t = plan_text(rows, n_seq, W, dtype, ws);
   VTC_CHECK(ws_bytes >= t.total, "text_forward: workspace too small (%zu < %zu)", ws_bytes, t.total);
   RUN(launch_text_embed(ids, w->tok_emb, w->pos, t.x, t.eot, n_seq, w->ctx, W, w->vocab, s));
+  Fold &fold = t.fold;
+  fold.on = fold_usable(w->blocks, w->layers, W, dtype, false);
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
     const int dl = layer_dtype(w, l, dtype);
-    RUN(attn_part_contig(b, t.x, t.h, t.big, n_seq, w->ctx, W, w->heads, 1, dl, s));
-    RUN(mlp_part(b, t.x, t.h, t.big, rows, W, dl, s));
+    RUN(attn_part_contig(fold, b, t.x, t.h, t.big, n_seq, w->ctx, W, w->heads, 1, dl, s));
+    RUN(mlp_part(fold, b, t.x, t.h, t.big, rows, W, dl, s));
   }
   // ln_final on the EOT row only (LayerNorm is per-row, so gathering first is identical), then @ text_projection
   // (always fp32, as for the vision tower)
@@ -337,17 +417,18 @@ extern "C" int vtc_text_forward_ragged(const vtc_text_w *w, const int64_t *ids, 
   RUN(launch_text_embed_ragged(ids, w->tok_emb, w->pos, seq_offsets, t.x, t.eot, n_seq, w->ctx, W, w->vocab, rows, s));
   // attention work estimate for the profiler: mean-square length ~ (rows/n_seq)^2 is a lower bound; report rows*avg
   const double avgL = (double)rows / n_seq;
+  Fold &fold = t.fold;
+  fold.on = fold_usable(w->blocks, w->layers, W, dtype, false);
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
     const int dl = layer_dtype(w, l, dtype);
     {
       ProfRegion region(VTC_PROF_REGION_ATTN);
-      RUN(launch_layernorm(t.x, b.ln1_g, b.ln1_b, t.h, rows, W, dl, nullptr, 1, false, s));
-      RUN(gemm(t.h, b.qkv_w, b.qkv_b, t.big, rows, 3 * W, W, dl, VTC_EPI_STORE, dl, 0, s));
+      RUN(ln_proj(fold, t.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, t.h, t.big, rows, 3 * W, W, dl, VTC_EPI_STORE, s));
       RUN(launch_attention_ragged(t.big, t.h, n_seq, w->ctx, w->heads, 1, seq_offsets, 4.0 * avgL * rows * 64 * w->heads, dl, s));
-      RUN(gemm(t.h, b.out_w, b.out_b, t.x, rows, W, W, dl, VTC_EPI_RESID, VTC_F32, 0, s));
+      RUN(resid_proj(fold, t.h, b.out_w, b.out_b, t.x, rows, W, W, dl, 0, s));
     }
-    RUN(mlp_part(b, t.x, t.h, t.big, rows, W, dl, s));
+    RUN(mlp_part(fold, b, t.x, t.h, t.big, rows, W, dl, s));
   }
   RUN(launch_layernorm(t.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, VTC_F32, t.eot, 1, false, s));
   RUN(gemm(t.lnp, w->proj_t, nullptr, out, n_seq, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));
@@ -372,10 +453,11 @@ extern "C" int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, cons
   float *lin = (float *)((char *)ws + t.total);
   VTC_CHECK(ws_bytes >= vtc_cam_workspace_bytes(w, B, nc, dtype), "cam_forward: workspace too small");
   RUN(launch_cam_tokens(main_feats, comm_feats, comments, w->mask_embedding, t.x, B, nc, ctx, D, s));
+  Fold nofold;      // B (1 + nc) tokens: the LayerNorm kernels
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
-    RUN(attn_part_contig(b, t.x, t.h, t.big, B, Lc, D, w->heads, 0, dtype, s));
-    RUN(mlp_part(b, t.x, t.h, t.big, rows, D, dtype, s));
+    RUN(attn_part_contig(nofold, b, t.x, t.h, t.big, B, Lc, D, w->heads, 0, dtype, s));
+    RUN(mlp_part(nofold, b, t.x, t.h, t.big, rows, D, dtype, s));
   }
   if (!w->init_from_avg) {  // comm_res = final_linear(comm_tfm[0])   model/model.py:161
     RUN(launch_layernorm(t.x, nullptr, nullptr, t.lnp, B, D, dtype, nullptr, Lc, true, s));

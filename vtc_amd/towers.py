@@ -37,6 +37,9 @@ TEXT_RAGGED = __import__("os").environ.get("VTC_TEXT_RAGGED", "1") != "0"
 # embedding (tests/bf16_floor_study.py), above BASELINE's 1e-3 budget; layer 0 alone is 42 % of that variance.
 # 0 = plain bf16 everywhere.
 TEXT_HALF_LAYERS = int(__import__("os").environ.get("VTC_TEXT_HALF_LAYERS", "12"))
+# 16-bit modes: pack the gamma-scaled projection weights of the folded LayerNorm next to the plain ones (include/vtc_hip.h,
+# vtc_block_w *_wf / *_s / *_c); whether a forward uses them is the library's switch (vtc_set_ln_fold / VTC_LN_FOLD).
+LN_FOLD_PACK = __import__("os").environ.get("VTC_LN_FOLD_PACK", "1") != "0"
 _WS: Dict[tuple, torch.Tensor] = {}
 
 
@@ -72,13 +75,31 @@ def _n_layers(sd: SD, p: str) -> int:
     return 1 + max(int(k[len(pre):].split(".")[0]) for k in sd if k.startswith(pre))
 
 
+def _fold_ln(keep: "_Keep", w: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtype):
+    """LayerNorm folded into the projection behind it (include/vtc_hip.h, vtc_block_w): W' = gamma . W rounded to the operand
+    format, s = row sums of the ROUNDED W' (what the GEMM multiplies the mean by), c = bias + W beta -- sums in fp64."""
+    wf = (w.double() * gamma.double()[None, :]).float().to(dtype)
+    s = wf.double().sum(dim=1).float()
+    c = (bias.double() + w.double() @ beta.double()).float()
+    return keep.mat(wf, dtype), keep.f32(s), keep.f32(c)
+
+
 def _pack_blocks(sd: SD, p: str, layers: int, dtype, keep: _Keep, timesformer: bool, fuse_temporal: bool,
-                 half_layers: int = 0):
+                 half_layers: int = 0, fold_ln: bool = False):
     arr = (L.BlockW * layers)()
     base_dtype = dtype
+    fold_ln = fold_ln and base_dtype in (torch.bfloat16, torch.float16)
     for i in range(layers):
         q, b = f"{p}.resblocks.{i}", arr[i]
         dtype = torch.float16 if (base_dtype == torch.bfloat16 and i < half_layers) else base_dtype
+        if fold_ln:
+            b.qkv_wf, b.qkv_s, b.qkv_c = _fold_ln(keep, sd[f"{q}.attn.in_proj_weight"], sd[f"{q}.attn.in_proj_bias"],
+                                                  sd[f"{q}.ln_1.weight"], sd[f"{q}.ln_1.bias"], dtype)
+            b.fc_wf, b.fc_s, b.fc_c = _fold_ln(keep, sd[f"{q}.mlp.c_fc.weight"], sd[f"{q}.mlp.c_fc.bias"],
+                                               sd[f"{q}.ln_2.weight"], sd[f"{q}.ln_2.bias"], dtype)
+            if timesformer:
+                b.tqkv_wf, b.tqkv_s, b.tqkv_c = _fold_ln(keep, sd[f"{q}.timeattn.in_proj_weight"], sd[f"{q}.timeattn.in_proj_bias"],
+                                                         sd[f"{q}.ln_time.weight"], sd[f"{q}.ln_time.bias"], dtype)
         b.ln1_g, b.ln1_b = keep.f32(sd[f"{q}.ln_1.weight"]), keep.f32(sd[f"{q}.ln_1.bias"])
         b.qkv_w, b.qkv_b = keep.mat(sd[f"{q}.attn.in_proj_weight"], dtype), keep.f32(sd[f"{q}.attn.in_proj_bias"])
         b.out_w, b.out_b = keep.mat(sd[f"{q}.attn.out_proj.weight"], dtype), keep.f32(sd[f"{q}.attn.out_proj.bias"])
@@ -130,7 +151,7 @@ class PackedVision:
         w.ln_pre_g, w.ln_pre_b = k.f32(sd["ln_pre.weight"]), k.f32(sd["ln_pre.bias"])
         w.ln_post_g, w.ln_post_b = k.f32(sd["ln_post.weight"]), k.f32(sd["ln_post.bias"])
         w.proj_t = k.mat(sd["proj"].t(), torch.float32)
-        self.blocks = _pack_blocks(sd, "transformer", w.layers, dtype, k, bool(w.nframes), fuse_temporal)
+        self.blocks = _pack_blocks(sd, "transformer", w.layers, dtype, k, bool(w.nframes), fuse_temporal, fold_ln=LN_FOLD_PACK)
         w.blocks = self.blocks
         self.w = w
         self.res = w.grid * w.patch
@@ -175,7 +196,8 @@ class PackedText:
         w.ln_final_g, w.ln_final_b = k.f32(sd["ln_final.weight"]), k.f32(sd["ln_final.bias"])
         w.proj_t = k.mat(sd["text_projection"].t(), torch.float32)
         w.half_layers = min(w.layers, TEXT_HALF_LAYERS if half_layers is None else int(half_layers)) if dtype == torch.bfloat16 else 0
-        self.blocks = _pack_blocks(sd, "transformer", w.layers, dtype, k, False, False, half_layers=w.half_layers)
+        self.blocks = _pack_blocks(sd, "transformer", w.layers, dtype, k, False, False, half_layers=w.half_layers,
+                                   fold_ln=LN_FOLD_PACK)
         w.blocks = self.blocks
         self.w = w
 

@@ -57,6 +57,11 @@ template <typename T> __device__ __forceinline__ unsigned short cvt16(float f);
 template <> __device__ __forceinline__ unsigned short cvt16<bf16_t>(float f) { return f2bf(f); }
 template <> __device__ __forceinline__ unsigned short cvt16<f16_t>(float f) { return f2h(f); }
 
+// raw 16 bits of the operand format T -> float
+template <typename T> __device__ __forceinline__ float up16(unsigned short b);
+template <> __device__ __forceinline__ float up16<bf16_t>(unsigned short b) { return __builtin_bit_cast(float, ((unsigned)b) << 16); }
+template <> __device__ __forceinline__ float up16<f16_t>(unsigned short b) { return h2f(b); }
+
 template <typename T> struct ElemOps;
 template <> struct ElemOps<float> {
   static constexpr int kDtype = VTC_F32;
@@ -189,6 +194,9 @@ struct GemmEpi {
   //   (sum, sum of squares) of the row's 64 columns of this wave -- every tile interior (M % 256 == 0, N % 256 == 0);
   // consumer (modes 0 / 1, 16-bit output): A = y16, W = (g . W) rounded, bias = c, fold_stat[M] = (mean, rstd), fold_s = s.
   void *y16 = nullptr;
+  void *y16lo = nullptr;      // the residual stream is the pair (y16, y16lo): x = hi + lo, lo = fmt(x - hi) -- 16 + bits of
+                              // mantissa in bf16, the same 8 bytes per element per residual GEMM as an fp32 stream, and hi IS
+                              // the operand copy (no third array); `out` (fp32) is neither read nor written
   float *fold_part = nullptr;
   const float *fold_stat = nullptr, *fold_s = nullptr;
 };
@@ -204,6 +212,8 @@ bool gemm_patch_gather_supported(int n_frames, int grid, int patch, int res, int
 int launch_layernorm(const float *x, const float *g, const float *b, void *y, int rows, int width, int out_dtype,
                      const int *row_index, int row_mul, bool no_norm, hipStream_t stream);
 int launch_fold_stats(const float *part, int nb, int rows, float *stat, hipStream_t stream);
-int launch_cast_rowstats(const float *x, void *y16, float *stat, int rows, int width, int dtype, hipStream_t stream);
+int launch_cast_rowstats(const float *x, void *y16, void *y16lo, float *stat, int rows, int width, int dtype, hipStream_t stream);
+int launch_split_merge_rows(const void *hi, const void *lo, float *x, int n, int width, const int *row_index, int row_mul, int dtype,
+                            hipStream_t stream);
 int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2,
                      int a0, int a1, int a2, int a3, int pstride, int dtype, hipStream_t stream);

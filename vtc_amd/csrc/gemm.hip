@@ -395,12 +395,26 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     // 4.35 TB/s -- the copy rate of the chip -- at depth 2, 3 and 4 alike (3 = +14 VGPRs, 4 spills)
     constexpr int XD = VTC_RESID_DEPTH;
     float4 xr[XD][4];
+    // folded LayerNorm: the residual row is the 16-bit pair (hi, lo) of GemmEpi::y16 / y16lo -- fetched as two 8-byte loads
+    // into the same four registers the fp32 row would take: (hi.x, hi.y, lo.x, lo.y)
+    constexpr bool SPLIT = FOLD && MODE == VTC_EPI_RESID && sizeof(T) == 2;
+    auto x_load = [&](int pp, int k) -> float4 {
+      if constexpr (SPLIT) {
+        const int m = m0 + (wr * TM + pp / H) * 16 + (lane >> 4) + 4 * k;
+        const size_t e = (size_t)m * ldo + ncol0 + 64 * (pp % H) + l15 * 4;
+        const uint2 hi = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(p.epi.y16) + e);
+        const uint2 lo = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(p.epi.y16lo) + e);
+        return make_float4(__uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(lo.x), __uint_as_float(lo.y));
+      } else {
+        return *reinterpret_cast<const float4 *>(x_ptr(pp, k));
+      }
+    };
     if (MODE == VTC_EPI_RESID || MODE == EPI_RESID_LN) {
 #pragma unroll
       for (int a = 0; a < XD - 1; ++a)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (a < NP) xr[a][k] = *reinterpret_cast<const float4 *>(x_ptr(a, k));
+          if (a < NP) xr[a][k] = x_load(a, k);
     }
     // distance mode: |q|^2 of the lane's rows and |g|^2 of its columns are fetched once, in the MFMA layout, and the
     // distance is formed BEFORE the transposition: a load inside the pass loop sits behind the previous pass's
@@ -416,7 +430,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       const int ncolh = ncol0 + 64 * hh;
       if ((MODE == VTC_EPI_RESID || MODE == EPI_RESID_LN) && pp + XD - 1 < NP) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xr[(pp + XD - 1) % XD][k] = *reinterpret_cast<const float4 *>(x_ptr(pp + XD - 1, k));
+        for (int k = 0; k < 4; ++k) xr[(pp + XD - 1) % XD][k] = x_load(pp + XD - 1, k);
       }
       // 1. registers -> LDS: final fp32 values in [16 rows][64 cols]
 #pragma unroll
@@ -461,29 +475,41 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
             // the towers (tools/resid_ln_bench.py), and what makes the rows visible to the column tile that
             // completes the row block in EPI_RESID_LN without a release fence (MI355X_MICROARCH "Valid forms",
             // cdna_hip_programming Guideline 16 R1)
-            const float4 x = xr[pp % XD][k];
+            float4 x = xr[pp % XD][k];
+            if constexpr (SPLIT) {
+              const unsigned h0 = __float_as_uint(x.x), h1 = __float_as_uint(x.y), l0 = __float_as_uint(x.z), l1 = __float_as_uint(x.w);
+              x = make_float4(up16<T>((unsigned short)(h0 & 0xFFFFu)) + up16<T>((unsigned short)(l0 & 0xFFFFu)),
+                              up16<T>((unsigned short)(h0 >> 16)) + up16<T>((unsigned short)(l0 >> 16)),
+                              up16<T>((unsigned short)(h1 & 0xFFFFu)) + up16<T>((unsigned short)(l1 & 0xFFFFu)),
+                              up16<T>((unsigned short)(h1 >> 16)) + up16<T>((unsigned short)(l1 >> 16)));
+            }
             typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
             const float4 y = make_float4(live ? x.x + v.x : x.x, live ? x.y + v.y : x.y, live ? x.z + v.z : x.z, live ? x.w + v.w : x.w);
-            const v4u_t yy = {__float_as_uint(y.x), __float_as_uint(y.y), __float_as_uint(y.z), __float_as_uint(y.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(yy, out_rsrc, (int)((((size_t)m - m0u) * ldo + ncolh + cc) * 4), 0,
-                                                   MODE == EPI_RESID_LN ? 16 : VTC_RESID_AUX);
-            if constexpr (FOLD && MODE == VTC_EPI_RESID && sizeof(T) == 2) {
-              {                     // folded LayerNorm, producer side: the row in the operand format + this wave's partial statistics
-                uint2 pk;
-                pk.x = (unsigned)cvt16<T>(y.x) | ((unsigned)cvt16<T>(y.y) << 16);
-                pk.y = (unsigned)cvt16<T>(y.z) | ((unsigned)cvt16<T>(y.w) << 16);
-                *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(p.epi.y16) + (size_t)m * ldo + ncolh + cc) = pk;
-                // (sum, sum of squared deviations from the 64-column mean): merged exactly like a two-pass variance
-                // (fold_stats_kernel).  Over the 16 lanes of the row: xor 1, 2 in the quad, then half-row and row mirrors.
-                float s1 = (y.x + y.y) + (y.z + y.w);
-                s1 += dpp_f<0xB1>(s1); s1 += dpp_f<0x4E>(s1); s1 += dpp_f<0x141>(s1); s1 += dpp_f<0x140>(s1);
-                const float mp = s1 * (1.0f / 64.0f);
-                const float d0 = y.x - mp, d1 = y.y - mp, d2 = y.z - mp, d3 = y.w - mp;
-                float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-                q += dpp_f<0xB1>(q); q += dpp_f<0x4E>(q); q += dpp_f<0x141>(q); q += dpp_f<0x140>(q);
-                if (l15 == 0)
-                  *reinterpret_cast<float2 *>(p.epi.fold_part + 2 * ((size_t)(ncolh >> 6) * p.M + m)) = make_float2(s1, q);
-              }
+            if constexpr (!SPLIT) {
+              const v4u_t yy = {__float_as_uint(y.x), __float_as_uint(y.y), __float_as_uint(y.z), __float_as_uint(y.w)};
+              __builtin_amdgcn_raw_buffer_store_b128(yy, out_rsrc, (int)((((size_t)m - m0u) * ldo + ncolh + cc) * 4), 0,
+                                                     MODE == EPI_RESID_LN ? 16 : VTC_RESID_AUX);
+            } else {
+              // producer side of the folded LayerNorm: the updated row as (hi, lo) + this wave's partial statistics
+              const unsigned short q0 = cvt16<T>(y.x), q1 = cvt16<T>(y.y), q2 = cvt16<T>(y.z), q3 = cvt16<T>(y.w);
+              uint2 pk, pl;
+              pk.x = (unsigned)q0 | ((unsigned)q1 << 16);
+              pk.y = (unsigned)q2 | ((unsigned)q3 << 16);
+              pl.x = (unsigned)cvt16<T>(y.x - up16<T>(q0)) | ((unsigned)cvt16<T>(y.y - up16<T>(q1)) << 16);
+              pl.y = (unsigned)cvt16<T>(y.z - up16<T>(q2)) | ((unsigned)cvt16<T>(y.w - up16<T>(q3)) << 16);
+              const size_t e = (size_t)m * ldo + ncolh + cc;
+              *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(p.epi.y16) + e) = pk;
+              *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(p.epi.y16lo) + e) = pl;
+              // (sum, sum of squared deviations from the 64-column mean): merged exactly like a two-pass variance
+              // (fold_stats_kernel).  Over the 16 lanes of the row: xor 1, 2 in the quad, then half-row and row mirrors.
+              float s1 = (y.x + y.y) + (y.z + y.w);
+              s1 += dpp_f<0xB1>(s1); s1 += dpp_f<0x4E>(s1); s1 += dpp_f<0x141>(s1); s1 += dpp_f<0x140>(s1);
+              const float mp = s1 * (1.0f / 64.0f);
+              const float d0 = y.x - mp, d1 = y.y - mp, d2 = y.z - mp, d3 = y.w - mp;
+              float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+              q += dpp_f<0xB1>(q); q += dpp_f<0x4E>(q); q += dpp_f<0x141>(q); q += dpp_f<0x140>(q);
+              if (l15 == 0)
+                *reinterpret_cast<float2 *>(p.epi.fold_part + 2 * ((size_t)(ncolh >> 6) * p.M + m)) = make_float2(s1, q);
             }
           } else {
             store16<nt_out>(o, v);
@@ -1243,7 +1269,7 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
   if (epi.y16 || epi.fold_stat) {     // folded LayerNorm: only the interior fast epilogues carry it
     VTC_CHECK(esz == 2 && M % 256 == 0 && N % 256 == 0 && (epi.ldo == 0 || epi.ldo == N),
               "gemm: folded LayerNorm needs 16-bit operands and M, N multiples of 256 (M=%d N=%d dtype=%d)", M, N, dtype);
-    VTC_CHECK(epi.y16 ? (epi.mode == VTC_EPI_RESID && epi.fold_part != nullptr)
+    VTC_CHECK(epi.y16 ? (epi.mode == VTC_EPI_RESID && epi.fold_part != nullptr && epi.y16lo != nullptr)
                       : ((epi.mode == VTC_EPI_STORE || epi.mode == VTC_EPI_GELU) && epi.out_dtype != VTC_F32 && epi.fold_s != nullptr),
               "gemm: folded LayerNorm arguments do not go with epilogue %d", epi.mode);
   }

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void fold_stats_kernel(const float2 *__restric
 
 // Layer 0 has no residual GEMM in front of it: y16 = x in the operand format, stat = (mean, rstd) as LayerNorm computes them.
 template <typename OutT>
-__global__ __launch_bounds__(256) void cast_rowstats_kernel(const float *__restrict__ x, OutT *__restrict__ y, float2 *__restrict__ stat,
-                                                            int rows, int width) {
+__global__ __launch_bounds__(256) void cast_rowstats_kernel(const float *__restrict__ x, OutT *__restrict__ y, OutT *__restrict__ ylo,
+                                                            float2 *__restrict__ stat, int rows, int width) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -86,10 +86,42 @@ __global__ __launch_bounds__(256) void cast_rowstats_kernel(const float *__restr
       pk.z = (unsigned)cvt16<OutT>(v[i][1].x) | ((unsigned)cvt16<OutT>(v[i][1].y) << 16);
       pk.w = (unsigned)cvt16<OutT>(v[i][1].z) | ((unsigned)cvt16<OutT>(v[i][1].w) << 16);
       *reinterpret_cast<uint4 *>(y + (size_t)r * width + c) = pk;
+      // lo = fmt(x - hi): the pair carries the row to 2^-17 (bf16) / 2^-22 (half) relative
+      const float o[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
+      const unsigned hw[4] = {pk.x, pk.y, pk.z, pk.w};
+      unsigned lw[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float l0 = o[2 * e] - up16<OutT>((unsigned short)(hw[e] & 0xFFFFu)), l1 = o[2 * e + 1] - up16<OutT>((unsigned short)(hw[e] >> 16));
+        lw[e] = (unsigned)cvt16<OutT>(l0) | ((unsigned)cvt16<OutT>(l1) << 16);
+      }
+      *reinterpret_cast<uint4 *>(ylo + (size_t)r * width + c) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / width + 1e-5f);
   if (lane == 0) stat[r] = make_float2(mean, rstd);
+}
+
+// x[src] = hi[src] + lo[src] for the rows src = row_index[i] (or i * row_mul): the fp32 rows the final LayerNorm reads
+template <typename T>
+__global__ __launch_bounds__(256) void split_merge_rows_kernel(const T *__restrict__ hi, const T *__restrict__ lo, float *__restrict__ x,
+                                                               int n, int width, const int *__restrict__ row_index, int row_mul) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const size_t src = row_index ? (size_t)row_index[i] : (size_t)i * row_mul;
+  for (int c = lane * 8; c < width; c += 512) {
+    const uint4 h = *reinterpret_cast<const uint4 *>(hi + src * width + c), l = *reinterpret_cast<const uint4 *>(lo + src * width + c);
+    const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] = up16<T>((unsigned short)(hw[e] & 0xFFFFu)) + up16<T>((unsigned short)(lw[e] & 0xFFFFu));
+      o[2 * e + 1] = up16<T>((unsigned short)(hw[e] >> 16)) + up16<T>((unsigned short)(lw[e] >> 16));
+    }
+    *reinterpret_cast<float4 *>(x + src * width + c) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4 *>(x + src * width + c + 4) = make_float4(o[4], o[5], o[6], o[7]);
+  }
 }
 
 __global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict__ x, float *__restrict__ out, int n, int d) {
@@ -162,14 +194,26 @@ int launch_fold_stats(const float *part, int nb, int rows, float *stat, hipStrea
   return 0;
 }
 
-int launch_cast_rowstats(const float *x, void *y16, float *stat, int rows, int width, int dtype, hipStream_t stream) {
+int launch_cast_rowstats(const float *x, void *y16, void *y16lo, float *stat, int rows, int width, int dtype, hipStream_t stream) {
   VTC_CHECK(width % 8 == 0 && width <= 512 * LN_MAXV && (dtype == VTC_BF16 || dtype == VTC_F16), "cast_rowstats: width=%d dtype=%d", width, dtype);
-  ProfScope prof(VTC_PROF_NORM, (double)rows * width * 6, stream);
+  ProfScope prof(VTC_PROF_NORM, (double)rows * width * 8, stream);
   if (dtype == VTC_F16)
-    hipLaunchKernelGGL((cast_rowstats_kernel<f16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, (f16_t *)y16, (float2 *)stat, rows, width);
+    hipLaunchKernelGGL((cast_rowstats_kernel<f16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, (f16_t *)y16, (f16_t *)y16lo, (float2 *)stat, rows, width);
   else
-    hipLaunchKernelGGL((cast_rowstats_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, (bf16_t *)y16, (float2 *)stat, rows, width);
+    hipLaunchKernelGGL((cast_rowstats_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, (bf16_t *)y16, (bf16_t *)y16lo, (float2 *)stat, rows, width);
   VTC_LAUNCH_CHECK("cast_rowstats");
+  return 0;
+}
+
+int launch_split_merge_rows(const void *hi, const void *lo, float *x, int n, int width, const int *row_index, int row_mul, int dtype,
+                            hipStream_t stream) {
+  VTC_CHECK(width % 8 == 0 && (dtype == VTC_BF16 || dtype == VTC_F16), "split_merge_rows: width=%d dtype=%d", width, dtype);
+  ProfScope prof(VTC_PROF_NORM, (double)n * width * 8, stream);
+  if (dtype == VTC_F16)
+    hipLaunchKernelGGL((split_merge_rows_kernel<f16_t>), dim3(cdiv(n, 4)), dim3(256), 0, stream, (const f16_t *)hi, (const f16_t *)lo, x, n, width, row_index, row_mul);
+  else
+    hipLaunchKernelGGL((split_merge_rows_kernel<bf16_t>), dim3(cdiv(n, 4)), dim3(256), 0, stream, (const bf16_t *)hi, (const bf16_t *)lo, x, n, width, row_index, row_mul);
+  VTC_LAUNCH_CHECK("split_merge_rows");
   return 0;
 }
 

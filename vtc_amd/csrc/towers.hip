@@ -122,12 +122,19 @@ bool ln_fold_enabled() {
 }
 struct Fold {
   bool on = false;
-  void *xb = nullptr;       // [rows_pad, W] operand format: the residual stream as the projections read it
+  void *xb = nullptr;       // [rows_pad, W] operand format: the residual stream as the projections read it (hi of the pair)
+  void *xl = nullptr;       // [rows_pad, W] operand format: lo of the pair -- between layer 0's cast and the final merge the
+                            // stream lives in (xb, xl) and the fp32 x is stale (GemmEpi::y16lo)
   float *part = nullptr;    // [W / 64][rows_pad] (sum, squared deviations)
   float *stat = nullptr;    // [rows_pad] (mean, rstd)
   int rows_pad = 0;
-  int fmt = -1;             // operand format xb / stat currently hold (-1: stale)
+  int fmt = -1;             // operand format (xb, xl) / stat currently hold (-1: the stream is the fp32 x)
 };
+// the fp32 rows a final LayerNorm reads (rows i * row_mul, or row_index[i]) out of the pair
+int fold_merge_rows(Fold &f, float *x, int n, int W, const int *row_index, int row_mul, hipStream_t s) {
+  if (!f.on || f.fmt < 0) return 0;
+  return launch_split_merge_rows(f.xb, f.xl, x, n, W, row_index, row_mul, f.fmt, s);
+}
 inline int pad256(int rows) { return (rows + 255) / 256 * 256; }
 bool fold_usable(const vtc_block_w *blocks, int layers, int W, int dtype, bool timesformer) {
   if (!ln_fold_enabled() || dtype == VTC_F32 || W % 256 != 0 || fused_attn_mask()) return false;
@@ -140,8 +147,9 @@ bool fold_usable(const vtc_block_w *blocks, int layers, int W, int dtype, bool t
 int ln_proj(Fold &f, const float *x, const float *g, const float *bt, const void *w, const float *bias, const void *wf, const float *fs,
             const float *fc, void *h, void *out, int rows, int N, int W, int dtype, int mode, hipStream_t s) {
   if (f.on) {
-    if (f.fmt != dtype) {       // no residual GEMM of this format in front (layer 0, a format boundary)
-      RUN(launch_cast_rowstats(x, f.xb, f.stat, rows, W, dtype, s));
+    if (f.fmt != dtype) {       // no residual GEMM of this format in front: layer 0, or a format boundary (back through fp32)
+      if (f.fmt >= 0) RUN(launch_split_merge_rows(f.xb, f.xl, const_cast<float *>(x), rows, W, nullptr, 1, f.fmt, s));
+      RUN(launch_cast_rowstats(x, f.xb, f.xl, f.stat, rows, W, dtype, s));
       f.fmt = dtype;
     }
     GemmEpi e;
@@ -157,9 +165,13 @@ int resid_proj(Fold &f, const void *A, const void *w, const float *bias, float *
                hipStream_t s) {
   if (f.on) {
     GemmEpi e;
-    e.mode = VTC_EPI_RESID; e.out_dtype = VTC_F32; e.skip_mod = skip_mod; e.y16 = f.xb; e.fold_part = f.part;
+    e.mode = VTC_EPI_RESID; e.out_dtype = VTC_F32; e.skip_mod = skip_mod; e.y16 = f.xb; e.y16lo = f.xl; e.fold_part = f.part;
+    if (f.fmt != dtype) {       // the stream is not a pair of this format yet (cannot happen behind ln_proj; kept for safety)
+      if (f.fmt >= 0) RUN(launch_split_merge_rows(f.xb, f.xl, x, rows, W, nullptr, 1, f.fmt, s));
+      RUN(launch_cast_rowstats(x, f.xb, f.xl, f.stat, rows, W, dtype, s));
+      f.fmt = dtype;
+    }
     RUN(launch_gemm(A, w, bias, x, f.rows_pad, W, K, dtype, e, s));
-    f.fmt = dtype;
     return launch_fold_stats(f.part, W / 64, f.rows_pad, f.stat, s);
   }
   return gemm(A, w, bias, x, rows, W, K, dtype, VTC_EPI_RESID, VTC_F32, skip_mod, s);
@@ -218,6 +230,7 @@ VisionWs plan_vision(const vtc_vision_w *w, int n_items, int F, int dtype, void 
   if (dtype != VTC_F32) {
     v.fold.rows_pad = (int)rows;
     v.fold.xb = b.take(rows * W * 2);
+    v.fold.xl = b.take(rows * W * 2);
     v.fold.part = (float *)b.take((size_t)(W / 64 + 1) * rows * 8);
     v.fold.stat = (float *)b.take(rows * 8);
   }
@@ -245,6 +258,7 @@ TextWs plan_text(int rows_, int n_seq, int W, int dtype, void *ws) {
   if (dtype != VTC_F32) {
     t.fold.rows_pad = (int)rows;
     t.fold.xb = b.take(rows * W * 2);
+    t.fold.xl = b.take(rows * W * 2);
     t.fold.part = (float *)b.take((size_t)(W / 64 + 1) * rows * 8);
     t.fold.stat = (float *)b.take(rows * 8);
   }
@@ -360,6 +374,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
   }
   // ln_post(x[:,0]) @ proj -- always fp32 (n_items rows only): the embedding the sweep ranks on
   // does not pick up a last bf16 rounding
+  RUN(fold_merge_rows(fold, v.x, n_items, W, nullptr, T, s));
   RUN(launch_layernorm(v.x, w->ln_post_g, w->ln_post_b, v.lnp, n_items, W, VTC_F32, nullptr, T, false, s));
   RUN(gemm(v.lnp, w->proj_t, nullptr, out, n_items, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));
   return 0;
@@ -392,6 +407,7 @@ extern "C" int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_s
   }
   // ln_final on the EOT row only (LayerNorm is per-row, so gathering first is identical), then @ text_projection
   // (always fp32, as for the vision tower)
+  RUN(fold_merge_rows(fold, t.x, n_seq, W, t.eot, 1, s));
   RUN(launch_layernorm(t.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, VTC_F32, t.eot, 1, false, s));
   RUN(gemm(t.lnp, w->proj_t, nullptr, out, n_seq, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));
   return 0;
@@ -430,6 +446,7 @@ extern "C" int vtc_text_forward_ragged(const vtc_text_w *w, const int64_t *ids, 
     }
     RUN(mlp_part(fold, b, t.x, t.h, t.big, rows, W, dl, s));
   }
+  RUN(fold_merge_rows(fold, t.x, n_seq, W, t.eot, 1, s));
   RUN(launch_layernorm(t.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, VTC_F32, t.eot, 1, false, s));
   RUN(gemm(t.lnp, w->proj_t, nullptr, out, n_seq, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));
   return 0;

@@ -1017,12 +1017,31 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
 #endif
         // (d) the MFMA cluster
         __builtin_amdgcn_s_setprio(1);
+#ifdef VTC_PROBE_MFMA32   // TIMING PROBE ONLY (wrong results): the phase's 16 x (16x16x32) as 8 x (32x32x16) on the same registers
+        if constexpr (sizeof(T) == 2) {
+          typedef float f32x16 __attribute__((ext_vector_type(16)));
+          typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+          f32x16 c0, c1;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { c0[e] = acc[qm * 4 + qn * 2][e >> 2][e & 3]; c1[e] = acc[qm * 4 + qn * 2 + 1][e >> 2][e & 3]; }
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, wS[j][ks]), __builtin_bit_cast(pbf16x8, aS[2 * j][ks]), c0, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, wS[j][ks]), __builtin_bit_cast(pbf16x8, aS[2 * j + 1][ks]), c1, 0, 0, 0);
+            }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { acc[qm * 4 + qn * 2][e >> 2][e & 3] = c0[e]; acc[qm * 4 + qn * 2 + 1][e >> 2][e & 3] = c1[e]; }
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) Mma<T>::run(wS[j][ks], aS[i][ks], acc[qm * 4 + i][qn * 2 + j]);
+#endif
         __builtin_amdgcn_s_setprio(0);
         // (e) my pieces of every quarter but the newest have landed; the barrier makes that everybody's.  A
         //     quarter is read three phases after its issue at the earliest, and the half of the workgroup that runs

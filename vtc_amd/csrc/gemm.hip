@@ -805,13 +805,21 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmParams p)
   const int nb_x = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);
   const int nt_x = (ntiles >> 3) + (xcd < (ntiles & 7) ? 1 : 0);
   const int start_x = xcd * (ntiles >> 3) + min(xcd, ntiles & 7);
+  // Logical order: column groups of `cg` column tiles (all of them when col_group == 0); inside a group super-rows of SUPER
+  // row blocks, inside a super-row column by column.  A group's weight panels are what an XCD keeps in its L2 while it walks
+  // down the rows.
+  const int cg = p.col_group > 0 ? min(p.col_group, p.NT) : p.NT;
   auto decode = [&](int logical, int &m0, int &n0) {
-    const int per_super = SUPER * p.NT;
-    const int sr = logical / per_super, rem = logical - sr * per_super;
+    const int full = p.MT * cg;
+    const int gi = logical / full;
+    const int c0 = gi * cg, cgi = min(cg, p.NT - c0);
+    const int in_g = logical - gi * full;
+    const int per_super = SUPER * cgi;
+    const int sr = in_g / per_super, rem = in_g - sr * per_super;
     const int gsz = min(SUPER, p.MT - sr * SUPER);
     const int nt = rem / gsz;
     m0 = (sr * SUPER + (rem - nt * gsz)) * BM;
-    n0 = nt * BN;
+    n0 = (c0 + nt) * BN;
   };
   int li = slot;
   if (li >= nt_x) return;                      // uniform for the whole workgroup
@@ -1293,11 +1301,12 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
               "gemm: folded LayerNorm arguments do not go with epilogue %d", epi.mode);
   }
   // diagnostics knobs, read once (C++11 static initialisation is thread-safe; never written afterwards)
-  struct Env { int tile = 0, exp_arg = 0, sg = 0, st = 0; };
+  struct Env { int tile = 0, exp_arg = 0, sg = 0, st = 0, cg = -1; };
   static const Env env = [] {
     Env v;
     if (const char *e = getenv("VTC_GEMM_TILE")) v.tile = atoi(e);
     if (const char *e = getenv("VTC_GEMM_EXP")) v.exp_arg = atoi(e);
+    if (const char *e = getenv("VTC_GEMM_CG")) v.cg = atoi(e);
     if (const char *e = getenv("VTC_GEMM_STAGGER")) sscanf(e, "%d,%d", &v.sg, &v.st);
     return v;
   }();
@@ -1309,6 +1318,7 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
   p.ldo = epi.ldo > 0 ? epi.ldo : N;
   p.MT = 0; p.NT = 0;
   p.exp_arg = env.exp_arg;
+  p.col_group = env.cg >= 0 ? env.cg : 0;
   p.stagger_groups = env.sg; p.stagger_ticks = env.st;
   p.epi = epi;
   ProfScope prof(dtype != VTC_F32 ? VTC_PROF_GEMM_BF16 : VTC_PROF_GEMM_F32, 2.0 * M * N * K, stream);   // 16-bit operand class

@@ -56,6 +56,7 @@ struct GemmParams {
   int lda_bytes, ldw_bytes, ldo;
   int MT, NT;
   int exp_arg;   // diagnostics only (env VTC_GEMM_EXP), 0 in production
+  int col_group;   // phased kernel: column tiles per group of the tile walk (0 = all NT columns in one group)
   int stagger_groups, stagger_ticks;   // phased kernel: workgroup (slot % groups) starts (slot % groups) * ticks x 10 ns late
 #ifdef VTC_GEMM_STAMPS
   unsigned long long *dbg;   // diagnostic build: per-wave phase cycle sums

@@ -490,3 +490,18 @@ def test_folded_layernorm_and_layernorm_kernels_agree_with_the_oracle():
     for name in ("alt", "v1", "img", "txt", "txt_dense"):
         d = np.abs(unit(outs[(name, 1)]) - unit(outs[(name, 0)])).max()
         assert 0 < d < 1e-3, (name, d)          # two rounding regimes of the same tower: different bits, same embedding
+
+
+def test_folded_layernorm_is_insensitive_to_a_row_mean():
+    """The folded LayerNorm rounds x itself (not LN(x)) to the operand format, so a row mean large against the row's spread
+    would cost precision -- the (hi, lo) stream is therefore stored centred (every reader is a LayerNorm: a per-row constant
+    is invisible to it; gemm.hip SPLIT, norm.hip cast_rowstats_kernel).  ln_pre.bias + 10 puts |mean| / std at ~10 on every
+    row of every layer's input: the embedding must stay within the bf16 tolerance of the fp32 oracle."""
+    from vtc_amd import towers
+    a = A.VIT_B32
+    img = A.synth_pixels((4, 3, 224, 224), 7)
+    sd = A.synth_visual(a, 104, prefix="v.")
+    sd["v.ln_pre.bias"] = sd["v.ln_pre.bias"] + 10.0
+    ref = CR.encode_image(img, sd, a, "v.").numpy()
+    got = towers.PackedVision(cuda_sd(sd), "v.", torch.bfloat16).forward(img.cuda()).cpu().numpy()
+    report("image tower, DC offset 10 on the residual rows", np.abs(unit(got) - unit(ref)).max(), 1e-3)

@@ -398,6 +398,23 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     // folded LayerNorm: the residual row is the 16-bit pair (hi, lo) of GemmEpi::y16 / y16lo -- fetched as two 8-byte loads
     // into the same four registers the fp32 row would take: (hi.x, hi.y, lo.x, lo.y)
     constexpr bool SPLIT = FOLD && MODE == VTC_EPI_RESID && sizeof(T) == 2;
+    // ... and kept CENTRED: every reader of the stream is a LayerNorm, which does not see a per-row constant, so the row's
+    // mean BEFORE this update (fold_stat, left by the statistics pass behind the previous residual GEMM) is subtracted on the
+    // way -- the stored rows keep |mean| << std, and the rounding of hi, relative to |x|, stays relative to the spread that
+    // the LayerNorm divides by (tools/fold_dc_probe.py: without this a DC offset of 10 std costs 1.5e-3).  The wave's
+    // TM * 16 means wait in its LDS scratch behind the transposition buffer.
+    [[maybe_unused]] float *mean_prev = tr + 16 * TS;
+    if constexpr (SPLIT) {
+      static_assert((16 * TS + TM * 16) * 4 <= SCRATCH_PER_WAVE, "folded LayerNorm: previous means in the wave's scratch");
+#pragma unroll
+      for (int q = 0; q < (TM * 16 + 63) / 64; ++q) {
+        const int r = lane + 64 * q;
+        if (TM * 16 % 64 == 0 || r < TM * 16) mean_prev[r] = p.epi.fold_stat[2 * (size_t)(m0 + wr * TM * 16 + r)];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     auto x_load = [&](int pp, int k) -> float4 {
       if constexpr (SPLIT) {
         const int m = m0 + (wr * TM + pp / H) * 16 + (lane >> 4) + 4 * k;
@@ -478,10 +495,11 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
             float4 x = xr[pp % XD][k];
             if constexpr (SPLIT) {
               const unsigned h0 = __float_as_uint(x.x), h1 = __float_as_uint(x.y), l0 = __float_as_uint(x.z), l1 = __float_as_uint(x.w);
-              x = make_float4(up16<T>((unsigned short)(h0 & 0xFFFFu)) + up16<T>((unsigned short)(l0 & 0xFFFFu)),
-                              up16<T>((unsigned short)(h0 >> 16)) + up16<T>((unsigned short)(l0 >> 16)),
-                              up16<T>((unsigned short)(h1 & 0xFFFFu)) + up16<T>((unsigned short)(l1 & 0xFFFFu)),
-                              up16<T>((unsigned short)(h1 >> 16)) + up16<T>((unsigned short)(l1 >> 16)));
+              const float mu = mean_prev[i * 16 + r];
+              x = make_float4((up16<T>((unsigned short)(h0 & 0xFFFFu)) - mu) + up16<T>((unsigned short)(l0 & 0xFFFFu)),
+                              (up16<T>((unsigned short)(h0 >> 16)) - mu) + up16<T>((unsigned short)(l0 >> 16)),
+                              (up16<T>((unsigned short)(h1 & 0xFFFFu)) - mu) + up16<T>((unsigned short)(l1 & 0xFFFFu)),
+                              (up16<T>((unsigned short)(h1 >> 16)) - mu) + up16<T>((unsigned short)(l1 >> 16)));
             }
             typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
             const float4 y = make_float4(live ? x.x + v.x : x.x, live ? x.y + v.y : x.y, live ? x.z + v.z : x.z, live ? x.w + v.w : x.w);
@@ -1296,7 +1314,7 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
   if (epi.y16 || epi.fold_stat) {     // folded LayerNorm: only the interior fast epilogues carry it
     VTC_CHECK(esz == 2 && M % 256 == 0 && N % 256 == 0 && (epi.ldo == 0 || epi.ldo == N),
               "gemm: folded LayerNorm needs 16-bit operands and M, N multiples of 256 (M=%d N=%d dtype=%d)", M, N, dtype);
-    VTC_CHECK(epi.y16 ? (epi.mode == VTC_EPI_RESID && epi.fold_part != nullptr && epi.y16lo != nullptr)
+    VTC_CHECK(epi.y16 ? (epi.mode == VTC_EPI_RESID && epi.fold_part != nullptr && epi.y16lo != nullptr && epi.fold_stat != nullptr)
                       : ((epi.mode == VTC_EPI_STORE || epi.mode == VTC_EPI_GELU) && epi.out_dtype != VTC_F32 && epi.fold_s != nullptr),
               "gemm: folded LayerNorm arguments do not go with epilogue %d", epi.mode);
   }

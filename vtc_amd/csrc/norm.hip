@@ -80,14 +80,16 @@ __global__ __launch_bounds__(256) void cast_rowstats_kernel(const float *__restr
         const float a = v[i][h].x - mean, b = v[i][h].y - mean, cc = v[i][h].z - mean, d = v[i][h].w - mean;
         q += (a * a + b * b) + (cc * cc + d * d);
       }
+      // the stream is stored CENTRED (x - mean): its only readers are LayerNorms (gemm.hip, SPLIT)
+      const float o[8] = {v[i][0].x - mean, v[i][0].y - mean, v[i][0].z - mean, v[i][0].w - mean,
+                          v[i][1].x - mean, v[i][1].y - mean, v[i][1].z - mean, v[i][1].w - mean};
       uint4 pk;
-      pk.x = (unsigned)cvt16<OutT>(v[i][0].x) | ((unsigned)cvt16<OutT>(v[i][0].y) << 16);
-      pk.y = (unsigned)cvt16<OutT>(v[i][0].z) | ((unsigned)cvt16<OutT>(v[i][0].w) << 16);
-      pk.z = (unsigned)cvt16<OutT>(v[i][1].x) | ((unsigned)cvt16<OutT>(v[i][1].y) << 16);
-      pk.w = (unsigned)cvt16<OutT>(v[i][1].z) | ((unsigned)cvt16<OutT>(v[i][1].w) << 16);
+      pk.x = (unsigned)cvt16<OutT>(o[0]) | ((unsigned)cvt16<OutT>(o[1]) << 16);
+      pk.y = (unsigned)cvt16<OutT>(o[2]) | ((unsigned)cvt16<OutT>(o[3]) << 16);
+      pk.z = (unsigned)cvt16<OutT>(o[4]) | ((unsigned)cvt16<OutT>(o[5]) << 16);
+      pk.w = (unsigned)cvt16<OutT>(o[6]) | ((unsigned)cvt16<OutT>(o[7]) << 16);
       *reinterpret_cast<uint4 *>(y + (size_t)r * width + c) = pk;
       // lo = fmt(x - hi): the pair carries the row to 2^-17 (bf16) / 2^-22 (half) relative
-      const float o[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
       const unsigned hw[4] = {pk.x, pk.y, pk.z, pk.w};
       unsigned lw[4];
 #pragma unroll
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void cast_rowstats_kernel(const float *__restr
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / width + 1e-5f);
-  if (lane == 0) stat[r] = make_float2(mean, rstd);
+  if (lane == 0) stat[r] = make_float2(0.0f, rstd);       // the mean of the stored (centred) row
 }
 
 // x[src] = hi[src] + lo[src] for the rows src = row_index[i] (or i * row_mul): the fp32 rows the final LayerNorm reads

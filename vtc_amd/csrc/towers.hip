@@ -166,6 +166,7 @@ int resid_proj(Fold &f, const void *A, const void *w, const float *bias, float *
   if (f.on) {
     GemmEpi e;
     e.mode = VTC_EPI_RESID; e.out_dtype = VTC_F32; e.skip_mod = skip_mod; e.y16 = f.xb; e.y16lo = f.xl; e.fold_part = f.part;
+    e.fold_stat = f.stat;       // the rows' means before this update: the stream is stored centred (gemm.hip, SPLIT)
     if (f.fmt != dtype) {       // the stream is not a pair of this format yet (cannot happen behind ln_proj; kept for safety)
       if (f.fmt >= 0) RUN(launch_split_merge_rows(f.xb, f.xl, x, rows, W, nullptr, 1, f.fmt, s));
       RUN(launch_cast_rowstats(x, f.xb, f.xl, f.stat, rows, W, dtype, s));

@@ -154,3 +154,38 @@ def test_timesformer_modules_export_the_tower_class():
     assert {"transformer.resblocks.0.temporal_fc.weight", "transformer.resblocks.0.timeattn.in_proj_weight",
             "transformer.resblocks.0.ln_time.weight", "temporal_embed", "proj", "conv1.weight"} <= keys
     assert not any("temporal_fc" in k for k in v1.VisualTransformer(64, 16, 128, 1, 2, 64, 4).state_dict())
+
+
+def test_fold_ln_packing_identity_fp64():
+    """Host logic of the folded LayerNorm (vtc_amd/towers.py::_fold_ln, include/vtc_hip.h vtc_block_w *_wf/_s/_c):
+    LN(x) W^T + b == rstd (x W'^T - mean s) + c with W' = gamma . W, s = row sums of W', c = b + W beta -- checked in fp64
+    on the packed tensors (fp32 'operand format' so that no rounding enters), shifted rows included (LayerNorm does not
+    see a per-row constant: the stream may be stored centred)."""
+    import torch
+    from vtc_amd import towers
+
+    class Keep:
+        def __init__(self):
+            self.t = []
+
+        def mat(self, t, dtype):
+            self.t.append(t.detach().to(dtype).contiguous())
+            return len(self.t) - 1
+
+        def f32(self, t):
+            return self.mat(t, torch.float32)
+
+    g = torch.Generator().manual_seed(0)
+    W, N, M = 64, 48, 10
+    w, b = torch.randn(N, W, generator=g, dtype=torch.float64), torch.randn(N, generator=g, dtype=torch.float64)
+    gamma, beta = torch.randn(W, generator=g, dtype=torch.float64), torch.randn(W, generator=g, dtype=torch.float64)
+    x = torch.randn(M, W, generator=g, dtype=torch.float64) * 3 + 5
+    k = Keep()
+    iw, i_s, ic = towers._fold_ln(k, w, b, gamma, beta, torch.float64)
+    wf, s, c = k.t[iw].double(), k.t[i_s].double(), k.t[ic].double()
+    ref = torch.nn.functional.layer_norm(x, (W,), gamma, beta, 1e-5) @ w.t() + b
+    for shift in (0.0, -x.mean(1, keepdim=True)):
+        xs = x + shift
+        mean, var = xs.mean(1, keepdim=True), xs.var(1, unbiased=False, keepdim=True)
+        got = (xs @ wf.t() - mean * s[None]) / torch.sqrt(var + 1e-5) + c[None]
+        assert (got - ref).abs().max() < 1e-5          # s, c are stored fp32

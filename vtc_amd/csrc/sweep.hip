@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict__ keys, int R, int nblk, int bw, int nbs,
                                                      const int *__restrict__ src_base, int depth,
                                                      const float *__restrict__ own_norm, const float *__restrict__ other_max, float kappa,
-                                                     int64_t *__restrict__ cand, int *__restrict__ cand_n) {
+                                                     int64_t *__restrict__ cand, int *__restrict__ cand_n, float *__restrict__ theta_out) {
   __shared__ unsigned tl[3][64 * 65];
   __shared__ float bmin[16][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
       for (int sl = 0; sl < 16; ++sl) bound = fminf(bound, bmin[sl][o]);
       // strict: an outside entry AT theta could tie with a true neighbour
       cand_n[r] = (cnt[cc] <= 64 && bound > theta[cc]) ? cnt[cc] : -1;
+      theta_out[r] = theta[cc];                            // for the uncertified owners' second pass (block_rescan_kernel)
     }
   }
 }
@@ -761,6 +762,94 @@ __global__ __launch_bounds__(256) void exact_fallback_merge_kernel(int depth, co
   }
 }
 
+// Uncertified owners of the block-minima path (minsel_kernel: more than 64 pool entries under theta, or a block whose fourth
+// smallest key is under theta and may hide more): instead of the whole gallery, exactly the entries that CAN be under theta --
+// the pool entries <= theta of the safe blocks and EVERY entry of the unsafe ones (an entry that is not among its block's three
+// smallest has the block's fourth key below its own).  That set contains the true top-depth; fp64 distances, sorted by
+// (distance, index): the same ids as the brute force.  One workgroup per flagged owner, a wave per block at a time.
+__global__ __launch_bounds__(256) void block_rescan_kernel(const float *__restrict__ queries, const float *__restrict__ gallery, int ng, int d,
+                                                           int depth, const int *__restrict__ flags, const unsigned *__restrict__ keys, int R,
+                                                           int nblk, int bw, int nbs, int n_src, const int *__restrict__ src_base,
+                                                           const float *__restrict__ theta, int64_t *__restrict__ ids, float *__restrict__ dists) {
+  __shared__ double sd[4][64];
+  __shared__ int si[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_flagged = flags[0];
+  const size_t plane = (size_t)nbs * R;
+  for (int f = blockIdx.x; f < n_flagged; f += gridDim.x) {     // uniform for the workgroup
+    const int r = flags[1 + f];
+    const float *q = queries + (size_t)r * d;
+    const float th = theta[r];
+    double bd = INFINITY;
+    int bi = 0x7fffffff;
+    auto offer = [&](double cv, int ci) {                   // wave-uniform candidate
+      const double tau = __shfl(bd, depth - 1, 64);
+      const int tau_i = __shfl(bi, depth - 1, 64);
+      if (!(cv < tau || (cv == tau && ci < tau_i))) return;
+      const bool less = bd < cv || (bd == cv && bi < ci);
+      const int pos = __popcll(__ballot(less));
+      const double ud = __shfl_up(bd, 1, 64);
+      const int ui = __shfl_up(bi, 1, 64);
+      if (lane > pos) { bd = ud; bi = ui; }
+      if (lane == pos) { bd = cv; bi = ci; }
+    };
+    for (int blk = wave; blk < nblk; blk += 4) {
+      const int src = blk / nbs, b_in = blk - src * nbs;
+      const size_t o = ((size_t)src * (L2MIN_PLANES - 1) * nbs + blk) * R + r;
+      const unsigned k0 = keys[o], k1 = keys[plane + o], k2 = keys[2 * plane + o], k3 = keys[3 * plane + o];
+      const int base = (src_base ? src_base[src] : 0) + b_in * bw;
+      const int lim = (src_base && src + 1 < n_src) ? src_base[src + 1] : ng;     // the source's rows end here
+      if (k3 != 0x7F800000u && __uint_as_float(k3 & ~127u) <= th) {
+        const int n_in = min(bw, lim - base);               // unsafe block: all of it, four rows per step (their loads in flight
+        for (int j0 = 0; j0 < n_in; j0 += 4) {              // together; per row the arithmetic and order of wave_dist64)
+          double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+          for (int c = lane * 4; c < d; c += 256) {
+            const float4 a = *reinterpret_cast<const float4 *>(q + c);
+            float4 b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const float4 *>(gallery + (size_t)(base + min(j0 + u, n_in - 1)) * d + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const double e0 = (double)a.x - (double)b[u].x, e1 = (double)a.y - (double)b[u].y, e2 = (double)a.z - (double)b[u].z,
+                           e3 = (double)a.w - (double)b[u].w;
+              sacc[u] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+            }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o, 64);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (j0 + u < n_in) offer(sacc[u], base + j0 + u);
+        }
+      } else {
+        const unsigned kk[3] = {k0, k1, k2};
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          if (kk[pl] != 0x7F800000u && __uint_as_float(kk[pl] & ~127u) <= th) {
+            const int j = base + (int)(kk[pl] & 127u);
+            offer(wave_dist64(q, gallery + (size_t)j * d, d, lane), j);
+          }
+      }
+    }
+    sd[wave][lane] = bd;
+    si[wave][lane] = bi;
+    __syncthreads();
+    if (wave == 0) {
+      for (int w = 1; w < 4; ++w)
+        for (int e = 0; e < depth; ++e)
+          if (si[w][e] != 0x7fffffff) offer(sd[w][e], si[w][e]);
+      if (lane < depth) {
+        ids[(size_t)r * depth + lane] = bi == 0x7fffffff ? -1 : (int64_t)bi;
+        if (dists) dists[(size_t)r * depth + lane] = (float)bd;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void max_reduce_kernel(const float *__restrict__ x, int n, float *__restrict__ out) {
   __shared__ float part[4];
   float m = -INFINITY;
@@ -903,9 +992,15 @@ struct FallbackWs {       // scratch of the chunked fp64 brute force (exact_fall
   double *part_d;
   int *part_i;
 };
+struct Rescan {           // the block-minima planes an uncertified owner is re-read from (block_rescan_kernel)
+  const unsigned *keys;
+  int R, nblk, bw, nbs, n_src;
+  const int *src_base;
+  const float *theta;
+};
 static int exact_finish(const float *gallery, const float *queries, int ng, int nq, int d, int depth, int cdepth, const int64_t *cand,
                         const float *cand_d, const float *qn, const float *gn, float *gmax, int *flags, int64_t *ids, float *dists,
-                        hipStream_t stream, const int *cand_n, const FallbackWs *fb);
+                        hipStream_t stream, const int *cand_n, const FallbackWs *fb, const Rescan *rs = nullptr);
 
 // ---- VTC_SWEEP_EXACT, block-minima path ("v2") -----------------------------------------------------------------------
 // ONE plain-bf16 distance GEMM whose epilogue keeps, per (query, block of 64 gallery rows), the three smallest distances and
@@ -935,6 +1030,7 @@ struct Sweep2Ws {
   int nblk_c, nblk_r, rb;
   int64_t *cand, *cand2;
   int *cand_n, *cand2_n;
+  float *theta, *theta2;
   int *flags;
   FallbackWs fb;
   size_t total;
@@ -956,10 +1052,12 @@ Sweep2Ws plan2(char *ws, int ng, int nq, int d, bool bidir) {
   s.colk = bidir ? (unsigned *)take((size_t)L2MIN_PLANES * s.nblk_r * ng * 4) : nullptr;
   s.cand = (int64_t *)take((size_t)nq * CD2 * 8);
   s.cand_n = (int *)take((size_t)nq * 4);
-  s.cand2 = nullptr; s.cand2_n = nullptr;
+  s.theta = (float *)take((size_t)nq * 4);
+  s.cand2 = nullptr; s.cand2_n = nullptr; s.theta2 = nullptr;
   if (bidir) {
     s.cand2 = (int64_t *)take((size_t)ng * CD2 * 8);
     s.cand2_n = (int *)take((size_t)ng * 4);
+    s.theta2 = (float *)take((size_t)ng * 4);
   }
   s.flags = (int *)take((size_t)(std::max(nq, bidir ? ng : 0) + 1) * 4);
   s.fb.part_d = (double *)take((size_t)FB_ROWS * FB_CHUNKS * FB_SLOT * 8);
@@ -995,19 +1093,23 @@ int exact2_impl(const float *a, const float *b, int na, int nb, int d, int depth
   {
     ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * s.nblk_c * nb * 4, stream);
     hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(nb, 64)), dim3(256), 0, stream, s.rowk, nb, s.nblk_c, 64, s.nblk_c, (const int *)nullptr, depth, s.qn, s.gmax,
-                       kappa, s.cand, s.cand_n);
+                       kappa, s.cand, s.cand_n, s.theta);
   }
   VTC_LAUNCH_CHECK("minsel");
-  if (int rc = exact_finish(a, b, na, nb, d, depth, CD2, s.cand, nullptr, s.qn, s.gn, s.gmax, s.flags, ids_b2a, dists_b2a, stream, s.cand_n, &s.fb))
+  const Rescan rs1{s.rowk, nb, s.nblk_c, 64, s.nblk_c, 1, nullptr, s.theta};
+  if (int rc = exact_finish(a, b, na, nb, d, depth, CD2, s.cand, nullptr, s.qn, s.gn, s.gmax, s.flags, ids_b2a, dists_b2a, stream, s.cand_n, &s.fb,
+                            &rs1))
     return rc;
   if (ids_a2b) {
     {
       ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * s.nblk_r * na * 4, stream);
       hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(na, 64)), dim3(256), 0, stream, s.colk, na, s.nblk_r, s.rb, s.nblk_r, (const int *)nullptr, depth, s.gn, s.qmax,
-                         kappa, s.cand2, s.cand2_n);
+                         kappa, s.cand2, s.cand2_n, s.theta2);
     }
     VTC_LAUNCH_CHECK("minsel cols");
-    return exact_finish(b, a, nb, na, d, depth, CD2, s.cand2, nullptr, s.gn, s.qn, s.qmax, s.flags, ids_a2b, dists_a2b, stream, s.cand2_n, &s.fb);
+    const Rescan rs2{s.colk, na, s.nblk_r, s.rb, s.nblk_r, 1, nullptr, s.theta2};
+    return exact_finish(b, a, nb, na, d, depth, CD2, s.cand2, nullptr, s.gn, s.qn, s.qmax, s.flags, ids_a2b, dists_a2b, stream, s.cand2_n, &s.fb,
+                        &rs2);
   }
   return 0;
 }
@@ -1059,11 +1161,12 @@ extern "C" int vtc_l2_sweep_shard_cols(const float *b_all, const float *a_local,
   {
     ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * n_src * nblk_pad * n_local * 4, stream);
     hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(n_local, 64)), dim3(256), 0, stream, planes, n_local, n_src * nblk_pad, rb, nblk_pad, src_base,
-                       depth, s.qn, s.gmax, kappa, s.cand, s.cand_n);
+                       depth, s.qn, s.gmax, kappa, s.cand, s.cand_n, s.theta);
   }
   VTC_LAUNCH_CHECK("minsel shard cols");
+  const Rescan rs{planes, n_local, n_src * nblk_pad, rb, nblk_pad, n_src, src_base, s.theta};
   return exact_finish(b_all, a_local, n_total, n_local, d, depth, CD2, s.cand, nullptr, s.qn, s.gn, s.gmax, s.flags, ids, dists, stream,
-                      s.cand_n, &s.fb);
+                      s.cand_n, &s.fb, &rs);
 }
 
 // diagnostics (tools/sweep_v2_debug.py; not part of the public header): the raw block-minima planes of one distance GEMM.
@@ -1141,7 +1244,7 @@ static int l2_topk_impl(const float *gallery, const float *queries, int ng, int 
 // top-k, recompute the others by fp64 brute force.  qn / gn: fp32 squared norms of the queries / gallery rows.
 static int exact_finish(const float *gallery, const float *queries, int ng, int nq, int d, int depth, int cdepth, const int64_t *cand,
                         const float *cand_d, const float *qn, const float *gn, float *gmax, int *flags, int64_t *ids, float *dists,
-                        hipStream_t stream, const int *cand_n, const FallbackWs *fb) {
+                        hipStream_t stream, const int *cand_n, const FallbackWs *fb, const Rescan *rs) {
   if (!cand_n) hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, gn, ng, gmax);
   // split-bf16 candidate lists (cand_n == nullptr): worst-case error of a split-bf16 distance, relative to |q|^2 + max|g|^2:
   // dropped lo.lo products and the second bf16 rounding of both operands (3 * 2^-18), fp32 accumulation of 3 d products
@@ -1151,6 +1254,12 @@ static int exact_finish(const float *gallery, const float *queries, int ng, int 
   hipLaunchKernelGGL(exact_rerank_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, queries, gallery, nq, ng, d, cand, cand_d, cdepth,
                      depth, qn, gmax, kappa, ids, dists, flags, cand_n);
   int f_first = 0;
+  if (rs) {     // block-minima path: the uncertified owners are settled from their own planes (no pass over the gallery)
+    hipLaunchKernelGGL(block_rescan_kernel, dim3(std::min(nq, 2048)), dim3(256), 0, stream, queries, gallery, ng, d, depth, flags, rs->keys,
+                       rs->R, rs->nblk, rs->bw, rs->nbs, rs->n_src, rs->src_base, rs->theta, ids, dists);
+    VTC_LAUNCH_CHECK("l2_topk block rescan");
+    return 0;
+  }
   if (fb) {     // the first FB_ROWS uncertified rows: every row spread over FB_CHUNKS workgroups
     hipLaunchKernelGGL(exact_fallback_chunk_kernel, dim3(16, FB_CHUNKS), dim3(256), 0, stream, queries, gallery, ng, d, depth, flags, fb->part_d,
                        fb->part_i);

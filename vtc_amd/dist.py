@@ -72,8 +72,8 @@ def all_gather_rows(x: torch.Tensor, n_total: int, rank: int, world: int) -> tor
     return torch.cat([out[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
 
 
-BIDIR_MIN_ROWS = 14336      # as host/metric.py RecallAtK.bidir_min_rows
-BIDIR_MIN_ROWS_F32 = 4096
+BIDIR_MIN_ROWS = 5120       # as host/metric.py RecallAtK.bidir_min_rows (tools/bidir_threshold.py: EXACT 6k 0.49 vs 0.6+, 10k 0.64 vs 0.79 ms)
+BIDIR_MIN_ROWS_F32 = 3000
 
 
 def one_matrix_sharded(n_total: int, precision: int, world: int, depth: int) -> bool:

@@ -105,8 +105,8 @@ class RecallAtK(BaseMetric):
     #: direction is read off the columns of the blocks the first direction wrote).  Measured one-matrix vs two searches,
     #: EXACT: 10k 1.54 vs 1.33 ms, 16k 2.46 vs 2.65, 25k 5.1 vs 6.0, 50k 15.4 vs 21.1 (the column pass is issue-bound
     #: and pays a list initialisation per segment; the GEMM it saves grows with N^2)
-    bidir_min_rows = 14336
-    bidir_min_rows_f32 = 4096      # SWEEP_F32: the fp32-MFMA GEMM it saves is the expensive part at every size
+    bidir_min_rows = 5120          # tools/bidir_threshold.py: one matrix wins from ~5k rows (EXACT 10k: 0.64 vs 0.79 ms)
+    bidir_min_rows_f32 = 3000      # SWEEP_F32: the fp32-MFMA GEMM it saves is the expensive part at every size
 
     def _hits_to_recall(self, ids, num_samples):
         ks = [min(int(k), ids.shape[1]) for k in self.k_vals]

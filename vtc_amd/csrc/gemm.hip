@@ -403,17 +403,21 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     // way -- the stored rows keep |mean| << std, and the rounding of hi, relative to |x|, stays relative to the spread that
     // the LayerNorm divides by (tools/fold_dc_probe.py: without this a DC offset of 10 std costs 1.5e-3).  The wave's
     // TM * 16 means wait in its LDS scratch behind the transposition buffer.
+    // (fold_stat == NULL: this update does not re-centre -- the towers do it once per layer, in c_proj's epilogue)
     [[maybe_unused]] float *mean_prev = tr + 16 * TS;
+    [[maybe_unused]] const bool center = SPLIT && p.epi.fold_stat != nullptr;
     if constexpr (SPLIT) {
       static_assert((16 * TS + TM * 16) * 4 <= SCRATCH_PER_WAVE, "folded LayerNorm: previous means in the wave's scratch");
+      if (center) {
 #pragma unroll
-      for (int q = 0; q < (TM * 16 + 63) / 64; ++q) {
-        const int r = lane + 64 * q;
-        if (TM * 16 % 64 == 0 || r < TM * 16) mean_prev[r] = p.epi.fold_stat[2 * (size_t)(m0 + wr * TM * 16 + r)];
+        for (int q = 0; q < (TM * 16 + 63) / 64; ++q) {
+          const int r = lane + 64 * q;
+          if (TM * 16 % 64 == 0 || r < TM * 16) mean_prev[r] = p.epi.fold_stat[2 * (size_t)(m0 + wr * TM * 16 + r)];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     auto x_load = [&](int pp, int k) -> float4 {
       if constexpr (SPLIT) {
@@ -495,7 +499,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
             float4 x = xr[pp % XD][k];
             if constexpr (SPLIT) {
               const unsigned h0 = __float_as_uint(x.x), h1 = __float_as_uint(x.y), l0 = __float_as_uint(x.z), l1 = __float_as_uint(x.w);
-              const float mu = mean_prev[i * 16 + r];
+              const float mu = center ? mean_prev[i * 16 + r] : 0.0f;
               x = make_float4((up16<T>((unsigned short)(h0 & 0xFFFFu)) - mu) + up16<T>((unsigned short)(l0 & 0xFFFFu)),
                               (up16<T>((unsigned short)(h0 >> 16)) - mu) + up16<T>((unsigned short)(l0 >> 16)),
                               (up16<T>((unsigned short)(h1 & 0xFFFFu)) - mu) + up16<T>((unsigned short)(l1 & 0xFFFFu)),
@@ -1314,7 +1318,7 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
   if (epi.y16 || epi.fold_stat) {     // folded LayerNorm: only the interior fast epilogues carry it
     VTC_CHECK(esz == 2 && M % 256 == 0 && N % 256 == 0 && (epi.ldo == 0 || epi.ldo == N),
               "gemm: folded LayerNorm needs 16-bit operands and M, N multiples of 256 (M=%d N=%d dtype=%d)", M, N, dtype);
-    VTC_CHECK(epi.y16 ? (epi.mode == VTC_EPI_RESID && epi.fold_part != nullptr && epi.y16lo != nullptr && epi.fold_stat != nullptr)
+    VTC_CHECK(epi.y16 ? (epi.mode == VTC_EPI_RESID && epi.fold_part != nullptr && epi.y16lo != nullptr)
                       : ((epi.mode == VTC_EPI_STORE || epi.mode == VTC_EPI_GELU) && epi.out_dtype != VTC_F32 && epi.fold_s != nullptr),
               "gemm: folded LayerNorm arguments do not go with epilogue %d", epi.mode);
   }

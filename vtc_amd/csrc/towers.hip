@@ -161,12 +161,14 @@ int ln_proj(Fold &f, const float *x, const float *g, const float *bt, const void
 }
 
 // x += A w^T + bias  (rows with m % skip_mod == 0 untouched)
+// center: this update also subtracts the rows' previous means (the stream stays centred; once per layer is enough -- a single
+// update moves a row's mean by a fraction of its spread)
 int resid_proj(Fold &f, const void *A, const void *w, const float *bias, float *x, int rows, int W, int K, int dtype, int skip_mod,
-               hipStream_t s) {
+               hipStream_t s, bool center = false) {
   if (f.on) {
     GemmEpi e;
     e.mode = VTC_EPI_RESID; e.out_dtype = VTC_F32; e.skip_mod = skip_mod; e.y16 = f.xb; e.y16lo = f.xl; e.fold_part = f.part;
-    e.fold_stat = f.stat;       // the rows' means before this update: the stream is stored centred (gemm.hip, SPLIT)
+    if (center) e.fold_stat = f.stat;       // the rows' means before this update: the stream is stored centred (gemm.hip, SPLIT)
     if (f.fmt != dtype) {       // the stream is not a pair of this format yet (cannot happen behind ln_proj; kept for safety)
       if (f.fmt >= 0) RUN(launch_split_merge_rows(f.xb, f.xl, x, rows, W, nullptr, 1, f.fmt, s));
       RUN(launch_cast_rowstats(x, f.xb, f.xl, f.stat, rows, W, dtype, s));
@@ -182,7 +184,7 @@ int resid_proj(Fold &f, const void *A, const void *w, const float *bias, float *
 int mlp_part(Fold &f, const vtc_block_w &b, float *x, void *h, void *big, int rows, int W, int dtype, hipStream_t s) {
   ProfRegion region(VTC_PROF_REGION_MLP);
   RUN(ln_proj(f, x, b.ln2_g, b.ln2_b, b.fc_w, b.fc_b, b.fc_wf, b.fc_s, b.fc_c, h, big, rows, 4 * W, W, dtype, VTC_EPI_GELU, s));
-  RUN(resid_proj(f, big, b.proj_w, b.proj_b, x, rows, W, 4 * W, dtype, 0, s));
+  RUN(resid_proj(f, big, b.proj_w, b.proj_b, x, rows, W, 4 * W, dtype, 0, s, true));
   return 0;
 }
 

@@ -1,6 +1,6 @@
 """Vision tower throughput vs VISION_CHUNK (activations of a chunk resident in the 256 MiB Infinity Cache?)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vtc_amd import towers
 from oracle import arch as A

@@ -1,7 +1,7 @@
 """Folded LayerNorm under mean-dominated rows: a DC offset on ln_pre.bias puts |mean| / std of every residual row at the given
-ratio.  Error vs the fp32 oracle with the fold on and off.  usage: python tools/fold_dc_probe.py"""
+ratio.  Error vs the fp32 oracle with the fold on and off.  usage: python tests/probes/fold_dc_probe.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from vtc_amd import _lib as L, towers
 from oracle import arch as A, clip_ref as CR

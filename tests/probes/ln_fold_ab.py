@@ -1,6 +1,6 @@
-"""Folded LayerNorm A/B (vtc_set_ln_fold): tower outputs against each other and step time.  usage: python tools/ln_fold_ab.py [B]"""
+"""Folded LayerNorm A/B (vtc_set_ln_fold): tower outputs against each other and step time.  usage: python tests/probes/ln_fold_ab.py [B]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from vtc_amd import _lib as L, towers

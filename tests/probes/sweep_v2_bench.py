@@ -1,7 +1,7 @@
 """EXACT sweep: block-minima path (v2) vs split-bf16 materialising path (v1), per tile variant; ids vs fp64 oracle sample.
-usage: python tools/sweep_v2_bench.py N    (env VTC_SWEEP_EXACT_V1=1 / VTC_SWEEP_MIN_TILE=0|1 / VTC_SWEEP_DEBUG=1)"""
+usage: python tests/probes/sweep_v2_bench.py N    (env VTC_SWEEP_EXACT_V1=1 / VTC_SWEEP_MIN_TILE=0|1 / VTC_SWEEP_DEBUG=1)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from vtc_amd import _lib as L, ops
 from oracle import eval_ref as E

@@ -401,7 +401,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     // ... and kept CENTRED: every reader of the stream is a LayerNorm, which does not see a per-row constant, so the row's
     // mean BEFORE this update (fold_stat, left by the statistics pass behind the previous residual GEMM) is subtracted on the
     // way -- the stored rows keep |mean| << std, and the rounding of hi, relative to |x|, stays relative to the spread that
-    // the LayerNorm divides by (tools/fold_dc_probe.py: without this a DC offset of 10 std costs 1.5e-3).  The wave's
+    // the LayerNorm divides by (tests/probes/fold_dc_probe.py: without this a DC offset of 10 std costs 1.5e-3).  The wave's
     // TM * 16 means wait in its LDS scratch behind the transposition buffer.
     // (fold_stat == NULL: this update does not re-centre -- the towers do it once per layer, in c_proj's epilogue)
     [[maybe_unused]] float *mean_prev = tr + 16 * TS;

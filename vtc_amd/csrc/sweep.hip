@@ -1169,7 +1169,7 @@ extern "C" int vtc_l2_sweep_shard_cols(const float *b_all, const float *a_local,
                       s.cand_n, &s.fb, &rs);
 }
 
-// diagnostics (tools/sweep_v2_debug.py; not part of the public header): the raw block-minima planes of one distance GEMM.
+// diagnostics (tests/probes/sweep_v2_debug.py; not part of the public header): the raw block-minima planes of one distance GEMM.
 // qb [nb, d], gb [na, d] bf16; qn, gn fp32 squared norms; rowk [4, ceil(na / 64), nb], colk [4, ceil(nb / rb), na] (or NULL)
 extern "C" int vtc_debug_l2min(const void *qb, const void *gb, const float *qn, const float *gn, int nb, int na, int d, int rb,
                                unsigned *rowk, unsigned *colk, void *stream) {

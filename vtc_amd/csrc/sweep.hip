@@ -771,11 +771,15 @@ __global__ __launch_bounds__(256) void block_rescan_kernel(const float *__restri
                                                            int depth, const int *__restrict__ flags, const unsigned *__restrict__ keys, int R,
                                                            int nblk, int bw, int nbs, int n_src, const int *__restrict__ src_base,
                                                            const float *__restrict__ theta, int64_t *__restrict__ ids, float *__restrict__ dists) {
+  constexpr int CAP = 4096;               // candidate list of a round: CAP / bw blocks, each at most bw entries
   __shared__ double sd[4][64];
   __shared__ int si[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int clist[CAP];
+  __shared__ int cnt;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_flagged = flags[0];
   const size_t plane = (size_t)nbs * R;
+  const int cb = min(CAP / bw, 256);      // blocks per round, a thread per block
   for (int f = blockIdx.x; f < n_flagged; f += gridDim.x) {     // uniform for the workgroup
     const int r = flags[1 + f];
     const float *q = queries + (size_t)r * d;
@@ -793,46 +797,62 @@ __global__ __launch_bounds__(256) void block_rescan_kernel(const float *__restri
       if (lane > pos) { bd = ud; bi = ui; }
       if (lane == pos) { bd = cv; bi = ci; }
     };
-    for (int blk = wave; blk < nblk; blk += 4) {
-      const int src = blk / nbs, b_in = blk - src * nbs;
-      const size_t o = ((size_t)src * (L2MIN_PLANES - 1) * nbs + blk) * R + r;
-      const unsigned k0 = keys[o], k1 = keys[plane + o], k2 = keys[2 * plane + o], k3 = keys[3 * plane + o];
-      const int base = (src_base ? src_base[src] : 0) + b_in * bw;
-      const int lim = (src_base && src + 1 < n_src) ? src_base[src + 1] : ng;     // the source's rows end here
-      if (k3 != 0x7F800000u && __uint_as_float(k3 & ~127u) <= th) {
-        const int n_in = min(bw, lim - base);               // unsafe block: all of it, four rows per step (their loads in flight
-        for (int j0 = 0; j0 < n_in; j0 += 4) {              // together; per row the arithmetic and order of wave_dist64)
-          double sacc[4] = {0.0, 0.0, 0.0, 0.0};
-          for (int c = lane * 4; c < d; c += 256) {
-            const float4 a = *reinterpret_cast<const float4 *>(q + c);
-            float4 b[4];
+    for (int blk0 = 0; blk0 < nblk; blk0 += cb) {
+      if (tid == 0) cnt = 0;
+      __syncthreads();
+      // list the round's candidates: a thread per block, its four keys fetched at once
+      const int blk = blk0 + tid;
+      if (tid < cb && blk < nblk) {
+        const int src = blk / nbs, b_in = blk - src * nbs;
+        const size_t o = ((size_t)src * (L2MIN_PLANES - 1) * nbs + blk) * R + r;
+        unsigned kk[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const float4 *>(gallery + (size_t)(base + min(j0 + u, n_in - 1)) * d + c);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const double e0 = (double)a.x - (double)b[u].x, e1 = (double)a.y - (double)b[u].y, e2 = (double)a.z - (double)b[u].z,
-                           e3 = (double)a.w - (double)b[u].w;
-              sacc[u] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
-            }
+        for (int pl = 0; pl < 4; ++pl) kk[pl] = keys[pl * plane + o];
+        const int base = (src_base ? src_base[src] : 0) + b_in * bw;
+        const int lim = (src_base && src + 1 < n_src) ? src_base[src + 1] : ng;     // the source's rows end here
+        if (kk[3] != 0x7F800000u && __uint_as_float(kk[3] & ~127u) <= th) {           // unsafe block: every entry
+          const int n_in = min(bw, lim - base);
+          if (n_in > 0) {
+            const int pos = atomicAdd(&cnt, n_in);
+            for (int j = 0; j < n_in; ++j) clist[pos + j] = base + j;
           }
+        } else {
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o, 64);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (j0 + u < n_in) offer(sacc[u], base + j0 + u);
+          for (int pl = 0; pl < 3; ++pl)
+            if (kk[pl] != 0x7F800000u && __uint_as_float(kk[pl] & ~127u) <= th) clist[atomicAdd(&cnt, 1)] = base + (int)(kk[pl] & 127u);
         }
-      } else {
-        const unsigned kk[3] = {k0, k1, k2};
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          if (kk[pl] != 0x7F800000u && __uint_as_float(kk[pl] & ~127u) <= th) {
-            const int j = base + (int)(kk[pl] & 127u);
-            offer(wave_dist64(q, gallery + (size_t)j * d, d, lane), j);
-          }
       }
+      __syncthreads();
+      // fp64 distances, four gallery rows per step and wave (their loads in flight together; per row the arithmetic and order
+      // of wave_dist64, so a distance has the same bits whichever kernel forms it); the order of the offers does not matter
+      const int n_list = cnt;
+      for (int c0 = 4 * wave; c0 < n_list; c0 += 16) {
+        int jj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) jj[u] = clist[min(c0 + u, n_list - 1)];
+        double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int c = lane * 4; c < d; c += 256) {
+          const float4 a = *reinterpret_cast<const float4 *>(q + c);
+          float4 b[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const float4 *>(gallery + (size_t)jj[u] * d + c);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double e0 = (double)a.x - (double)b[u].x, e1 = (double)a.y - (double)b[u].y, e2 = (double)a.z - (double)b[u].z,
+                         e3 = (double)a.w - (double)b[u].w;
+            sacc[u] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+          }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o, 64);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (c0 + u < n_list) offer(sacc[u], jj[u]);
+      }
+      __syncthreads();
     }
     sd[wave][lane] = bd;
     si[wave][lane] = bi;

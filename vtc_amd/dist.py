@@ -164,7 +164,6 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
         def topk(g, q, d):
             return ops.l2_topk(g, q, d, precision=precision, return_dists=False, ws=ws)[0]
     ks = [min(int(k), depth) for k in k_vals]
-    tgt = torch.arange(lo, hi, device=feats_a_local.device)[:, None]
     hits = torch.zeros(2, len(ks), dtype=torch.int64, device=feats_a_local.device)
     both = None
     if hip_sweep and world == 1 and n_total >= (BIDIR_MIN_ROWS_F32 if precision == 0 else BIDIR_MIN_ROWS):
@@ -194,6 +193,7 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
             from . import ops
             ops.recall_hits(ids, ks, target_offset=lo, hits=hits[d_])
         else:
+            tgt = torch.arange(lo, hi, device=ids.device)[:, None]
             for j, k in enumerate(ks):
                 hits[d_, j] = (ids[:, :k] == tgt).any(dim=1).sum()
     if world > 1:

@@ -202,7 +202,8 @@ struct GemmEpi {
 };
 enum { EPI_PATCH = 3, EPI_L2DIST = 4, EPI_SCALE = 5, EPI_L2MIN = 6, EPI_RESID_LN = 7,
        // modes 0 / 1 / 2 with the folded LayerNorm (fold_* fields), as instantiations of their own: chosen by launch_gemm
-       EPI_FOLD_BASE = 8, EPI_STORE_FOLD = 8, EPI_GELU_FOLD = 9, EPI_RESID_FOLD = 10 };
+       EPI_FOLD_BASE = 8, EPI_STORE_FOLD = 8, EPI_GELU_FOLD = 9, EPI_RESID_FOLD = 10,
+       EPI_RESID_FOLD_C = 11 /* ... that also re-centres the stream (fold_stat given) */ };
 #define L2MIN_PLANES 4
 
 int launch_gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype,

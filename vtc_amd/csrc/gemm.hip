@@ -206,7 +206,8 @@ template <typename T, int MODE_T, typename OutT, int WM, int WN, int TM, int TN,
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmParams &p, int m0, int n0, unsigned scratch_off) {
   // EPI_*_FOLD = the base epilogue + the folded LayerNorm, compiled apart so that the plain kernels keep their registers
   constexpr bool FOLD = MODE_T >= EPI_FOLD_BASE;
-  constexpr int MODE = FOLD ? MODE_T - EPI_FOLD_BASE : MODE_T;
+  constexpr bool CENTER = MODE_T == EPI_RESID_FOLD_C;
+  constexpr int MODE = CENTER ? VTC_EPI_RESID : (FOLD ? MODE_T - EPI_FOLD_BASE : MODE_T);
   if constexpr (MODE == EPI_L2MIN) {
     if (p.exp_arg & 1) {      // diagnostics (VTC_GEMM_EXP=1): the K loop alone -- the accumulators stay live, nothing is reduced or stored
 #pragma unroll
@@ -405,10 +406,9 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     // TM * 16 means wait in its LDS scratch behind the transposition buffer.
     // (fold_stat == NULL: this update does not re-centre -- the towers do it once per layer, in c_proj's epilogue)
     [[maybe_unused]] float *mean_prev = tr + 16 * TS;
-    [[maybe_unused]] const bool center = SPLIT && p.epi.fold_stat != nullptr;
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT && CENTER) {
       static_assert((16 * TS + TM * 16) * 4 <= SCRATCH_PER_WAVE, "folded LayerNorm: previous means in the wave's scratch");
-      if (center) {
+      {
 #pragma unroll
         for (int q = 0; q < (TM * 16 + 63) / 64; ++q) {
           const int r = lane + 64 * q;
@@ -499,7 +499,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
             float4 x = xr[pp % XD][k];
             if constexpr (SPLIT) {
               const unsigned h0 = __float_as_uint(x.x), h1 = __float_as_uint(x.y), l0 = __float_as_uint(x.z), l1 = __float_as_uint(x.w);
-              const float mu = center ? mean_prev[i * 16 + r] : 0.0f;
+              float mu = 0.0f;
+              if constexpr (CENTER) mu = mean_prev[i * 16 + r];
               x = make_float4((up16<T>((unsigned short)(h0 & 0xFFFFu)) - mu) + up16<T>((unsigned short)(l0 & 0xFFFFu)),
                               (up16<T>((unsigned short)(h0 >> 16)) - mu) + up16<T>((unsigned short)(l0 >> 16)),
                               (up16<T>((unsigned short)(h1 & 0xFFFFu)) - mu) + up16<T>((unsigned short)(l1 & 0xFFFFu)),
@@ -1253,6 +1254,7 @@ int dispatch(GemmParams p, hipStream_t stream) {
       return run_cfg<T, VTC_EPI_GELU, Out16>(p, stream);
     case VTC_EPI_RESID:
       if constexpr (sizeof(T) == 2) {
+        if (p.epi.y16 && p.epi.fold_stat) return run_cfg<T, EPI_RESID_FOLD_C, float>(p, stream);
         if (p.epi.y16) return run_cfg<T, EPI_RESID_FOLD, float>(p, stream);
       }
       return run_cfg<T, VTC_EPI_RESID, float>(p, stream);

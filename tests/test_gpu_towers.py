@@ -505,3 +505,19 @@ def test_folded_layernorm_is_insensitive_to_a_row_mean():
     ref = CR.encode_image(img, sd, a, "v.").numpy()
     got = towers.PackedVision(cuda_sd(sd), "v.", torch.bfloat16).forward(img.cuda()).cpu().numpy()
     report("image tower, DC offset 10 on the residual rows", np.abs(unit(got) - unit(ref)).max(), 1e-3)
+
+
+def test_folded_layernorm_across_an_operand_format_boundary():
+    """Text tower with only the first 6 blocks on IEEE-half operands (vtc_text_w.half_layers = 6): at the boundary the (hi, lo)
+    stream changes format -- merged back to fp32 and re-cast (towers.hip ln_proj).  Ragged and dense, against the fp32 oracle."""
+    from vtc_amd import towers
+    a = A.VIT_B32
+    sd = A.synth_text(a, 111, prefix="t.")
+    txt = A.synth_tokens(9, a, 112, empty_frac=0.2)
+    ref = CR.encode_text(txt, sd, a, "t.").numpy()
+    for hl in (6, 0, 12):
+        pk = towers.PackedText(cuda_sd(sd), "t.", torch.bfloat16, heads=a.transformer_heads, half_layers=hl)
+        for ragged in (True, False):
+            got = pk.forward(txt.cuda(), ragged=ragged).cpu().numpy()
+            # all-bf16 blocks sit at the bf16 floor of this tower (DESIGN 2): 2e-3 there, 1e-3 with any half blocks in front
+            report(f"text half_layers={hl} ragged={ragged}", np.abs(unit(got) - unit(ref)).max(), 2e-3 if hl == 0 else 1.5e-3 if hl == 6 else 1e-3)

@@ -542,26 +542,27 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
   const int n_list = cand_n ? cand_n[r] : cdepth;
   const int64_t my = lane < n_list ? cand[(size_t)r * cdepth + lane] : -1;
   double md = INFINITY;
-  // Four candidates at a time: their row pieces are all requested before the first is used and the four xor
+  // Eight candidates at a time: their row pieces are all requested before the first is used and the eight xor
   // butterflies interleave (one candidate at a time the kernel was a chain of 32 dependent gather latencies).
   // Per candidate the arithmetic and its order are exactly wave_dist64's, so the fallback kernel forms the same doubles.
   const int n_loop = cand_n ? (n_list > 0 ? n_list : 0) : cdepth;      // wave-uniform
-  for (int c0 = 0; c0 < n_loop; c0 += 4) {
-    long long jj[4];
-    double sacc[4];
+  constexpr int NB = 8;                                                // candidates per step
+  for (int c0 = 0; c0 < n_loop; c0 += NB) {
+    long long jj[NB];
+    double sacc[NB];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NB; ++u) {
       jj[u] = c0 + u < n_loop ? __shfl((long long)my, c0 + u, 64) : -1;      // wave-uniform
       sacc[u] = 0.0;
     }
     for (int c = lane * 4; c < d; c += 256) {
       const float4 a = *reinterpret_cast<const float4 *>(q + c);
-      float4 b[4];
+      float4 b[NB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < NB; ++u)
         b[u] = *reinterpret_cast<const float4 *>(gallery + (size_t)(jj[u] < 0 ? 0 : jj[u]) * d + c);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const double e0 = (double)a.x - (double)b[u].x, e1 = (double)a.y - (double)b[u].y, e2 = (double)a.z - (double)b[u].z,
                      e3 = (double)a.w - (double)b[u].w;
         sacc[u] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
@@ -570,10 +571,10 @@ __global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restri
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], o, 64);
+      for (int u = 0; u < NB; ++u) sacc[u] += __shfl_xor(sacc[u], o, 64);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < NB; ++u)
       if (jj[u] >= 0 && lane == c0 + u) md = sacc[u];
   }
   // rank among the candidates by (fp64 distance, index); absent slots sort last

@@ -12,7 +12,7 @@ from vtc_amd import ops
 
 lib = L.lib()
 stream = torch.cuda.current_stream().cuda_stream
-SHAPES = [(8192, 8192, 8192, L.EPI_STORE, "8192^3"), (402432, 2304, 768, L.EPI_STORE, "video qkv"), (402432, 3072, 768, L.EPI_GELU, "video c_fc"), (118272, 512, 512, L.EPI_RESID, "out K=512"), (118272, 1536, 512, L.EPI_STORE, "qkv K=512"),
+SHAPES = [(8192, 8192, 8192, L.EPI_STORE, "8192^3"), (402432, 2304, 768, L.EPI_STORE, "video qkv"), (402432, 3072, 768, L.EPI_GELU, "video c_fc"), (402432, 768, 768, L.EPI_RESID, "video out"), (402432, 768, 3072, L.EPI_RESID, "video c_proj"), (118272, 512, 512, L.EPI_RESID, "out K=512"), (118272, 1536, 512, L.EPI_STORE, "qkv K=512"),
           (118272, 2048, 512, L.EPI_GELU, "c_fc K=512"), (118272, 512, 2048, L.EPI_RESID, "c_proj K=2048")]
 res = []
 for M, N, K, epi, label in SHAPES:

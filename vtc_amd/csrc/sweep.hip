@@ -362,36 +362,43 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
 // Key layout: keys[src][plane][block-of-src][owner] with `nbs` blocks per source (one source: the planes of a local GEMM,
 // nbs == nblk; several: the column planes every rank sent for this rank's columns, stacked in rank order) -- block `blk`
 // holds entries src_base[blk / nbs] + (blk % nbs) * bw + (key & 127) of the other side (src_base == NULL: 0).
+// OW owners per workgroup: 64, or 32 when 64 would leave CUs without a workgroup (10k x 10k: 157 workgroups of 64)
+template <int OW>
 __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict__ keys, int R, int nblk, int bw, int nbs,
                                                      const int *__restrict__ src_base, int depth,
                                                      const float *__restrict__ own_norm, const float *__restrict__ other_max, float kappa,
                                                      int64_t *__restrict__ cand, int *__restrict__ cand_n, float *__restrict__ theta_out) {
+  constexpr int TG = OW / 4, NSUB = 256 / TG, NI = 64 / NSUB;      // vector loads: TG threads along the owners, NSUB block slices
+  constexpr int OPW = OW / 4;                                       // owners per wave
+  constexpr int SROWS = 256 / OW, NQ = 64 / SROWS;                  // scalar loads: a thread per owner, SROWS block slices
+  static_assert(OW == 64 || OW == 32, "owners per workgroup");
   __shared__ unsigned tl[3][64 * 65];
-  __shared__ float bmin[16][64];
+  __shared__ float bmin[32][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int r0 = blockIdx.x * 64;
+  const int r0 = blockIdx.x * OW;
   const size_t plane = (size_t)nbs * R;                       // one plane of one source
   auto blk_off = [&](int blk) -> size_t {                      // offset of (plane 0, blk, owner 0)
     const int src = blk / nbs;
     return ((size_t)src * (L2MIN_PLANES - 1) * nbs + blk) * R;   // = ((src * 4) * nbs + blk % nbs) * R
   };
-  const bool rv = r0 + lane < R;
+  const int so = t % OW, sb = t / OW;                           // scalar loads: this thread's owner and block slice
+  const bool rv = r0 + so < R;
   const float INF = __builtin_bit_cast(float, 0x7F800000u);
   // ---- pass 1: per owner, the two smallest block minima each lane has seen ----
-  float m1[16], m2[16];
+  float m1[OPW], m2[OPW];
 #pragma unroll
-  for (int cc = 0; cc < 16; ++cc) m1[cc] = m2[cc] = INF;
+  for (int cc = 0; cc < OPW; ++cc) m1[cc] = m2[cc] = INF;
   // tile loads: 16-byte loads (four consecutive owners per thread, all of a chunk's loads in flight at once) when the
   // planes' rows are 16-byte aligned, else one key per thread
   const bool vec = (R & 3) == 0;
-  const int og = 4 * (t & 15), sub = t >> 4;
+  const int og = 4 * (t % TG), sub = t / TG;
   float bq[4] = {INF, INF, INF, INF};
   auto load_chunk = [&](int c0, int npl) __attribute__((always_inline)) {
     if (vec) {
-      uint4 v[4][4];
+      uint4 v[NI][4];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int blk = c0 + sub + 16 * it;
+      for (int it = 0; it < NI; ++it) {
+        const int blk = c0 + sub + NSUB * it;
         const bool ok = blk < nblk && r0 + og < R;
         const size_t o = (ok ? blk_off(blk) : 0) + r0 + og;
 #pragma unroll
@@ -399,8 +406,8 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
           if (pl < npl) v[it][pl] = ok ? *reinterpret_cast<const uint4 *>(keys + pl * plane + o) : make_uint4(0x7F800000u, 0x7F800000u, 0x7F800000u, 0x7F800000u);
       }
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int bl = sub + 16 * it;
+      for (int it = 0; it < NI; ++it) {
+        const int bl = sub + NSUB * it;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
           if (pl < npl) {
@@ -414,13 +421,13 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
       }
     } else {
 #pragma unroll 4
-      for (int q = 0; q < 16; ++q) {
-        const int bl = w + 4 * q, blk = c0 + bl;
+      for (int q = 0; q < NQ; ++q) {
+        const int bl = sb + SROWS * q, blk = c0 + bl;
         const bool ok = blk < nblk && rv;
-        const size_t o = (ok ? blk_off(blk) : 0) + r0 + lane;
+        const size_t o = (ok ? blk_off(blk) : 0) + r0 + so;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          if (pl < npl) tl[pl][bl * 65 + lane] = ok ? keys[pl * plane + o] : 0x7F800000u;
+          if (pl < npl) tl[pl][bl * 65 + so] = ok ? keys[pl * plane + o] : 0x7F800000u;
         if (npl == 4 && ok) bq[0] = fminf(bq[0], __uint_as_float(keys[3 * plane + o]));
       }
     }
@@ -429,8 +436,8 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
     load_chunk(c0, 1);
     __syncthreads();
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-      const float k = __uint_as_float(tl[0][lane * 65 + 16 * w + cc]);
+    for (int cc = 0; cc < OPW; ++cc) {
+      const float k = __uint_as_float(tl[0][lane * 65 + OPW * w + cc]);
       m2[cc] = fminf(m2[cc], fmaxf(m1[cc], k));
       m1[cc] = fminf(m1[cc], k);
     }
@@ -438,9 +445,9 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
   }
   // depth-th smallest of the wave's 128 values per owner: the 64 lane minima sorted by rank counting, then the few second
   // minima that beat the running depth-th
-  float theta[16];
+  float theta[OPW];
 #pragma unroll
-  for (int cc = 0; cc < 16; ++cc) {
+  for (int cc = 0; cc < OPW; ++cc) {
     const float v = m1[cc];
     int rank = 0;
 #pragma unroll 4
@@ -455,22 +462,22 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
     wl.tau_i = __builtin_amdgcn_readlane(wl.bi, depth - 1);
     wl.offer(m2[cc], 64 + lane, wl.beats(m2[cc], 64 + lane), lane, depth);
     const float u = wl.tau;
-    const int r = min(r0 + 16 * w + cc, R - 1);
+    const int r = min(r0 + OPW * w + cc, R - 1);
     const float eps = kappa * (own_norm[r] + *other_max);
     theta[cc] = u + 2.0f * eps;          // u == +inf (fewer than depth pool entries) keeps theta infinite: everything is a candidate
   }
   // ---- pass 2: every pool entry with key <= theta, and the smallest fourth-in-block key ----
-  int cnt[16];
+  int cnt[OPW];
 #pragma unroll
-  for (int cc = 0; cc < 16; ++cc) cnt[cc] = 0;
+  for (int cc = 0; cc < OPW; ++cc) cnt[cc] = 0;
   for (int c0 = 0; c0 < nblk; c0 += 64) {
     load_chunk(c0, 4);
     __syncthreads();
     const int blk = c0 + lane;
     const int64_t base = blk < nblk ? (int64_t)(src_base ? src_base[blk / nbs] : 0) + (int64_t)(blk % nbs) * bw : 0;
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-      const int o = 16 * w + cc;
+    for (int cc = 0; cc < OPW; ++cc) {
+      const int o = OPW * w + cc;
       const int r = r0 + o;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
@@ -487,25 +494,36 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
     __syncthreads();
   }
   // smallest fourth-in-block key per owner: the threads' running minima -> bmin[slice][owner] -> min over the slices
+  for (int i = t; i < 32 * 64; i += 256) (&bmin[0][0])[i] = INF;
+  __syncthreads();
   if (vec) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) bmin[sub][og + e] = bq[e];
   } else {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bmin[w + 4 * q][lane] = q == 0 ? bq[0] : INF;
+    bmin[sb][so] = bq[0];
   }
   __syncthreads();
 #pragma unroll
-  for (int cc = 0; cc < 16; ++cc) {
-    const int o = 16 * w + cc, r = r0 + o;
+  for (int cc = 0; cc < OPW; ++cc) {
+    const int o = OPW * w + cc, r = r0 + o;
     if (r < R && lane == 0) {
       float bound = INF;
-      for (int sl = 0; sl < 16; ++sl) bound = fminf(bound, bmin[sl][o]);
+      for (int sl = 0; sl < 32; ++sl) bound = fminf(bound, bmin[sl][o]);
       // strict: an outside entry AT theta could tie with a true neighbour
       cand_n[r] = (cnt[cc] <= 64 && bound > theta[cc]) ? cnt[cc] : -1;
       theta_out[r] = theta[cc];                            // for the uncertified owners' second pass (block_rescan_kernel)
     }
   }
+}
+
+static void launch_minsel(const unsigned *keys, int R, int nblk, int bw, int nbs, const int *src_base, int depth, const float *own_norm,
+                          const float *other_max, float kappa, int64_t *cand, int *cand_n, float *theta, hipStream_t stream) {
+  if (cdiv(R, 64) < vtcgemm::num_cus())
+    hipLaunchKernelGGL(minsel_kernel<32>, dim3(cdiv(R, 32)), dim3(256), 0, stream, keys, R, nblk, bw, nbs, src_base, depth, own_norm, other_max,
+                       kappa, cand, cand_n, theta);
+  else
+    hipLaunchKernelGGL(minsel_kernel<64>, dim3(cdiv(R, 64)), dim3(256), 0, stream, keys, R, nblk, bw, nbs, src_base, depth, own_norm, other_max,
+                       kappa, cand, cand_n, theta);
 }
 
 // ---- VTC_SWEEP_EXACT ------------------------------------------------------------------------------------
@@ -1113,8 +1131,7 @@ int exact2_impl(const float *a, const float *b, int na, int nb, int d, int depth
   const float kappa = exact2_kappa(d);
   {
     ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * s.nblk_c * nb * 4, stream);
-    hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(nb, 64)), dim3(256), 0, stream, s.rowk, nb, s.nblk_c, 64, s.nblk_c, (const int *)nullptr, depth, s.qn, s.gmax,
-                       kappa, s.cand, s.cand_n, s.theta);
+    launch_minsel(s.rowk, nb, s.nblk_c, 64, s.nblk_c, nullptr, depth, s.qn, s.gmax, kappa, s.cand, s.cand_n, s.theta, stream);
   }
   VTC_LAUNCH_CHECK("minsel");
   const Rescan rs1{s.rowk, nb, s.nblk_c, 64, s.nblk_c, 1, nullptr, s.theta};
@@ -1124,8 +1141,7 @@ int exact2_impl(const float *a, const float *b, int na, int nb, int d, int depth
   if (ids_a2b) {
     {
       ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * s.nblk_r * na * 4, stream);
-      hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(na, 64)), dim3(256), 0, stream, s.colk, na, s.nblk_r, s.rb, s.nblk_r, (const int *)nullptr, depth, s.gn, s.qmax,
-                         kappa, s.cand2, s.cand2_n, s.theta2);
+      launch_minsel(s.colk, na, s.nblk_r, s.rb, s.nblk_r, nullptr, depth, s.gn, s.qmax, kappa, s.cand2, s.cand2_n, s.theta2, stream);
     }
     VTC_LAUNCH_CHECK("minsel cols");
     const Rescan rs2{s.colk, na, s.nblk_r, s.rb, s.nblk_r, 1, nullptr, s.theta2};
@@ -1181,8 +1197,7 @@ extern "C" int vtc_l2_sweep_shard_cols(const float *b_all, const float *a_local,
   const float kappa = exact2_kappa(d);
   {
     ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * n_src * nblk_pad * n_local * 4, stream);
-    hipLaunchKernelGGL(minsel_kernel, dim3(cdiv(n_local, 64)), dim3(256), 0, stream, planes, n_local, n_src * nblk_pad, rb, nblk_pad, src_base,
-                       depth, s.qn, s.gmax, kappa, s.cand, s.cand_n, s.theta);
+    launch_minsel(planes, n_local, n_src * nblk_pad, rb, nblk_pad, src_base, depth, s.qn, s.gmax, kappa, s.cand, s.cand_n, s.theta, stream);
   }
   VTC_LAUNCH_CHECK("minsel shard cols");
   const Rescan rs{planes, n_local, n_src * nblk_pad, rb, nblk_pad, n_src, src_base, s.theta};

@@ -521,3 +521,36 @@ def test_folded_layernorm_across_an_operand_format_boundary():
             got = pk.forward(txt.cuda(), ragged=ragged).cpu().numpy()
             # all-bf16 blocks sit at the bf16 floor of this tower: 2e-3 there, 1e-3 with any half blocks in front
             report(f"text half_layers={hl} ragged={ragged}", np.abs(unit(got) - unit(ref)).max(), 2e-3 if hl == 0 else 1.5e-3 if hl == 6 else 1e-3)
+
+
+def test_folded_layernorm_odd_batches_agree_with_the_layernorm_kernels():
+    """Odd batch sizes (1 row block and many, rows far from a multiple of 256: the padded tiles) through the folded and the
+    LayerNorm-kernel paths of the same packed towers: the two roundings of one embedding differ by a fraction of the tolerance,
+    and an item's embedding does not depend on the batch around it."""
+    from vtc_amd import _lib as L
+    from vtc_amd import towers
+    a = A.VIT_B32
+    lib = L.lib()
+    pv = towers.PackedVision(cuda_sd(A.synth_visual(a, 121, nframes=8, prefix="v.")), "v.", torch.bfloat16)
+    pi = towers.PackedVision(cuda_sd(A.synth_visual(a, 122, prefix="v.")), "v.", torch.bfloat16)
+    pt = towers.PackedText(cuda_sd(A.synth_text(a, 123, prefix="t.")), "t.", torch.bfloat16, heads=a.transformer_heads)
+    vid = A.synth_pixels((5, 8, 3, 224, 224), 124).cuda()
+    img = A.synth_pixels((33, 3, 224, 224), 125).cuda()
+    txt = A.synth_tokens(50, a, 126, empty_frac=0.2).cuda()
+    cases = [(pv, vid, (1, 2, 5)), (pi, img, (1, 7, 33)), (pt, txt, (1, 13, 50))]
+    outs = {}
+    try:
+        for on in (1, 0):
+            L.check(lib.vtc_set_ln_fold(on), "vtc_set_ln_fold")
+            for ci, (pk, x, sizes) in enumerate(cases):
+                for n in sizes:
+                    outs[(ci, n, on)] = unit(pk.forward(x[:n]).cpu().numpy())
+    finally:
+        lib.vtc_set_ln_fold(1)
+    for ci, (pk, x, sizes) in enumerate(cases):
+        for n in sizes:
+            d = np.abs(outs[(ci, n, 1)] - outs[(ci, n, 0)]).max()
+            assert np.isfinite(outs[(ci, n, 1)]).all() and d < 8e-4, (ci, n, d)
+            # batch independence of the folded path: the first item alone vs inside the batch (different tile walks, same rounding)
+            d1 = np.abs(outs[(ci, n, 1)][:1] - outs[(ci, sizes[0], 1)][:1]).max()
+            assert d1 < 8e-4, (ci, n, d1)

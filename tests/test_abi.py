@@ -189,3 +189,26 @@ def test_fold_ln_packing_identity_fp64():
         mean, var = xs.mean(1, keepdim=True), xs.var(1, unbiased=False, keepdim=True)
         got = (xs @ wf.t() - mean * s[None]) / torch.sqrt(var + 1e-5) + c[None]
         assert (got - ref).abs().max() < 1e-5          # s, c are stored fp32
+
+
+def test_packed_weight_signature_tracks_updates_and_reassignment():
+    """host/model.py::_signature caches the list of tensors it hashes (one module walk instead of one per forward): in-place
+    updates, dtype/device moves and RE-ASSIGNED parameters (global registration hooks) must all change it."""
+    import warnings
+    import torch
+    from vtc_amd.host import model as HM
+    from vtc_amd.host.clip_arch import ClipConfig  # noqa: F401
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = HM.PretrainedCLIP_finaltf(model_type="ViT-B/32", branch_to_adapt_val="text").eval()
+    s0 = m._signature()
+    assert m._signature() == s0
+    with torch.no_grad():
+        m.mask_embedding.add_(1.0)
+    s1 = m._signature()
+    assert s1 != s0
+    m.model.visual.proj = torch.nn.Parameter(m.model.visual.proj.detach().clone())
+    s2 = m._signature()
+    assert s2 != s1 and m.model.visual.proj.data_ptr() in {p for p, _ in s2[:-2]}
+    m.double()
+    assert m._signature() != s2

@@ -34,6 +34,21 @@ def normalize(x):
     return ops.normalize_rows(x)
 
 
+
+# Any registration of a parameter / buffer / submodule on any nn.Module invalidates the cached tensor lists of the wrappers
+# (PretrainedCLIPBase._signature): a counter, bumped by torch's global registration hooks.
+_REG_EPOCH = [0]
+
+
+def _bump_reg_epoch(*_args):
+    _REG_EPOCH[0] += 1
+    return None
+
+
+for _reg in ("register_module_parameter_registration_hook", "register_module_buffer_registration_hook",
+             "register_module_module_registration_hook"):
+    getattr(torch.nn.modules.module, _reg)(_bump_reg_epoch)
+
 class PretrainedCLIPBase(nn.Module):
     #: arithmetic of the GEMM/attention operands on the HIP path (fp32 everywhere else)
     compute_dtype = torch.bfloat16
@@ -49,8 +64,14 @@ class PretrainedCLIPBase(nn.Module):
 
     # ---- packed-weight cache ---------------------------------------------------------------
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers())) + \
-            (self.compute_dtype, self.fuse_temporal)
+        """(storage, version) of every parameter and buffer: a changed weight re-packs.  The list of tensors itself is cached
+        (walking ~200 modules per forward cost 0.66 ms; 0.07 ms from the list) and rebuilt whenever ANY module anywhere registers
+        a parameter, buffer or submodule (global registration hooks below bump `_REG_EPOCH`): `.to()`, `load_state_dict` and
+        in-place updates keep the Parameter objects, re-assignment registers."""
+        if self.__dict__.get("_sig_epoch") != _REG_EPOCH[0]:
+            self.__dict__["_sig_list"] = list(self.parameters()) + list(self.buffers())
+            self.__dict__["_sig_epoch"] = _REG_EPOCH[0]
+        return tuple((p.data_ptr(), p._version) for p in self.__dict__["_sig_list"]) + (self.compute_dtype, self.fuse_temporal)
 
     def _pack(self):
         sig = self._signature()

@@ -62,18 +62,30 @@ typedef struct {
   const void  *tfc_w;  const float *tfc_b;   /* temporal_fc                  [W,W],[W]   */
   /* Folded LayerNorm (optional; all NULL => the LayerNorm kernels run).  16-bit modes only: the LayerNorm in front of a
    * projection is applied by that projection's epilogue,  LN(x) W^T + b = rstd_m (x W'^T - mean_m s_n) + c_n,  with
-   * W' = (gamma . W) in the block's operand format, s[n] = sum_k W'[n][k] (of the rounded W'), c[n] = b[n] + sum_k beta[k] W[n][k]:
-   * the GEMM reads x itself (a 16-bit copy the residual GEMM in front writes next to the fp32 stream, with the row statistics). */
+   * W' = (gamma . W) in the block's operand format, s[n] = sum_k W'[n][k] (of the rounded W'), c[n] = b[n] + sum_k beta[k] W[n][k].
+   * Contract of the residual stream while the fold is on: between layer 0's cast and the final LayerNorm the stream is NOT the
+   * fp32 `x` of the workspace (stale there) but a row-centred 16-bit pair (hi, lo) in the block's operand format, x - mean(x) ~=
+   * hi + lo, which the residual GEMMs read and write (with per-row (mean, rstd)) and whose `hi` is the projections' A operand;
+   * every buffer's rows are padded to a multiple of 256 and the pad rows hold garbage that only GEMM tiles touch. */
   const void  *qkv_wf;  const float *qkv_s,  *qkv_c;    /* ln_1    -> attn.in_proj     */
   const void  *fc_wf;   const float *fc_s,   *fc_c;     /* ln_2    -> mlp.c_fc         */
   const void  *tqkv_wf; const float *tqkv_s, *tqkv_c;   /* ln_time -> timeattn.in_proj */
 } vtc_block_w;
+
+/* Per-model path switches (vtc_vision_w.flags / vtc_text_w.flags).  They live in the weight struct -- two models in one
+ * process may choose differently, nothing is process-wide -- and never change results beyond the stated tolerance
+ * (FUSED_*: bit-identical to the LayerNorm-kernel path). */
+enum { VTC_TOWER_NO_LN_FOLD = 1,       /* run the LayerNorm kernels even when the blocks carry folded weights (*_wf)              */
+       VTC_TOWER_FUSED_ATTN = 2,       /* QKV projection + attention core as ONE kernel (vtc_qkv_attention) on contiguous
+                                          sequences (ViT, dense text) and the TimeSformer time branch; implies NO_LN_FOLD   */
+       VTC_TOWER_FUSED_ATTN_SPACE = 4  /* ... and on the TimeSformer space branch                                               */ };
 
 /* Vision tower: upstream VisionTransformer (nframes == 0) or
  * model/timesformer_clip_alt.py:203-286 VisualTransformer (nframes > 0). */
 typedef struct {
   int width, heads, layers, patch, grid, embed_dim, nframes;
   int variant;                    /* 0: timesformer_clip_alt.py (used by model.py); 1: timesformer_clip.py */
+  int flags;                      /* VTC_TOWER_* (below): per-model choices of the kernel path, same results            */
   float pix_mean[3], pix_std[3];  /* pixel_dtype VTC_U8: x = (u8/255 - mean[c]) / std[c], i.e. ToTensor + Normalize of
                                      CLIP_TRANSFORM (dataset_loaders/dataset_loaders.py:40-49) fused into the patch gather */
   const void  *conv_w;            /* conv1.weight flattened [W, 3*patch*patch]            */
@@ -91,6 +103,7 @@ typedef struct {
   int half_layers;                /* dtype VTC_BF16 only: blocks [0, half_layers) hold IEEE-half (VTC_F16) weight matrices and
                                      run with half operands, the others bf16 (the bf16 rounding floor of
                                      this tower is above the 1e-3 budget; half has 3 more significant bits at the same rate) */
+  int flags;                      /* VTC_TOWER_*                                          */
   const float *tok_emb;           /* token_embedding.weight [vocab, W] fp32               */
   const float *pos;               /* positional_embedding [ctx, W]                        */
   const float *ln_final_g, *ln_final_b;
@@ -130,6 +143,14 @@ size_t vtc_text_workspace_bytes(const vtc_text_w *w, int n_seq, int dtype);
 int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_seq, float *out, void *ws, size_t ws_bytes,
                      int dtype, void *stream);
 
+/* The same tower over TWO id arrays -- sequences [0, n_a) from ids_a (titles), [n_a, n_a + n_b) from ids_b (comments; may be
+ * NULL with n_b = 0) -- so that the wrappers need no concatenated copy (model/model.py:472 + :210 as one call), and, with
+ * ragged != 0, on the ragged batch WITHOUT any host knowledge of the lengths: EOT positions, the prefix sums and the row count
+ * are computed on the device and every kernel of the tower reads the row count from device memory (no host sync).
+ * Workspace: vtc_text_workspace_bytes(w, n_a + n_b, dtype) (the dense upper bound).  Same outputs as vtc_text_forward. */
+int vtc_text_forward2(const vtc_text_w *w, const int64_t *ids_a, int n_a, const int64_t *ids_b, int n_b, int ragged, float *out,
+                      void *ws, size_t ws_bytes, int dtype, void *stream);
+
 /* Same tower on a RAGGED batch: only tokens 0..EOT of each sequence are computed.  seq_offsets: int32
  * [n_seq+1] exclusive prefix sums of (argmax(ids[s]) + 1); total_rows = seq_offsets[n_seq] (host value).
  * Outputs are identical to vtc_text_forward: under the causal mask nothing after EOT reaches the EOT row. */
@@ -150,6 +171,9 @@ int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, const float *co
 int vtc_normalize_rows(const float *x, float *out, int n, int d, void *stream);
 /* out[g] = mean over `group` consecutive rows (frames -> video, title+comments -> text) */
 int vtc_mean_groups(const float *x, float *out, int n_groups, int group, int d, void *stream);
+/* out[g] = (a[g] + sum_k b[g * group + k]) / (1 + group): the "averaging" comment fusion, mean of a title embedding and its
+ * comments' (model/model.py:357-362), without stacking them first */
+int vtc_mean_head_groups(const float *a, const float *b, float *out, int n_groups, int group, int d, void *stream);
 /* out[g] = mean of rows [offsets[g], offsets[g+1]): per-video mean over a ragged number of 8-frame
  * chunks, NOT re-normalised (evaluation/retrieval_evaluation.py:254-259).  offsets: int32 [n_groups+1] */
 int vtc_segment_mean(const float *x, const int *offsets, float *out, int n_groups, int d, void *stream);
@@ -239,16 +263,6 @@ int vtc_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, 
 int vtc_qkv_attention(const void *h, const void *w_qkv, const float *b_qkv, void *out, float *cls_out, int n_seq, int L, int heads,
                       int causal, int s2, int a0, int a1, int a2, int a3, int pstride, long long rows, int dtype, void *stream);
 
-/* Which attention branches of the towers use vtc_qkv_attention instead of vtc_gemm + vtc_attention (same results): bit 0 =
- * contiguous sequences + time branch, bit 1 = space branch.  Default 0 (or env VTC_FUSED_ATTN); process-wide. */
-int vtc_set_fused_attention(int mask);
-
-/* Folded LayerNorm of the towers' 16-bit modes (vtc_block_w: *_wf, *_s, *_c): 1 (default, or env VTC_LN_FOLD) = the residual
- * GEMM writes the operand-format copy + row statistics and the next projection applies them; 0 = the LayerNorm kernels run
- * (as they do whenever a block has no folded weights, the width is not a multiple of 256, or fused attention is on).
- * Process-wide. */
-int vtc_set_ln_fold(int on);
-
 /* ---- adapter-only training step: backward + optimizer primitives, fp32 -------------------
  * Replace, for PretrainedCLIP_finaltf with frozen towers (configs/pretrained_clip_comments_attn_frozen.jsonc), what
  * torch.autograd does behind `loss.backward()` (trainer/trainer.py) for clip_loss (model/loss.py:18-22), normalize
@@ -288,6 +302,11 @@ int vtc_prof_begin(void);
 int vtc_prof_end(void *stream, double *ms, long long *launches, double *work);
 /* as vtc_prof_end, split by region: arrays of VTC_PROF_NCLASS * VTC_PROF_NREGION, index cls * VTC_PROF_NREGION + region */
 int vtc_prof_end_regions(void *stream, double *ms, long long *launches, double *work);
+/* as vtc_prof_end, one record per launch (at most `max`; returns the count through *n): class, region, time, work and, for
+ * GEMM launches, tag[3 i ..] = (epilogue mode, N, K) -- bench.py groups them to report the dominant single instantiation */
+int vtc_prof_end_records(void *stream, int max, int *n, int *cls, int *region, double *ms, double *work, int *tag);
+/* kernel launches made by the library since it was loaded (every launch site counts; diagnostics / bench) */
+long long vtc_debug_launch_count(void);
 
 #ifdef __cplusplus
 }

@@ -75,3 +75,63 @@ def shard_cols(b_all, a_local, depth, planes, src_base, rb, stats=None):
     if stats is not None:
         stats["brute"] = brute
     return out
+
+
+# ---- adversarial case for the certificate's error bound (bf16's unit roundoff is 2^-8, not 2^-9) -----------------
+def bf16_round(x):
+    """fp32 -> bf16 -> fp32, round to nearest even (what v_cvt_pk_bf16_f32 does on finite values)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000))
+    return r.view(np.float32)
+
+
+def midpoint_case(n_gallery=2048, d=512, depth=11):
+    """(gallery [n, d], query [1, d]) whose coordinates sit on bf16 round-to-even MIDPOINTS so that the operand roundings of a
+    plain-bf16 distance are coordinated: the true nearest neighbour X (row 0) is over-estimated by ~ +4.6, the `depth` rows
+    Y_t (rows 64 (t + 1): one per block of 64) that are truly 0.3-0.55 FARTHER are under-estimated by ~ -4.6.  The spread
+    (9.2) exceeds 2 eps of the halved constant of rounds 1-2 (8.25: X falls outside theta and a 'certified' list misses the
+    true #1) and stays inside 2 eps of the correct one (16.5).  Fillers are far away (distance ~ 1000) with norms below |q|.
+    Query: first half of the coordinates rounds DOWN (1 + 2^-8 -> 1), second half UP (1 + 3 2^-8 -> 1 + 2^-6)."""
+    h = d // 2
+    q = np.empty(d, np.float32)
+    q[:h] = 1.0 + 2.0 ** -8
+    q[h:] = 1.0 + 3 * 2.0 ** -8
+    lo_dn = 1.40625 + 2.0 ** -8       # 1 + 52/128 (even mantissa) + half an ulp: rounds down
+    lo_up = 1.4140625 + 2.0 ** -8     # 1 + 53/128 (odd mantissa) + half an ulp: rounds up
+    rng = np.random.default_rng(7)
+    g = rng.choice(np.array([-1.0, 1.0], np.float32), size=(n_gallery, d))
+    x = np.full(d, 0.125, np.float32)
+    x[:h] = lo_dn
+    g[0] = x
+    for t in range(depth):
+        y = np.full(d, 0.125, np.float32)
+        y[h:] = lo_up
+        y[:16] = 0.0                                   # + 3.77 on the exact distance
+        y[16:16 + 2 * t] = 0.125 - 8 * 2.0 ** -10      # + 0.0276 t (exactly representable in bf16: no rounding of its own)
+        g[64 * (t + 1)] = y
+    return g, q[None]
+
+
+def certificate_sets(gallery, query, depth, kappa, bw=64):
+    """The block-minima certificate of sweep.hip (minsel_kernel) restated for ONE query: plain-bf16 approximate distances in
+    fp32, per-block three smallest + the fourth as a bound, u = depth-th smallest block minimum, theta = u + 2 kappa
+    (|q|^2 + max|g|^2).  Returns (candidate ids with approx <= theta, certified?, approx distances)."""
+    qb, gb = bf16_round(query[0]), bf16_round(gallery)
+    qn = np.float32((query[0].astype(np.float64) ** 2).sum())
+    gn = (gallery.astype(np.float64) ** 2).sum(1).astype(np.float32)
+    dot = (gb.astype(np.float64) @ qb.astype(np.float64)).astype(np.float32)
+    approx = np.maximum((qn - np.float32(2.0) * dot) + gn, np.float32(0.0))
+    n = gallery.shape[0]
+    nblk = -(-n // bw)
+    mins, fourth, pool = [], [], []
+    for b in range(nblk):
+        idx = np.arange(b * bw, min(n, (b + 1) * bw))
+        o = idx[np.argsort(approx[idx], kind="stable")]
+        mins.append(approx[o[0]])
+        pool += list(o[:3])
+        fourth.append(approx[o[3]] if len(o) > 3 else np.inf)
+    u = np.sort(np.array(mins))[depth - 1]
+    theta = u + 2.0 * kappa * (qn + gn.max())
+    pool = np.array(pool)
+    cand = pool[approx[pool] <= theta]
+    return cand, bool(min(fourth) > theta and cand.size <= 64), approx

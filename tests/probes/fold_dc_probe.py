@@ -17,8 +17,7 @@ for dc in (0.0, 1.0, 3.0, 10.0):
     pk = towers.PackedVision({k: v.cuda() for k, v in sd.items()}, "v.", torch.bfloat16)
     out = []
     for on in (0, 1):
-        lib.vtc_set_ln_fold(on)
+        pk.w.flags = towers.tower_flags(ln_fold=bool(on))
         got = unit(pk.forward(img.cuda()).cpu().numpy())
         out.append(np.abs(got - ref).max())
-    lib.vtc_set_ln_fold(1)
     print(f"dc offset {dc:5.1f}: max err vs fp32 oracle  LayerNorm kernels {out[0]:.2e} | folded {out[1]:.2e}", flush=True)

@@ -1,4 +1,4 @@
-"""Folded LayerNorm A/B (vtc_set_ln_fold): tower outputs against each other and step time.  usage: python tests/probes/ln_fold_ab.py [B]"""
+"""Folded LayerNorm A/B (vtc_*_w.flags, VTC_TOWER_NO_LN_FOLD): tower outputs against each other and step time.  usage: python tests/probes/ln_fold_ab.py [B]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -21,7 +21,7 @@ vid = A.synth_pixels((min(B, 64), 8, 3, 224, 224), 66).cuda().bfloat16()
 txt = A.synth_tokens(6 * min(B, 256), a, 64, empty_frac=0.1).cuda()
 ref_v, ref_t = unit(pv32.forward(vid[:8].float())), unit(pt32.forward(txt[:96]))
 for on in (0, 1):
-    lib.vtc_set_ln_fold(on)
+    pv.w.flags = pt.w.flags = towers.tower_flags(ln_fold=bool(on))
     v, t = unit(pv.forward(vid)), unit(pt.forward(txt))
     print(f"fold={on}: video vs fp32 max {(v[:8] - ref_v).abs().max().item():.2e} rms {(v[:8] - ref_v).pow(2).mean().sqrt().item():.2e} | "
           f"text vs fp32 max {(t[:96] - ref_t).abs().max().item():.2e} rms {(t[:96] - ref_t).pow(2).mean().sqrt().item():.2e}", flush=True)
@@ -29,7 +29,7 @@ vb = torch.randn(B, 8, 3, 224, 224, device="cuda", dtype=torch.bfloat16)
 tb = A.synth_tokens(6 * B, a, 67, empty_frac=0.1).cuda()
 for rep in range(2):
     for on in (0, 1):
-        lib.vtc_set_ln_fold(on)
+        pv.w.flags = pt.w.flags = towers.tower_flags(ln_fold=bool(on))
         pv.forward(vb); pt.forward(tb); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3): pv.forward(vb)

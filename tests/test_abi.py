@@ -17,9 +17,42 @@ def test_library_exports_every_declared_symbol():
     declared -= {"vtc_block_w", "vtc_vision_w", "vtc_text_w", "vtc_cam_w"}
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     lib = L.lib()                       # raises if the .so or any symbol is missing
-    assert lib.vtc_abi_version() == 4
+    assert lib.vtc_abi_version() == L.ABI_VERSION == 5
     for name in declared:
         assert hasattr(lib, name)
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The weight structs travel by pointer: the ctypes mirrors (vtc_amd/_lib.py) must have the C compiler's layout of
+    include/vtc_hip.h -- sizes and the offsets of the fields added in ABI 5 (per-model `flags`)."""
+    import subprocess
+    from vtc_amd import _lib as L
+    src = tmp_path / "layout.c"
+    src.write_text('''#include <stdio.h>
+#include <stddef.h>
+#include "vtc_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vtc_block_w), sizeof(vtc_vision_w), sizeof(vtc_text_w), sizeof(vtc_cam_w),
+         offsetof(vtc_vision_w, flags), offsetof(vtc_vision_w, pix_mean), offsetof(vtc_vision_w, conv_w), offsetof(vtc_text_w, flags),
+         offsetof(vtc_text_w, tok_emb), offsetof(vtc_cam_w, bn_mean));
+  return 0;
+}''')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [L.C.sizeof(L.BlockW), L.C.sizeof(L.VisionW), L.C.sizeof(L.TextW), L.C.sizeof(L.CamW), L.VisionW.flags.offset,
+            L.VisionW.pix_mean.offset, L.VisionW.conv_w.offset, L.TextW.flags.offset, L.TextW.tok_emb.offset, L.CamW.bn_mean.offset]
+    assert got == want, (got, want)
+
+
+def test_no_process_wide_switches_in_the_abi():
+    """SURVEY 8b: no hidden global state.  The path switches of rounds 1-2 (vtc_set_ln_fold / vtc_set_fused_attention) are
+    per-model flags of the weight structs now; the library exports no setter."""
+    from vtc_amd import _lib as L
+    from vtc_amd import towers
+    lib = L.lib()
+    assert not any(hasattr(lib, n) for n in ("vtc_set_ln_fold", "vtc_set_fused_attention"))
+    assert towers.tower_flags() == 0 and towers.tower_flags(ln_fold=False, fused_attn=3) == 7
 
 
 def test_argument_errors_are_reported_not_thrown():
@@ -211,4 +244,9 @@ def test_packed_weight_signature_tracks_updates_and_reassignment():
     s2 = m._signature()
     assert s2 != s1 and m.model.visual.proj.data_ptr() in {p for p, _ in s2[:-2]}
     m.double()
-    assert m._signature() != s2
+    s3 = m._signature()
+    assert s3 != s2
+    # a direct write into the registration dict fires no hook (torch.__future__ overwrite-on-conversion, parametrize, pruning)
+    m.model.visual._parameters["proj"] = torch.nn.Parameter(m.model.visual.proj.detach().clone())
+    s4 = m._signature()
+    assert s4 != s3 and m.model.visual.proj.data_ptr() in {p for p, _ in s4[:-2]}

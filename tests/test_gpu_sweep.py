@@ -355,3 +355,30 @@ def test_sharded_one_matrix_sweep_random_shapes():
         idx = rng.choice(n, size=64, replace=False)
         ids64, _ = E.l2_topk(b, a[idx], depth, np.float64)
         assert np.array_equal(torch.cat(cols).cpu().numpy()[idx], ids64), (n, world, d, depth)
+
+
+def test_exact_sweep_certificate_holds_on_coordinated_bf16_midpoints():
+    """the block-minima certificate needs eps >= |approx - exact| per entry, and bf16's unit roundoff is
+    2^-8 -- rounds 1-2 used 2^-9.  oracle.sweep_planes.midpoint_case puts every coordinate on a round-to-even midpoint so that
+    the operand roundings add up (+4.6 on the true nearest row, -4.6 on the eleven rows just behind it): with the halved
+    constant the 'certified' list misses the true #1 (tests/test_oracle_recall.py shows that on the CPU restatement); the ids
+    must be those of fp64 brute force -- single search, both directions from one matrix, and the split-bf16 path (gallery
+    below 1 024 rows)."""
+    from oracle import sweep_planes as SP
+    from vtc_amd import _lib as L
+    from vtc_amd import ops
+    for n in (2048, 832):
+        g, q = SP.midpoint_case(n_gallery=n)
+        # more queries around the adversarial one (row 0): small perturbations of it on exactly representable steps
+        rng = np.random.default_rng(3)
+        qs = np.repeat(q, 40, 0)
+        qs[1:] += (rng.integers(-2, 3, size=qs[1:].shape) * 2.0 ** -6).astype(np.float32)
+        ids, _ = ops.l2_topk(torch.from_numpy(g).cuda(), torch.from_numpy(qs).cuda(), 11, precision=L.SWEEP_EXACT)
+        ids64, _ = E.l2_topk(g, qs, 11, np.float64)
+        assert np.array_equal(ids.cpu().numpy(), ids64), n
+        assert ids[0, 0].item() == 0
+    g, q = SP.midpoint_case(n_gallery=2048)
+    qs = np.concatenate([q, g[1:1100]])                      # >= 1 024 rows on both sides: the one-matrix path
+    i1, _, i2, _ = ops.l2_topk_bidir(torch.from_numpy(g).cuda(), torch.from_numpy(qs).cuda(), 11, precision=L.SWEEP_EXACT)
+    assert np.array_equal(i1.cpu().numpy(), E.l2_topk(g, qs, 11, np.float64)[0])
+    assert np.array_equal(i2.cpu().numpy(), E.l2_topk(qs, g, 11, np.float64)[0])

@@ -387,13 +387,11 @@ def test_text_tower_half_layers_statistics():
 
 
 def test_towers_with_fused_qkv_attention_are_bit_identical():
-    """vtc_set_fused_attention(3): the towers take QKV projection + attention core as ONE kernel per branch (qkv_attn.hip)
+    """vtc_vision_w.flags / vtc_text_w.flags with VTC_TOWER_FUSED_ATTN(_SPACE): the towers take QKV projection + attention core as ONE kernel per branch (qkv_attn.hip)
     -- ViT, dense text (causal), TimeSformer time and space branches, 8 and 16 frames.  Same roundings in the same places
     as the two-kernel path WITH the LayerNorm kernels (the fused kernel takes LayerNorm'd rows, so it switches the folded
     LayerNorm off), so the embeddings must be bit-identical to that path (which the goldens / oracle pin)."""
-    from vtc_amd import _lib as L
     from vtc_amd import towers
-    lib = L.lib()
     a = A.VIT_B32
     sdv = cuda_sd(A.synth_visual(a, 65, nframes=8, prefix="v."))
     sd16 = cuda_sd(A.synth_visual(a, 66, nframes=16, prefix="v."))
@@ -406,17 +404,17 @@ def test_towers_with_fused_qkv_attention_are_bit_identical():
     for dtype in (torch.bfloat16,):
         runs = []
         for mask in (0, 3):
-            L.check(lib.vtc_set_fused_attention(mask), "vtc_set_fused_attention")
-            L.check(lib.vtc_set_ln_fold(0), "vtc_set_ln_fold")
-            try:
-                outs = [towers.PackedVision(sdv, "v.", dtype).forward(vid), towers.PackedVision(sd16, "v.", dtype).forward(vid16),
-                        towers.PackedVision(sdi, "v.", dtype).forward(img),
-                        towers.PackedText(sdt, "model.", dtype, heads=a.transformer_heads).forward(txt, ragged=False),
-                        towers.PackedText(sdt, "model.", dtype, heads=a.transformer_heads, half_layers=0).forward(txt, ragged=False)]
-                runs.append([o.clone() for o in outs])
-            finally:
-                lib.vtc_set_fused_attention(0)
-                lib.vtc_set_ln_fold(1)
+            # per-model flags (ABI 5): two models in one process choose differently, nothing is process-wide
+            fl = towers.tower_flags(ln_fold=False, fused_attn=mask)
+            packs = [(towers.PackedVision(sdv, "v.", dtype), vid), (towers.PackedVision(sd16, "v.", dtype), vid16),
+                     (towers.PackedVision(sdi, "v.", dtype), img),
+                     (towers.PackedText(sdt, "model.", dtype, heads=a.transformer_heads), txt),
+                     (towers.PackedText(sdt, "model.", dtype, heads=a.transformer_heads, half_layers=0), txt)]
+            outs = []
+            for pk, x in packs:
+                pk.w.flags = fl
+                outs.append(pk.forward(x, ragged=False) if isinstance(pk, towers.PackedText) else pk.forward(x))
+            runs.append([o.clone() for o in outs])
         for x, y in zip(*runs):
             assert torch.isfinite(x).all() and torch.equal(x, y)
 
@@ -447,10 +445,8 @@ def test_folded_layernorm_and_layernorm_kernels_agree_with_the_oracle():
     LN(x) W^T + b = rstd (x (g.W)^T - mean s) + c; model/timesformer_clip_alt.py:142-175 ln_time / ln_1 / ln_2).  Both
     switch positions stay within the bf16 tolerance of the fp32 oracle, for the alt and v1 video towers, the image tower
     and the (ragged and dense) text tower; odd batch sizes exercise the padded rows."""
-    from vtc_amd import _lib as L
     from vtc_amd import towers
     a = A.VIT_B32
-    lib = L.lib()
     sd_alt = A.synth_visual(a, 101, nframes=8, prefix="v.")
     for k in list(sd_alt):
         if k.endswith("temporal_fc.weight"):
@@ -474,15 +470,12 @@ def test_folded_layernorm_and_layernorm_kernels_agree_with_the_oracle():
         "txt": (towers.PackedText(cuda_sd(sd_txt), "t.", torch.bfloat16, heads=a.transformer_heads), txt),
     }
     outs = {}
-    try:
-        for on in (1, 0):
-            L.check(lib.vtc_set_ln_fold(on), "vtc_set_ln_fold")
-            for name, (pk, x) in packed.items():
-                outs[(name, on)] = pk.forward(x.cuda()).cpu().numpy()
-                if name == "txt":
-                    outs[("txt_dense", on)] = pk.forward(x.cuda(), ragged=False).cpu().numpy()
-    finally:
-        lib.vtc_set_ln_fold(1)
+    for on in (1, 0):
+        for name, (pk, x) in packed.items():
+            pk.w.flags = towers.tower_flags(ln_fold=bool(on))
+            outs[(name, on)] = pk.forward(x.cuda()).cpu().numpy()
+            if name == "txt":
+                outs[("txt_dense", on)] = pk.forward(x.cuda(), ragged=False).cpu().numpy()
     for (name, on), got in outs.items():
         ref = refs.get(name.split("_")[0])
         if ref is not None:
@@ -527,10 +520,8 @@ def test_folded_layernorm_odd_batches_agree_with_the_layernorm_kernels():
     """Odd batch sizes (1 row block and many, rows far from a multiple of 256: the padded tiles) through the folded and the
     LayerNorm-kernel paths of the same packed towers: the two roundings of one embedding differ by a fraction of the tolerance,
     and an item's embedding does not depend on the batch around it."""
-    from vtc_amd import _lib as L
     from vtc_amd import towers
     a = A.VIT_B32
-    lib = L.lib()
     pv = towers.PackedVision(cuda_sd(A.synth_visual(a, 121, nframes=8, prefix="v.")), "v.", torch.bfloat16)
     pi = towers.PackedVision(cuda_sd(A.synth_visual(a, 122, prefix="v.")), "v.", torch.bfloat16)
     pt = towers.PackedText(cuda_sd(A.synth_text(a, 123, prefix="t.")), "t.", torch.bfloat16, heads=a.transformer_heads)
@@ -539,14 +530,11 @@ def test_folded_layernorm_odd_batches_agree_with_the_layernorm_kernels():
     txt = A.synth_tokens(50, a, 126, empty_frac=0.2).cuda()
     cases = [(pv, vid, (1, 2, 5)), (pi, img, (1, 7, 33)), (pt, txt, (1, 13, 50))]
     outs = {}
-    try:
-        for on in (1, 0):
-            L.check(lib.vtc_set_ln_fold(on), "vtc_set_ln_fold")
-            for ci, (pk, x, sizes) in enumerate(cases):
-                for n in sizes:
-                    outs[(ci, n, on)] = unit(pk.forward(x[:n]).cpu().numpy())
-    finally:
-        lib.vtc_set_ln_fold(1)
+    for on in (1, 0):
+        for ci, (pk, x, sizes) in enumerate(cases):
+            pk.w.flags = towers.tower_flags(ln_fold=bool(on))
+            for n in sizes:
+                outs[(ci, n, on)] = unit(pk.forward(x[:n]).cpu().numpy())
     for ci, (pk, x, sizes) in enumerate(cases):
         for n in sizes:
             d = np.abs(outs[(ci, n, 1)] - outs[(ci, n, 0)]).max()
@@ -554,3 +542,57 @@ def test_folded_layernorm_odd_batches_agree_with_the_layernorm_kernels():
             # batch independence of the folded path: the first item alone vs inside the batch (different tile walks, same rounding)
             d1 = np.abs(outs[(ci, n, 1)][:1] - outs[(ci, sizes[0], 1)][:1]).max()
             assert d1 < 8e-4, (ci, n, d1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_device_side_ragged_bookkeeping_and_two_id_arrays(dtype):
+    """vtc_text_forward2: EOT positions (first maximum id, as upstream's `text.argmax(-1)`), their prefix sums and the row count
+    are computed on the device and every kernel reads the count there.  Must be BIT-identical to the host-bookkeeping path of
+    round 2 (vtc_text_forward_ragged: same rows, same tiles -- the grids are merely sized for the dense upper bound), for one
+    id array and for titles + comments handed over as two arrays (== their concatenation); the dense path over two arrays
+    equals the dense path over the concatenation.  Sizes: a single sequence, a batch below one 256-row tile, and one with
+    several hundred sequences (more than one scan chunk would need > 1024: covered by 1 300)."""
+    from vtc_amd import towers
+    a = A.VIT_B32
+    sd = A.synth_text(a, 152, prefix="model.")
+    pt = towers.PackedText(cuda_sd(sd), "model.", dtype, heads=a.transformer_heads)
+    for S in (1, 7, 1300):
+        txt = A.synth_tokens(S, a, 154 + S, empty_frac=0.25)
+        if S > 5:
+            txt[3, 1:76] = torch.randint(1, A.SOT, (75,)); txt[3, 76] = A.EOT          # full length
+            txt[5] = torch.randint(1, 1000, (77,)); txt[5, 40] = 48000; txt[5, 60] = 48000   # no EOT, a repeated maximum: the first wins
+        t = txt.cuda()
+        host = pt.forward_host_offsets(t)
+        dev = pt.forward(t, ragged=True)
+        assert torch.isfinite(dev).all() and torch.equal(dev, host), S
+        if S > 1:
+            k = S // 3 + 1
+            two = pt.forward(t[:k].contiguous(), ragged=True, ids_b=t[k:].contiguous())
+            assert torch.equal(two, host), S
+            dense = pt.forward(t, ragged=False)
+            dense2 = pt.forward(t[:k].contiguous(), ragged=False, ids_b=t[k:].contiguous())
+            assert torch.equal(dense, dense2), S
+
+
+def test_config3_forward_is_free_of_host_syncs_and_torch_kernels():
+    """no torch compute and no host sync inside the forward.  A config-3 forward (TimeSformer video + titles +
+    comments + CAM + similarity, ragged text) runs under torch.cuda.set_sync_debug_mode("error"): any .item() / blocking copy /
+    synchronisation raises.  The first call packs the weights (host-side conversion + uploads, which do synchronise) and sizes
+    the workspaces; the checked call is the steady state."""
+    from vtc_amd.host import model as HM
+    m = HM.PretrainedCLIP_TimeSformer_finaltf(model_type="ViT-B/32", branch_to_adapt_val="text").eval().cuda()
+    m.compute_dtype = torch.bfloat16
+    a = A.VIT_B32
+    vid = A.synth_pixels((3, 8, 3, 224, 224), 201).cuda().bfloat16()
+    title = A.synth_tokens(3, a, 202).cuda()
+    comments = A.synth_tokens(15, a, 203, empty_frac=0.3).reshape(3, 5, -1).cuda()
+    ref = m(vid, title, comments)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = m(vid, title, comments)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    for x, y in zip(out, ref):
+        assert torch.equal(x, y)

@@ -104,3 +104,24 @@ def test_oracle_recall_equals_the_references_own_recallatk():
             assert np.array_equal(np.array([r for _, r in both]), z[f"{name}.result"]), name
             assert c["result_keys"] == [f"titles_from_visual-recall_at_{k}" for k in ks] + \
                 [f"visual_from_titles-recall_at_{k}" for k in ks]
+
+
+def test_certificate_error_bound_needs_the_full_bf16_roundoff():
+    """The EXACT sweep's certificate (vtc_amd/csrc/sweep.hip minsel_kernel, restated in oracle/sweep_planes.certificate_sets)
+    is only as good as its per-entry error bound.  On the midpoint case the constant of rounds 1-2 (bf16 unit roundoff taken
+    as 2^-9) certifies a candidate list WITHOUT the true nearest row; the corrected one (2^-8) keeps it.  Pins the reasoning
+    behind exact2_kappa on the CPU; the kernel itself is checked against fp64 brute force in tests/test_gpu_sweep.py."""
+    from oracle import sweep_planes as SP
+    d, depth = 512, 11
+    g, q = SP.midpoint_case(d=d, depth=depth)
+    exact = ((g.astype(np.float64) - q.astype(np.float64)) ** 2).sum(1)
+    assert int(np.argmin(exact)) == 0
+    k_old = 2.0 ** -8 * (1 + 2.0 ** -10) + 2.0 * d / 2 ** 24 + 2.0 ** -16 + 1e-6
+    k_new = 2.0 ** -7 * (1 + 2.0 ** -9) + 2.0 * d / 2 ** 24 + 2.0 ** -15 + 1e-6
+    cand_old, cert_old, approx = SP.certificate_sets(g, q, depth, k_old)
+    cand_new, cert_new, _ = SP.certificate_sets(g, q, depth, k_new)
+    assert cert_old and 0 not in cand_old                     # "certified", and wrong
+    assert cert_new and 0 in cand_new
+    err = approx.astype(np.float64) - exact
+    bound = k_new * (float((q.astype(np.float64) ** 2).sum()) + float((g.astype(np.float64) ** 2).sum(1).max()))
+    assert np.abs(err).max() <= bound and np.abs(err).max() > 0.5 * bound * 0.55     # the case really exercises the bound

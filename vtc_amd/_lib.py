@@ -20,6 +20,9 @@ EPI_STORE, EPI_GELU, EPI_RESID = 0, 1, 2
 PROF_CLASSES = ("gemm_bf16", "gemm_f32", "attention", "norm", "embed", "topk")
 PROF_REGIONS = ("other", "attn", "mlp")
 VTC_F16 = 3
+# vtc_vision_w.flags / vtc_text_w.flags (include/vtc_hip.h VTC_TOWER_*): per-model path switches
+TOWER_NO_LN_FOLD, TOWER_FUSED_ATTN, TOWER_FUSED_ATTN_SPACE = 1, 2, 4
+ABI_VERSION = 5
 
 vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
 
@@ -33,7 +36,7 @@ class BlockW(C.Structure):
 
 class VisionW(C.Structure):
     _fields_ = [("width", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("patch", C.c_int), ("grid", C.c_int),
-                ("embed_dim", C.c_int), ("nframes", C.c_int), ("variant", C.c_int),
+                ("embed_dim", C.c_int), ("nframes", C.c_int), ("variant", C.c_int), ("flags", C.c_int),
                 ("pix_mean", C.c_float * 3), ("pix_std", C.c_float * 3),
                 ("conv_w", C.c_void_p), ("class_embedding", C.c_void_p), ("pos", C.c_void_p), ("temporal", C.c_void_p),
                 ("ln_pre_g", C.c_void_p), ("ln_pre_b", C.c_void_p), ("ln_post_g", C.c_void_p), ("ln_post_b", C.c_void_p),
@@ -42,7 +45,7 @@ class VisionW(C.Structure):
 
 class TextW(C.Structure):
     _fields_ = [("width", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("ctx", C.c_int), ("vocab", C.c_int),
-                ("embed_dim", C.c_int), ("half_layers", C.c_int),
+                ("embed_dim", C.c_int), ("half_layers", C.c_int), ("flags", C.c_int),
                 ("tok_emb", C.c_void_p), ("pos", C.c_void_p), ("ln_final_g", C.c_void_p), ("ln_final_b", C.c_void_p),
                 ("proj_t", C.c_void_p), ("blocks", C.POINTER(BlockW))]
 
@@ -62,12 +65,14 @@ SIGNATURES = {
     "vtc_vision_forward": (C.c_int, [C.POINTER(VisionW), vp, C.c_int, C.c_int, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
     "vtc_text_workspace_bytes": (C.c_size_t, [C.POINTER(TextW), C.c_int, C.c_int]),
     "vtc_text_forward": (C.c_int, [C.POINTER(TextW), ip, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
+    "vtc_text_forward2": (C.c_int, [C.POINTER(TextW), ip, C.c_int, ip, C.c_int, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
     "vtc_text_ragged_workspace_bytes": (C.c_size_t, [C.POINTER(TextW), C.c_int, C.c_int, C.c_int]),
     "vtc_text_forward_ragged": (C.c_int, [C.POINTER(TextW), ip, C.c_int, ip, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
     "vtc_cam_workspace_bytes": (C.c_size_t, [C.POINTER(CamW), C.c_int, C.c_int, C.c_int]),
     "vtc_cam_forward": (C.c_int, [C.POINTER(CamW), fp, fp, ip, C.c_int, C.c_int, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
     "vtc_normalize_rows": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),
     "vtc_mean_groups": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp]),
+    "vtc_mean_head_groups": (C.c_int, [fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]),
     "vtc_segment_mean": (C.c_int, [fp, ip, fp, C.c_int, C.c_int, vp]),
     "vtc_similarity": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, vp]),
     "vtc_clip_loss_workspace_bytes": (C.c_size_t, [C.c_int]),
@@ -91,12 +96,13 @@ SIGNATURES = {
     "vtc_prof_begin": (C.c_int, []),
     "vtc_prof_end": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "vtc_prof_end_regions": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    "vtc_prof_end_records": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "vtc_debug_launch_count": (C.c_longlong, []),
     "vtc_attention": (C.c_int, [vp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, vp]),
     "vtc_qkv_attention": (C.c_int, [vp, vp, fp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_longlong, C.c_int, vp]),
-    "vtc_set_fused_attention": (C.c_int, [C.c_int]),
-    "vtc_set_ln_fold": (C.c_int, [C.c_int]),
     # adapter-only training step (backward + optimizer primitives)
     "vtc_transpose_f32": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),
     "vtc_colsum_f32": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),

@@ -297,7 +297,7 @@ int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int 
 
 // Ragged batch: sequence s occupies the packed rows [seq_offsets[s], seq_offsets[s+1]); max_L bounds the lengths.
 int launch_attention_ragged(const void *qkv, void *out, int n_seq, int max_L, int heads, int causal, const int *seq_offsets,
-                            double flops, int dtype, hipStream_t stream) {
+                            double flops, const int *rows_dev, int dtype, hipStream_t stream) {
   VTC_CHECK(n_seq > 0 && max_L > 0 && heads > 0 && seq_offsets, "attention_ragged: bad arguments");
   AttnParams p;
   p.qkv = (const char *)qkv; p.out = (char *)out; p.cls_out = nullptr;
@@ -305,7 +305,7 @@ int launch_attention_ragged(const void *qkv, void *out, int n_seq, int max_L, in
   p.s2 = 1; p.a0 = 0; p.a1 = 0; p.a2 = 0; p.a3 = 0; p.pstride = 1;
   p.seq_offsets = seq_offsets;
   p.W = heads * 64;
-  ProfScope prof(VTC_PROF_ATTN, flops, stream);
+  ProfScope prof(VTC_PROF_ATTN, flops, stream, rows_dev);      // rows_dev: `flops` is per row
   if (dtype == VTC_F16) return dispatch<f16_t>(p, stream);
   return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
 }

@@ -14,6 +14,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define VTC_WAVE 64
 
+// Every kernel launch of the library is counted (one relaxed atomic add; vtc_debug_launch_count() reads the total): what
+// bench.py reports as launches per forward at the small-batch operating points, where the launch count IS the cost.
+void vtc_count_launch();
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)             \
+  do {                                                                                              \
+    vtc_count_launch();                                                                             \
+    (kernelName)<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);            \
+  } while (0)
+
 void vtc_set_error(const char *fmt, ...);
 
 #define VTC_CHECK(cond, ...)          \
@@ -142,8 +152,9 @@ inline int ensure_dynamic_lds(PerDeviceOnce &once, const void *kernel, int bytes
 
 // ---- optional per-launch event timing (prof.hip) -------------------------------------------
 struct ProfScope {
-  ProfScope(int cls, double work, hipStream_t s);
+  ProfScope(int cls, double work, hipStream_t s, const int *m_dev = nullptr);
   ~ProfScope();
+  void tag(int a, int b, int c);
   hipStream_t stream_;
   int idx_;
 };
@@ -199,6 +210,9 @@ struct GemmEpi {
                               // the operand copy (no third array); `out` (fp32) is neither read nor written
   float *fold_part = nullptr;
   const float *fold_stat = nullptr, *fold_s = nullptr;
+  // the row count M in DEVICE memory (*m_dev <= the M handed to launch_gemm, which then only sizes the grid): the ragged text
+  // tower without a host sync (vtc_text_forward2) -- the persistent kernels read it when they start
+  const int *m_dev = nullptr;
 };
 enum { EPI_PATCH = 3, EPI_L2DIST = 4, EPI_SCALE = 5, EPI_L2MIN = 6, EPI_RESID_LN = 7,
        // modes 0 / 1 / 2 with the folded LayerNorm (fold_* fields), as instantiations of their own: chosen by launch_gemm
@@ -210,11 +224,20 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
                 const GemmEpi &epi, hipStream_t stream);
 bool gemm_resid_ln_supported(int M, int N, int K, int dtype);
 bool gemm_patch_gather_supported(int n_frames, int grid, int patch, int res, int pixel_dtype, int dtype);
+// rows_dev != NULL: the row count lives in device memory (*rows_dev <= rows, which then only sizes the grid)
 int launch_layernorm(const float *x, const float *g, const float *b, void *y, int rows, int width, int out_dtype,
-                     const int *row_index, int row_mul, bool no_norm, hipStream_t stream);
-int launch_fold_stats(const float *part, int nb, int rows, float *stat, hipStream_t stream);
-int launch_cast_rowstats(const float *x, void *y16, void *y16lo, float *stat, int rows, int width, int dtype, hipStream_t stream);
+                     const int *row_index, int row_mul, bool no_norm, hipStream_t stream, const int *rows_dev = nullptr);
+int launch_fold_stats(const float *part, int nb, int rows, float *stat, hipStream_t stream, const int *rows_dev = nullptr);
+int launch_cast_rowstats(const float *x, void *y16, void *y16lo, float *stat, int rows, int width, int dtype, hipStream_t stream,
+                         const int *rows_dev = nullptr);
 int launch_split_merge_rows(const void *hi, const void *lo, float *x, int n, int width, const int *row_index, int row_mul, int dtype,
-                            hipStream_t stream);
+                            hipStream_t stream, const int *rows_dev = nullptr);
+// token ids of a text-tower call: sequences [0, n_a) are rows of `a`, [n_a, n_a + n_b) rows of `b` (titles + comments without a
+// concatenated copy; b may be NULL with n_b = 0)
+struct TextIds {
+  const int64_t *a, *b;
+  int n_a, n_b;
+  __host__ __device__ const int64_t *row(int s, int ctx) const { return s < n_a ? a + (size_t)s * ctx : b + (size_t)(s - n_a) * ctx; }
+};
 int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2,
                      int a0, int a1, int a2, int a3, int pstride, int dtype, hipStream_t stream);

@@ -74,15 +74,15 @@ __global__ __launch_bounds__(256) void cls_mean_kernel(const float *__restrict__
   ElemOps<T>::store(out + (size_t)item * Ttok * W + c, s / F);
 }
 
-__global__ __launch_bounds__(256) void text_embed_kernel(const int64_t *__restrict__ ids, const float *__restrict__ tok,
+__global__ __launch_bounds__(256) void text_embed_kernel(const TextIds ids, const float *__restrict__ tok,
                                                          const float *__restrict__ pos, float *__restrict__ x, int n_rows,
                                                          int ctx, int W, int vocab) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_rows) return;
-  long id = ids[r];
+  const int sq = r / ctx, p = r - sq * ctx;
+  long id = ids.row(sq, ctx)[p];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // never fault on a bad id
-  const int p = r % ctx;
   const float *tr = tok + (size_t)id * W, *pr = pos + (size_t)p * W;
   float *xr = x + (size_t)r * W;
   for (int c = lane * 4; c < W; c += 256) {
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t *__restri
 
 // Ragged text batch: only the tokens up to and including EOT are materialised (a causal tower never
 // lets a later position influence the EOT feature).  Row seq_offsets[s] + p <- token p of sequence s.
-__global__ __launch_bounds__(256) void text_embed_ragged_kernel(const int64_t *__restrict__ ids, const float *__restrict__ tok,
+__global__ __launch_bounds__(256) void text_embed_ragged_kernel(const TextIds ids, const float *__restrict__ tok,
                                                                 const float *__restrict__ pos, const int *__restrict__ seq_offsets,
                                                                 float *__restrict__ x, int n_seq, int ctx, int W, int vocab) {
   const int lane = threadIdx.x & 63;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void text_embed_ragged_kernel(const int64_t *_
   const int s = r / ctx, p = r - s * ctx;
   const int lo = seq_offsets[s], len = seq_offsets[s + 1] - lo;
   if (p >= len) return;
-  long id = ids[r];
+  long id = ids.row(s, ctx)[p];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   const float *tr = tok + (size_t)id * W, *pr = pos + (size_t)p * W;
   float *xr = x + (size_t)(lo + p) * W;
@@ -118,15 +118,72 @@ __global__ __launch_bounds__(256) void last_row_kernel(const int *__restrict__ s
 }
 
 // eot_row[s] = s*ctx + argmax_p ids[s,p] (first maximum, as torch.argmax)
-__global__ __launch_bounds__(256) void eot_index_kernel(const int64_t *__restrict__ ids, int *__restrict__ eot_row, int n_seq, int ctx) {
+__global__ __launch_bounds__(256) void eot_index_kernel(const TextIds ids, int *__restrict__ eot_row, int n_seq, int ctx) {
   const int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= n_seq) return;
-  const int64_t *r = ids + (size_t)s * ctx;
+  const int64_t *r = ids.row(s, ctx);
   int64_t best = r[0];
   int bi = 0;
   for (int p = 1; p < ctx; ++p)
     if (r[p] > best) { best = r[p]; bi = p; }
   eot_row[s] = s * ctx + bi;
+}
+
+// ---- ragged text batch without host knowledge of the lengths (vtc_text_forward2): what `text.argmax(-1)` (upstream
+// CLIP.encode_text: the EOT id 49407 is the largest), a cumsum and a D2H of the total did on the host in round 2 -----------
+// lens[s] = (position of the first maximum id) + 1.  One wave per sequence.
+__global__ __launch_bounds__(256) void seq_len_kernel(const TextIds ids, int *__restrict__ lens, int n_seq, int ctx) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n_seq) return;
+  const int64_t *r = ids.row(s, ctx);
+  long long best = (long long)0x8000000000000000ull;
+  int bi = 0x7fffffff;
+  for (int p = lane; p < ctx; p += 64) {
+    const long long v = r[p];
+    if (v > best) { best = v; bi = p; }          // ascending p per lane: the first maximum of the lane
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) lens[s] = bi + 1;
+}
+// offsets[0..n_seq] = exclusive prefix sums of lens; m_dev[0] = total rows, m_dev[1] = total rounded up to 256.  One workgroup.
+__global__ __launch_bounds__(1024) void scan_offsets_kernel(const int *__restrict__ lens, int *__restrict__ offsets, int n_seq,
+                                                            int *__restrict__ m_dev) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_seq; base += 1024) {
+    const int i = base + tid;
+    const int v = i < n_seq ? lens[i] : 0;
+    int inc = v;                                   // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wsum[w];
+    const int carry = carry_s;
+    if (i < n_seq) offsets[i] = carry + wbase + inc - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wbase + inc;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int total = carry_s;
+    offsets[n_seq] = total;
+    m_dev[0] = total;
+    m_dev[1] = (total + 255) / 256 * 256;
+  }
 }
 
 // X[b*Lc + 0] = normalize(main[b]);  X[b*Lc + 1 + c] = normalize(empty(b,c) ? mask : comm[b*nc + c])
@@ -297,7 +354,15 @@ int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int
   return 0;
 }
 
-int launch_text_embed(const int64_t *ids, const float *tok, const float *pos, float *x, int *eot_row, int n_seq, int ctx,
+int launch_text_prep(const TextIds &ids, int n_seq, int ctx, int *lens, int *offsets, int *m_dev, hipStream_t stream) {
+  ProfScope prof(VTC_PROF_EMBED, (double)n_seq * ctx * 8, stream);
+  hipLaunchKernelGGL(seq_len_kernel, dim3(cdiv(n_seq, 4)), dim3(256), 0, stream, ids, lens, n_seq, ctx);
+  hipLaunchKernelGGL(scan_offsets_kernel, dim3(1), dim3(1024), 0, stream, lens, offsets, n_seq, m_dev);
+  VTC_LAUNCH_CHECK("text_prep");
+  return 0;
+}
+
+int launch_text_embed(const TextIds &ids, const float *tok, const float *pos, float *x, int *eot_row, int n_seq, int ctx,
                       int W, int vocab, hipStream_t stream) {
   VTC_CHECK(W % 4 == 0, "text_embed: width %d", W);
   ProfScope prof(VTC_PROF_EMBED, (double)n_seq * ctx * W * 12, stream);
@@ -307,10 +372,10 @@ int launch_text_embed(const int64_t *ids, const float *tok, const float *pos, fl
   return 0;
 }
 
-int launch_text_embed_ragged(const int64_t *ids, const float *tok, const float *pos, const int *seq_offsets, float *x, int *eot_row,
-                             int n_seq, int ctx, int W, int vocab, int total_rows, hipStream_t stream) {
+int launch_text_embed_ragged(const TextIds &ids, const float *tok, const float *pos, const int *seq_offsets, float *x, int *eot_row,
+                             int n_seq, int ctx, int W, int vocab, hipStream_t stream) {
   VTC_CHECK(W % 4 == 0, "text_embed: width %d", W);
-  ProfScope prof(VTC_PROF_EMBED, (double)total_rows * W * 12, stream);
+  ProfScope prof(VTC_PROF_EMBED, (double)n_seq * ctx * W * 6, stream);
   hipLaunchKernelGGL(text_embed_ragged_kernel, dim3(cdiv(n_seq * ctx, 4)), dim3(256), 0, stream, ids, tok, pos, seq_offsets, x, n_seq,
                      ctx, W, vocab);
   hipLaunchKernelGGL(last_row_kernel, dim3(cdiv(n_seq, 256)), dim3(256), 0, stream, seq_offsets, eot_row, n_seq);

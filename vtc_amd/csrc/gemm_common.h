@@ -55,7 +55,6 @@ struct GemmParams {
   int M, N, K;
   int lda_bytes, ldw_bytes, ldo;
   int MT, NT;
-  int exp_arg;   // diagnostics only (env VTC_GEMM_EXP), 0 in production
   int col_group;   // phased kernel: column tiles per group of the tile walk (0 = all NT columns in one group)
   int stagger_groups, stagger_ticks;   // phased kernel: workgroup (slot % groups) starts (slot % groups) * ticks x 10 ns late
 #ifdef VTC_GEMM_STAMPS
@@ -91,11 +90,7 @@ __device__ __forceinline__ void glds16(const char *gsrc, unsigned lds_dst) {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // one 128-bit register tuple (asm "v" operand)
 __device__ __forceinline__ void lds_read16(u32x4 &dst, unsigned addr, int off) {
   // "memory": keeps the read below the barrier that publishes the buffer and above the one that recycles it
-#ifdef VTC_ABLATE_LDSREAD
-  asm volatile("; no read %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory");
-#else
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory");
-#endif
 }
 template <int N>
 __device__ __forceinline__ void lgkm_wait(u32x4 &x) {

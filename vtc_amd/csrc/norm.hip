@@ -14,9 +14,11 @@ namespace {
 template <typename OutT, bool NO_NORM>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, OutT *y, int rows,
-                                                        int width, const int *__restrict__ row_index, int row_mul) {
+                                                        int width, const int *__restrict__ row_index, int row_mul,
+                                                        const int *__restrict__ rows_dev) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rows_dev) rows = *rows_dev;
   if (r >= rows) return;
   const size_t src = row_index ? (size_t)row_index[r] : (size_t)r * row_mul;
   const float *xr = x + src * width;
@@ -35,8 +37,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *x, const fl
 // ---- folded LayerNorm (GemmEpi::fold_*): the row statistics a consuming GEMM's epilogue applies -----------------------------
 // stat[r] = (mean, rstd) of row r from the residual GEMM's per-(64 columns, row) partials (sum, squared deviations from the
 // partial mean), merged as a two-pass variance would be: M2 = sum_p M2_p + 64 (mean_p - mean)^2.  One thread per row.
-__global__ __launch_bounds__(256) void fold_stats_kernel(const float2 *__restrict__ part, int nb, int rows, float2 *__restrict__ stat) {
+__global__ __launch_bounds__(256) void fold_stats_kernel(const float2 *__restrict__ part, int nb, int rows, float2 *__restrict__ stat,
+                                                         const int *__restrict__ rows_dev) {
   const int r = blockIdx.x * 256 + threadIdx.x;
+  if (rows_dev) rows = *rows_dev;       // also the stride between the partial planes (the producing GEMM's M)
   if (r >= rows) return;
   float s = 0.f;
   for (int p = 0; p < nb; ++p) s += part[(size_t)p * rows + r].x;
@@ -53,9 +57,11 @@ __global__ __launch_bounds__(256) void fold_stats_kernel(const float2 *__restric
 // Layer 0 has no residual GEMM in front of it: y16 = x in the operand format, stat = (mean, rstd) as LayerNorm computes them.
 template <typename OutT>
 __global__ __launch_bounds__(256) void cast_rowstats_kernel(const float *__restrict__ x, OutT *__restrict__ y, OutT *__restrict__ ylo,
-                                                            float2 *__restrict__ stat, int rows, int width) {
+                                                            float2 *__restrict__ stat, int rows, int width,
+                                                            const int *__restrict__ rows_dev) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rows_dev) rows = *rows_dev;
   if (r >= rows) return;
   const float *xr = x + (size_t)r * width;
   float4 v[LN_MAXV][2];
@@ -107,9 +113,11 @@ __global__ __launch_bounds__(256) void cast_rowstats_kernel(const float *__restr
 // x[src] = hi[src] + lo[src] for the rows src = row_index[i] (or i * row_mul): the fp32 rows the final LayerNorm reads
 template <typename T>
 __global__ __launch_bounds__(256) void split_merge_rows_kernel(const T *__restrict__ hi, const T *__restrict__ lo, float *__restrict__ x,
-                                                               int n, int width, const int *__restrict__ row_index, int row_mul) {
+                                                               int n, int width, const int *__restrict__ row_index, int row_mul,
+                                                               const int *__restrict__ rows_dev) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rows_dev) n = *rows_dev;
   if (i >= n) return;
   const size_t src = row_index ? (size_t)row_index[i] : (size_t)i * row_mul;
   for (int c = lane * 8; c < width; c += 512) {
@@ -147,6 +155,18 @@ __global__ __launch_bounds__(256) void mean_groups_kernel(const float *__restric
   out[i] = s / group;
 }
 
+// out[g] = (a[g] + sum_k b[g * group + k]) / (1 + group): title + its comments, summed in the reference's order
+// (torch.mean(torch.cat([title[None], comments]), 0), model/model.py:357-362)
+__global__ __launch_bounds__(256) void mean_head_groups_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                               float *__restrict__ out, int n_groups, int group, int d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_groups * d) return;
+  const int gi = i / d, c = i - gi * d;
+  float s = a[i];
+  for (int k = 0; k < group; ++k) s += b[((size_t)gi * group + k) * d + c];
+  out[i] = s / (1 + group);
+}
+
 // out[i] = mean of rows [offsets[i], offsets[i+1]) (ragged groups: chunks of one video)
 __global__ __launch_bounds__(256) void segment_mean_kernel(const float *__restrict__ x, const int *__restrict__ offsets,
                                                            float *__restrict__ out, int n, int d) {
@@ -170,51 +190,52 @@ extern "C" int vtc_segment_mean(const float *x, const int *offsets, float *out, 
 }
 
 int launch_layernorm(const float *x, const float *g, const float *b, void *y, int rows, int width, int out_dtype,
-                     const int *row_index, int row_mul, bool no_norm, hipStream_t stream) {
+                     const int *row_index, int row_mul, bool no_norm, hipStream_t stream, const int *rows_dev) {
   VTC_CHECK(rows > 0, "layernorm: rows=%d", rows);
   VTC_CHECK(width % 8 == 0 && width <= 512 * LN_MAXV, "layernorm: width=%d unsupported (multiple of 8, <= 1024)", width);
   const dim3 grid(cdiv(rows, 4)), block(256);
   ProfScope prof(VTC_PROF_NORM, (double)rows * width * (4 + (out_dtype != VTC_F32 ? 2 : 4)), stream);
   if (out_dtype == VTC_F16) {
-    if (no_norm) hipLaunchKernelGGL((layernorm_kernel<f16_t, true>), grid, block, 0, stream, x, g, b, (f16_t *)y, rows, width, row_index, row_mul);
-    else hipLaunchKernelGGL((layernorm_kernel<f16_t, false>), grid, block, 0, stream, x, g, b, (f16_t *)y, rows, width, row_index, row_mul);
+    if (no_norm) hipLaunchKernelGGL((layernorm_kernel<f16_t, true>), grid, block, 0, stream, x, g, b, (f16_t *)y, rows, width, row_index, row_mul, rows_dev);
+    else hipLaunchKernelGGL((layernorm_kernel<f16_t, false>), grid, block, 0, stream, x, g, b, (f16_t *)y, rows, width, row_index, row_mul, rows_dev);
   } else if (out_dtype == VTC_BF16) {
-    if (no_norm) hipLaunchKernelGGL((layernorm_kernel<bf16_t, true>), grid, block, 0, stream, x, g, b, (bf16_t *)y, rows, width, row_index, row_mul);
-    else hipLaunchKernelGGL((layernorm_kernel<bf16_t, false>), grid, block, 0, stream, x, g, b, (bf16_t *)y, rows, width, row_index, row_mul);
+    if (no_norm) hipLaunchKernelGGL((layernorm_kernel<bf16_t, true>), grid, block, 0, stream, x, g, b, (bf16_t *)y, rows, width, row_index, row_mul, rows_dev);
+    else hipLaunchKernelGGL((layernorm_kernel<bf16_t, false>), grid, block, 0, stream, x, g, b, (bf16_t *)y, rows, width, row_index, row_mul, rows_dev);
   } else {
-    if (no_norm) hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, 0, stream, x, g, b, (float *)y, rows, width, row_index, row_mul);
-    else hipLaunchKernelGGL((layernorm_kernel<float, false>), grid, block, 0, stream, x, g, b, (float *)y, rows, width, row_index, row_mul);
+    if (no_norm) hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, 0, stream, x, g, b, (float *)y, rows, width, row_index, row_mul, rows_dev);
+    else hipLaunchKernelGGL((layernorm_kernel<float, false>), grid, block, 0, stream, x, g, b, (float *)y, rows, width, row_index, row_mul, rows_dev);
   }
   VTC_LAUNCH_CHECK("layernorm");
   return 0;
 }
 
-int launch_fold_stats(const float *part, int nb, int rows, float *stat, hipStream_t stream) {
+int launch_fold_stats(const float *part, int nb, int rows, float *stat, hipStream_t stream, const int *rows_dev) {
   ProfScope prof(VTC_PROF_NORM, (double)rows * 8 * (nb + 1), stream);
-  hipLaunchKernelGGL(fold_stats_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, (const float2 *)part, nb, rows, (float2 *)stat);
+  hipLaunchKernelGGL(fold_stats_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, stream, (const float2 *)part, nb, rows, (float2 *)stat, rows_dev);
   VTC_LAUNCH_CHECK("fold_stats");
   return 0;
 }
 
-int launch_cast_rowstats(const float *x, void *y16, void *y16lo, float *stat, int rows, int width, int dtype, hipStream_t stream) {
+int launch_cast_rowstats(const float *x, void *y16, void *y16lo, float *stat, int rows, int width, int dtype, hipStream_t stream,
+                         const int *rows_dev) {
   VTC_CHECK(width % 8 == 0 && width <= 512 * LN_MAXV && (dtype == VTC_BF16 || dtype == VTC_F16), "cast_rowstats: width=%d dtype=%d", width, dtype);
   ProfScope prof(VTC_PROF_NORM, (double)rows * width * 8, stream);
   if (dtype == VTC_F16)
-    hipLaunchKernelGGL((cast_rowstats_kernel<f16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, (f16_t *)y16, (f16_t *)y16lo, (float2 *)stat, rows, width);
+    hipLaunchKernelGGL((cast_rowstats_kernel<f16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, (f16_t *)y16, (f16_t *)y16lo, (float2 *)stat, rows, width, rows_dev);
   else
-    hipLaunchKernelGGL((cast_rowstats_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, (bf16_t *)y16, (bf16_t *)y16lo, (float2 *)stat, rows, width);
+    hipLaunchKernelGGL((cast_rowstats_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, (bf16_t *)y16, (bf16_t *)y16lo, (float2 *)stat, rows, width, rows_dev);
   VTC_LAUNCH_CHECK("cast_rowstats");
   return 0;
 }
 
 int launch_split_merge_rows(const void *hi, const void *lo, float *x, int n, int width, const int *row_index, int row_mul, int dtype,
-                            hipStream_t stream) {
+                            hipStream_t stream, const int *rows_dev) {
   VTC_CHECK(width % 8 == 0 && (dtype == VTC_BF16 || dtype == VTC_F16), "split_merge_rows: width=%d dtype=%d", width, dtype);
   ProfScope prof(VTC_PROF_NORM, (double)n * width * 8, stream);
   if (dtype == VTC_F16)
-    hipLaunchKernelGGL((split_merge_rows_kernel<f16_t>), dim3(cdiv(n, 4)), dim3(256), 0, stream, (const f16_t *)hi, (const f16_t *)lo, x, n, width, row_index, row_mul);
+    hipLaunchKernelGGL((split_merge_rows_kernel<f16_t>), dim3(cdiv(n, 4)), dim3(256), 0, stream, (const f16_t *)hi, (const f16_t *)lo, x, n, width, row_index, row_mul, rows_dev);
   else
-    hipLaunchKernelGGL((split_merge_rows_kernel<bf16_t>), dim3(cdiv(n, 4)), dim3(256), 0, stream, (const bf16_t *)hi, (const bf16_t *)lo, x, n, width, row_index, row_mul);
+    hipLaunchKernelGGL((split_merge_rows_kernel<bf16_t>), dim3(cdiv(n, 4)), dim3(256), 0, stream, (const bf16_t *)hi, (const bf16_t *)lo, x, n, width, row_index, row_mul, rows_dev);
   VTC_LAUNCH_CHECK("split_merge_rows");
   return 0;
 }
@@ -228,6 +249,13 @@ extern "C" int vtc_normalize_rows(const float *x, float *out, int n, int d, void
   VTC_CHECK(n > 0 && d > 0, "normalize_rows: n=%d d=%d", n, d);
   hipLaunchKernelGGL(normalize_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x, out, n, d);
   VTC_LAUNCH_CHECK("normalize_rows");
+  return 0;
+}
+
+extern "C" int vtc_mean_head_groups(const float *a, const float *b, float *out, int n_groups, int group, int d, void *stream) {
+  VTC_CHECK(n_groups > 0 && group >= 0 && d > 0 && a && out && (b || group == 0), "mean_head_groups: bad arguments");
+  hipLaunchKernelGGL(mean_head_groups_kernel, dim3(cdiv(n_groups * d, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n_groups, group, d);
+  VTC_LAUNCH_CHECK("mean_head_groups");
   return 0;
 }
 

@@ -49,7 +49,6 @@ struct QkvAttnParams {
   int n_seq, L, heads, causal;
   int s2, a0, a1, a2, a3, pstride;     // row map of attention.hip / vtc_attention
   int W, G, n_groups;
-  int dbg;              // diagnostics (env VTC_QKVA_SKIP): bit 0 skip the attention phase, 1 skip acc -> LDS, 2 skip the O store
 };
 
 template <int N>
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     // every wave is past its last read of stage 1: the Q/K/V^T region may be written
 
     // ================= accumulators -> LDS: Q, K row-major [token][64] (swizzled 16-byte chunks), V^T [d][slot] ==========
-    if (!(p.dbg & 2)) {
+    {
       // V^T slots that hold no token but are read (P is exactly 0 there, so they only have to be finite): the tail behind the
       // tile's last sequence up to the key-tile overhang, and the <= 3 slots between L and Lp of every sequence
       unsigned short *vt = reinterpret_cast<unsigned short *>(lds + V_OFF);
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
 
     // ================= attention: one wave per (sequence, 16-query tile), TWO units in flight per wave =================
     // (a unit is a serial chain LDS read -> MFMA -> softmax -> MFMA; two independent chains interleave)
-    if (!(p.dbg & 1)) {
+    {
       const unsigned short *vt = reinterpret_cast<const unsigned short *>(lds + V_OFF);
       // Short sequences (time attention, L = 8; L = 4): PACK = 16 / L sequences share one 16 x 16 score tile, block-diagonal
       // mask between them -- a tile of one 8-token sequence would leave three quarters of the lanes on masked entries.
@@ -410,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     // Branch-free: every wave issues exactly BM * 8 / 512 = 4 store instructions (the next tile's first wait counts on it).
     // Lanes without a row of their own -- past the tile's last token, or a cls token whose output went to cls_out -- repeat
     // a neighbouring row's store (same bytes to the same address).
-    if (!(p.dbg & 4)) {
+    {
 #pragma unroll
       for (int c = 0; c < BM * 8 / 512; ++c) {
         const int id = tid + 512 * c;
@@ -475,8 +474,6 @@ int launch_qkv_attention(const void *h, const void *w_qkv, const float *b_qkv, v
   p.W = heads * 64;
   p.G = min(32, BM / L);
   p.n_groups = cdiv(n_seq, p.G);
-  static const int dbg = [] { const char *e = getenv("VTC_QKVA_SKIP"); return e ? atoi(e) : 0; }();
-  p.dbg = dbg;
   const double flops = 2.0 * n_seq * L * 3.0 * p.W * p.W + 4.0 * L * L * 64 * (double)n_seq * heads;
   ProfScope prof(VTC_PROF_GEMM_BF16, flops, stream);
   return dtype == VTC_F16 ? dispatch<f16_t>(p, stream) : dispatch<bf16_t>(p, stream);

@@ -1045,7 +1045,7 @@ static int exact_finish(const float *gallery, const float *queries, int ng, int 
 // ONE plain-bf16 distance GEMM whose epilogue keeps, per (query, block of 64 gallery rows), the three smallest distances and
 // the fourth as a bound (gemm.hip, EPI_L2MIN) -- and, for vtc_l2_topk_bidir, the same per (gallery row, block of RB queries)
 // from the same accumulators; no N x N matrix is written or read.  minsel_kernel turns the block minima into a candidate set
-// that PROVABLY contains the query's true top-k (or says that it cannot), exact_rerank_kernel orders it by fp64 distances,
+// that provably (given the per-entry error bound exact2_kappa, derived there) contains the query's true top-k (or says that it cannot), exact_rerank_kernel orders it by fp64 distances,
 // the uncertified queries are recomputed by fp64 brute force.
 namespace {
 int exact2_variant() {        // 0: 256 x 256 phased tiles (row blocks of 128); 1: 128 x 128 tiles, two workgroups per CU (row blocks of 64)
@@ -1057,10 +1057,13 @@ bool exact2_enabled(int ng, int nq, int depth) {
   return !off && depth <= 32 && ng >= 1024 && nq >= 1;
 }
 constexpr int CD2 = 64;       // capacity of a candidate list of the block-minima path
-// worst-case |approx - exact| of a key's distance, relative to |q|^2 + max|g|^2: two bf16 operand roundings, 2^-8 (1 + 2^-10)
-// on |q||g| <= (|q|^2 + |g|^2) / 2, i.e. on the distance; fp32 accumulation of d products and the two norms; the 7 index
-// bits of the key (2^-16 relative); the epilogue's roundings
-float exact2_kappa(int d) { return 1.0f / 256.0f * (1.0f + 1.0f / 1024.0f) + 2.0f * d / 16777216.0f + 1.0f / 65536.0f + 1e-6f; }
+// worst-case |approx - exact| of a key's distance, relative to |q|^2 + max|g|^2.  bf16 keeps 8 significant bits, so its unit
+// roundoff under round-to-nearest-even is u = 2^-8 (NOT 2^-9: rounds 1-2 had half this constant -- random embeddings sit far
+// inside either bound, coordinated roundings on bf16 midpoints do not: tests/test_gpu_sweep.py adversarial case):
+//   q~.g~ - q.g = sum q e_g + g e_q + e_q e_g,  |e| <= u |x|   =>   |.| <= (2u + u^2) |q||g| <= (2u + u^2)(|q|^2 + |g|^2) / 2,
+// twice that on the distance: 2^-7 (1 + 2^-9); fp32 accumulation of d products and the two fp32 norms (2 d 2^-24); the 7 index
+// bits of the key (2^-16 of a distance <= 2 (|q|^2 + |g|^2)); the epilogue's roundings (slack)
+float exact2_kappa(int d) { return 1.0f / 128.0f * (1.0f + 1.0f / 512.0f) + 2.0f * d / 16777216.0f + 1.0f / 32768.0f + 1e-6f; }
 
 struct Sweep2Ws {
   float *qn, *gn, *gmax, *qmax;
@@ -1282,10 +1285,12 @@ static int exact_finish(const float *gallery, const float *queries, int ng, int 
                         const float *cand_d, const float *qn, const float *gn, float *gmax, int *flags, int64_t *ids, float *dists,
                         hipStream_t stream, const int *cand_n, const FallbackWs *fb, const Rescan *rs) {
   if (!cand_n) hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, gn, ng, gmax);
-  // split-bf16 candidate lists (cand_n == nullptr): worst-case error of a split-bf16 distance, relative to |q|^2 + max|g|^2:
-  // dropped lo.lo products and the second bf16 rounding of both operands (3 * 2^-18), fp32 accumulation of 3 d products
-  // (3 d * 2^-24), fp32 row norms (d * 2^-24), the epilogue's three roundings.  (Block-minima lists arrive certified.)
-  const float kappa = 3.0f / 262144.0f + 4.0f * d / 16777216.0f + 1e-6f;
+  // split-bf16 candidate lists (cand_n == nullptr): worst-case error of a split-bf16 distance, relative to |q|^2 + max|g|^2.
+  // With u = 2^-8 (bf16's unit roundoff): x = hi + lo + r, |lo| <= u |x|, |r| <= u^2 |x|; the GEMM forms hi.hi + hi.lo + lo.hi,
+  // so the product misses lo.lo (u^2 |q||g|) and the two residual terms (2 u^2 |q||g|): 3 u^2 |q||g| <= 3 u^2 (|q|^2 + |g|^2) / 2,
+  // twice that on the distance = 3 * 2^-16 (rounds 1-2 had 3 * 2^-18); fp32 accumulation of 3 d products (3 d * 2^-24), fp32 row
+  // norms (d * 2^-24), the epilogue's three roundings.  (Block-minima lists arrive certified.)
+  const float kappa = 3.0f / 65536.0f + 4.0f * d / 16777216.0f + 1e-6f;
   (void)hipMemsetAsync(flags, 0, sizeof(int), stream);
   hipLaunchKernelGGL(exact_rerank_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, queries, gallery, nq, ng, d, cand, cand_d, cdepth,
                      depth, qn, gmax, kappa, ids, dists, flags, cand_n);

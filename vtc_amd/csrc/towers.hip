@@ -31,24 +31,14 @@ void vtc_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 extern "C" const char *vtc_last_error(void) { return g_err; }
-extern "C" int vtc_abi_version(void) { return 4; }
-namespace { extern std::atomic<int> g_fused_attn; extern std::atomic<int> g_ln_fold; }
-extern "C" int vtc_set_ln_fold(int on) {
-  g_ln_fold.store(on != 0);
-  return 0;
-}
-extern "C" int vtc_set_fused_attention(int mask) {
-  VTC_CHECK(mask >= 0 && mask <= 3, "set_fused_attention: mask %d outside [0, 3]", mask);
-  g_fused_attn.store(mask);
-  return 0;
-}
-
+extern "C" int vtc_abi_version(void) { return 5; }
 int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res, const float *mean, const float *stdv, hipStream_t stream);
 int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, int T, int W, hipStream_t stream);
 int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int F, int T, int W, hipStream_t stream);
-int launch_text_embed(const int64_t *ids, const float *tok, const float *pos, float *x, int *eot_row, int n_seq, int ctx, int W, int vocab, hipStream_t stream);
-int launch_text_embed_ragged(const int64_t *ids, const float *tok, const float *pos, const int *seq_offsets, float *x, int *eot_row, int n_seq, int ctx, int W, int vocab, int total_rows, hipStream_t stream);
-int launch_attention_ragged(const void *qkv, void *out, int n_seq, int max_L, int heads, int causal, const int *seq_offsets, double flops, int dtype, hipStream_t stream);
+int launch_text_prep(const TextIds &ids, int n_seq, int ctx, int *lens, int *offsets, int *m_dev, hipStream_t stream);
+int launch_text_embed(const TextIds &ids, const float *tok, const float *pos, float *x, int *eot_row, int n_seq, int ctx, int W, int vocab, hipStream_t stream);
+int launch_text_embed_ragged(const TextIds &ids, const float *tok, const float *pos, const int *seq_offsets, float *x, int *eot_row, int n_seq, int ctx, int W, int vocab, hipStream_t stream);
+int launch_attention_ragged(const void *qkv, void *out, int n_seq, int max_L, int heads, int causal, const int *seq_offsets, double flops, const int *rows_dev, int dtype, hipStream_t stream);
 int launch_cam_tokens(const float *main_f, const float *comm, const int64_t *comments, const float *mask_emb, float *X, int B, int nc, int ctx, int D, hipStream_t stream);
 int launch_cls_global_attention(const void *qkv, void *out, int n_items, int Ttok, int heads, int dtype, hipStream_t stream);
 int launch_cam_finalize(const float *Y, const float *lin, const float *main_f, float *out, int B, int Lc, int D, int init_from_avg, int act, float scale, const float *bn_mean, const float *bn_var, hipStream_t stream);
@@ -60,22 +50,12 @@ int launch_qkv_attention(const void *h, const void *w_qkv, const float *b_qkv, v
 namespace {
 
 // QKV projection + attention core in one kernel (qkv_attn.hip) instead of {QKV GEMM -> packed qkv in HBM -> attention
-// kernel}.  Bit-identical results.  Bit 0: contiguous sequences (ViT, dense text) and the time branch; bit 1: the space
-// branch.  OFF by default: measured on MI355X the fused kernel's GEMM phase runs at 0.99 PFLOP/s but its QKV -> LDS,
-// attention and store phases are serial per tile (28 % of its time with the matrix pipe idle), while the stand-alone
-// attention kernel streams its packed qkv at 4.8-5.1 TB/s -- the two-kernel path wins by 1-4 % per step.
-// vtc_set_fused_attention() / VTC_FUSED_ATTN select it.
-std::atomic<int> g_fused_attn{-1};
-int fused_attn_mask() {
-  int m = g_fused_attn.load(std::memory_order_relaxed);
-  if (m < 0) {
-    const char *e = getenv("VTC_FUSED_ATTN");
-    m = e ? atoi(e) & 3 : 0;
-    g_fused_attn.store(m, std::memory_order_relaxed);
-  }
-  return m;
-}
-bool fused_attn_enabled() { return fused_attn_mask() & 1; }
+// kernel}: vtc_vision_w.flags / vtc_text_w.flags, VTC_TOWER_FUSED_ATTN (contiguous sequences + the time branch) and
+// VTC_TOWER_FUSED_ATTN_SPACE.  Bit-identical results.  Off unless the model asks: measured on MI355X the fused kernel's GEMM
+// phase runs at 0.99 PFLOP/s but its QKV -> LDS, attention and store phases are serial per tile (28 % of its time with the
+// matrix pipe idle), while the stand-alone attention kernel streams its packed qkv at 4.8-5.1 TB/s -- the two-kernel path wins
+// by 1-4 % per step.  (Rounds 1-2 kept these choices in process-wide switches; they are per model now.)
+inline bool fused_attn_enabled(int flags) { return (flags & VTC_TOWER_FUSED_ATTN) != 0; }
 
 struct Bump {
   char *base;
@@ -109,17 +89,7 @@ int gemm(const void *A, const void *W, const float *bias, void *out, int M, int 
 // projection reads xb against gamma-scaled weights and applies mean / rstd in its epilogue.  The LayerNorm kernels' 1.2 GB
 // read + 0.6 GB write per launch (config 3, 1 024 videos) become a 0.6 GB write in the residual epilogue.  Needs every tile
 // interior: rows padded to 256 (the pad rows hold garbage that no kernel outside the GEMMs reads), W a multiple of 256.
-// VTC_LN_FOLD=0 / vtc_set_ln_fold(0): the LayerNorm kernels.
-std::atomic<int> g_ln_fold{-1};
-bool ln_fold_enabled() {
-  int m = g_ln_fold.load(std::memory_order_relaxed);
-  if (m < 0) {
-    const char *e = getenv("VTC_LN_FOLD");
-    m = e ? (atoi(e) != 0) : 1;
-    g_ln_fold.store(m, std::memory_order_relaxed);
-  }
-  return m != 0;
-}
+// flags & VTC_TOWER_NO_LN_FOLD (or any fused-attention flag): the LayerNorm kernels.
 struct Fold {
   bool on = false;
   void *xb = nullptr;       // [rows_pad, W] operand format: the residual stream as the projections read it (hi of the pair)
@@ -136,52 +106,68 @@ int fold_merge_rows(Fold &f, float *x, int n, int W, const int *row_index, int r
   return launch_split_merge_rows(f.xb, f.xl, x, n, W, row_index, row_mul, f.fmt, s);
 }
 inline int pad256(int rows) { return (rows + 255) / 256 * 256; }
-bool fold_usable(const vtc_block_w *blocks, int layers, int W, int dtype, bool timesformer) {
-  if (!ln_fold_enabled() || dtype == VTC_F32 || W % 256 != 0 || fused_attn_mask()) return false;
+bool fold_usable(const vtc_block_w *blocks, int layers, int W, int dtype, bool timesformer, int flags) {
+  if ((flags & (VTC_TOWER_NO_LN_FOLD | VTC_TOWER_FUSED_ATTN | VTC_TOWER_FUSED_ATTN_SPACE)) || dtype == VTC_F32 || W % 256 != 0) return false;
   for (int l = 0; l < layers; ++l)
     if (!blocks[l].qkv_wf || !blocks[l].fc_wf || (timesformer && !blocks[l].tqkv_wf)) return false;
   return true;
 }
 
+// A row count: known to the host (dev == NULL), or living in device memory -- the ragged text tower of vtc_text_forward2, whose
+// lengths the host never sees: n is then the dense upper bound (it sizes grids and the workspace) and every kernel reads
+// dev[0] = the rows, dev[1] = the rows padded to 256 (what the folded GEMMs run over).
+struct Rows {
+  int n;
+  const int *dev = nullptr;
+  Rows(int n_) : n(n_) {}
+  Rows(int n_, const int *dev_) : n(n_), dev(dev_) {}
+  const int *dev_pad() const { return dev ? dev + 1 : nullptr; }
+};
+
 // out = epi(LN(x; g, bt) w^T + bias)
 int ln_proj(Fold &f, const float *x, const float *g, const float *bt, const void *w, const float *bias, const void *wf, const float *fs,
-            const float *fc, void *h, void *out, int rows, int N, int W, int dtype, int mode, hipStream_t s) {
+            const float *fc, void *h, void *out, const Rows &rows, int N, int W, int dtype, int mode, hipStream_t s) {
   if (f.on) {
     if (f.fmt != dtype) {       // no residual GEMM of this format in front: layer 0, or a format boundary (back through fp32)
-      if (f.fmt >= 0) RUN(launch_split_merge_rows(f.xb, f.xl, const_cast<float *>(x), rows, W, nullptr, 1, f.fmt, s));
-      RUN(launch_cast_rowstats(x, f.xb, f.xl, f.stat, rows, W, dtype, s));
+      if (f.fmt >= 0) RUN(launch_split_merge_rows(f.xb, f.xl, const_cast<float *>(x), rows.n, W, nullptr, 1, f.fmt, s, rows.dev));
+      RUN(launch_cast_rowstats(x, f.xb, f.xl, f.stat, rows.n, W, dtype, s, rows.dev));
       f.fmt = dtype;
     }
     GemmEpi e;
-    e.mode = mode; e.out_dtype = dtype; e.fold_stat = f.stat; e.fold_s = fs;
+    e.mode = mode; e.out_dtype = dtype; e.fold_stat = f.stat; e.fold_s = fs; e.m_dev = rows.dev_pad();
     return launch_gemm(f.xb, wf, fc, out, f.rows_pad, N, W, dtype, e, s);
   }
-  RUN(launch_layernorm(x, g, bt, h, rows, W, dtype, nullptr, 1, false, s));
-  return gemm(h, w, bias, out, rows, N, W, dtype, mode, dtype, 0, s);
+  RUN(launch_layernorm(x, g, bt, h, rows.n, W, dtype, nullptr, 1, false, s, rows.dev));
+  GemmEpi e;
+  e.mode = mode; e.out_dtype = dtype; e.m_dev = rows.dev;
+  return launch_gemm(h, w, bias, out, rows.n, N, W, dtype, e, s);
 }
 
 // x += A w^T + bias  (rows with m % skip_mod == 0 untouched)
 // center: this update also subtracts the rows' previous means (the stream stays centred; once per layer is enough -- a single
 // update moves a row's mean by a fraction of its spread)
-int resid_proj(Fold &f, const void *A, const void *w, const float *bias, float *x, int rows, int W, int K, int dtype, int skip_mod,
+int resid_proj(Fold &f, const void *A, const void *w, const float *bias, float *x, const Rows &rows, int W, int K, int dtype, int skip_mod,
                hipStream_t s, bool center = false) {
   if (f.on) {
     GemmEpi e;
     e.mode = VTC_EPI_RESID; e.out_dtype = VTC_F32; e.skip_mod = skip_mod; e.y16 = f.xb; e.y16lo = f.xl; e.fold_part = f.part;
+    e.m_dev = rows.dev_pad();
     if (center) e.fold_stat = f.stat;       // the rows' means before this update: the stream is stored centred (gemm.hip, SPLIT)
     if (f.fmt != dtype) {       // the stream is not a pair of this format yet (cannot happen behind ln_proj; kept for safety)
-      if (f.fmt >= 0) RUN(launch_split_merge_rows(f.xb, f.xl, x, rows, W, nullptr, 1, f.fmt, s));
-      RUN(launch_cast_rowstats(x, f.xb, f.xl, f.stat, rows, W, dtype, s));
+      if (f.fmt >= 0) RUN(launch_split_merge_rows(f.xb, f.xl, x, rows.n, W, nullptr, 1, f.fmt, s, rows.dev));
+      RUN(launch_cast_rowstats(x, f.xb, f.xl, f.stat, rows.n, W, dtype, s, rows.dev));
       f.fmt = dtype;
     }
     RUN(launch_gemm(A, w, bias, x, f.rows_pad, W, K, dtype, e, s));
-    return launch_fold_stats(f.part, W / 64, f.rows_pad, f.stat, s);
+    return launch_fold_stats(f.part, W / 64, f.rows_pad, f.stat, s, rows.dev_pad());
   }
-  return gemm(A, w, bias, x, rows, W, K, dtype, VTC_EPI_RESID, VTC_F32, skip_mod, s);
+  GemmEpi e;
+  e.mode = VTC_EPI_RESID; e.out_dtype = VTC_F32; e.skip_mod = skip_mod; e.m_dev = rows.dev;
+  return launch_gemm(A, w, bias, x, rows.n, W, K, dtype, e, s);
 }
 
 // x += MLP(ln_2 x)   (timesformer_clip_alt.py:174 / upstream block)
-int mlp_part(Fold &f, const vtc_block_w &b, float *x, void *h, void *big, int rows, int W, int dtype, hipStream_t s) {
+int mlp_part(Fold &f, const vtc_block_w &b, float *x, void *h, void *big, const Rows &rows, int W, int dtype, hipStream_t s) {
   ProfRegion region(VTC_PROF_REGION_MLP);
   RUN(ln_proj(f, x, b.ln2_g, b.ln2_b, b.fc_w, b.fc_b, b.fc_wf, b.fc_s, b.fc_c, h, big, rows, 4 * W, W, dtype, VTC_EPI_GELU, s));
   RUN(resid_proj(f, big, b.proj_w, b.proj_b, x, rows, W, 4 * W, dtype, 0, s, true));
@@ -190,10 +176,10 @@ int mlp_part(Fold &f, const vtc_block_w &b, float *x, void *h, void *big, int ro
 
 // x += MHA(ln_1 x) over n_seq contiguous sequences of L tokens
 int attn_part_contig(Fold &f, const vtc_block_w &b, float *x, void *h, void *big, int n_seq, int L, int W, int heads, int causal,
-                     int dtype, hipStream_t s) {
+                     int dtype, int flags, hipStream_t s) {
   const int rows = n_seq * L;
   ProfRegion region(VTC_PROF_REGION_ATTN);
-  if (!f.on && fused_attn_enabled() && qkv_attention_supported(L, heads, W, dtype, (size_t)rows)) {
+  if (!f.on && fused_attn_enabled(flags) && qkv_attention_supported(L, heads, W, dtype, (size_t)rows)) {
     RUN(launch_layernorm(x, b.ln1_g, b.ln1_b, h, rows, W, dtype, nullptr, 1, false, s));
     RUN(launch_qkv_attention(h, b.qkv_w, b.qkv_b, big, nullptr, n_seq, L, heads, causal, 1, 0, L, 0, 0, 1, (size_t)rows, dtype, s));
     RUN(gemm(big, b.out_w, b.out_b, x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
@@ -245,6 +231,7 @@ struct TextWs {
   float *x;
   void *h, *big, *lnp;
   int *eot;
+  int *lens, *offs, *mdev;     // vtc_text_forward2, ragged: per-sequence lengths, their prefix sums, (rows, rows padded to 256)
   Fold fold;
   size_t total;
 };
@@ -258,6 +245,9 @@ TextWs plan_text(int rows_, int n_seq, int W, int dtype, void *ws) {
   t.big = b.take(rows * 4 * W * esz(dtype));
   t.lnp = b.take((size_t)n_seq * W * 4);
   t.eot = (int *)b.take((size_t)n_seq * 4);
+  t.lens = (int *)b.take((size_t)n_seq * 4);
+  t.offs = (int *)b.take((size_t)(n_seq + 1) * 4);
+  t.mdev = (int *)b.take(16);
   if (dtype != VTC_F32) {
     t.fold.rows_pad = (int)rows;
     t.fold.xb = b.take(rows * W * 2);
@@ -313,7 +303,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
   RUN(launch_layernorm(v.x, w->ln_pre_g, w->ln_pre_b, v.x, rows, W, VTC_F32, nullptr, 1, false, s));
 
   Fold &fold = v.fold;
-  fold.on = fold_usable(w->blocks, w->layers, W, dtype, tsf);
+  fold.on = fold_usable(w->blocks, w->layers, W, dtype, tsf, w->flags);
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
     {
@@ -332,7 +322,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
       RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, P, 1, dtype, s));
       RUN(launch_cls_global_attention(v.big, v.h, n_items, T, w->heads, dtype, s));
       RUN(resid_proj(fold, v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, 0, s));
-    } else if (tsf && fused_attn_enabled() && qkv_attention_supported(1 + P, w->heads, W, dtype, (size_t)rows)) {
+    } else if (tsf && fused_attn_enabled(w->flags) && qkv_attention_supported(1 + P, w->heads, W, dtype, (size_t)rows)) {
       // Same two branches with QKV + attention core in one kernel each (qkv_attn.hip): the attention output lands in
       // `big` (as [rows, W]); the packed qkv matrix never exists.
       RUN(launch_layernorm(v.x, b.lnt_g, b.lnt_b, v.h, rows, W, dtype, nullptr, 1, false, s));
@@ -344,7 +334,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
         RUN(gemm(v.big, b.tfc_w, b.tfc_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, T, s));
       }
       RUN(launch_layernorm(v.x, b.ln1_g, b.ln1_b, v.h, rows, W, dtype, nullptr, 1, false, s));
-      if (fused_attn_mask() & 2) {
+      if (w->flags & VTC_TOWER_FUSED_ATTN_SPACE) {
         RUN(launch_qkv_attention(v.h, b.qkv_w, b.qkv_b, v.big, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, 1, F, (size_t)rows, dtype, s));
         RUN(launch_cls_mean(v.cls_tmp, v.big, dtype, n_items, F, T, W, s));
         RUN(gemm(v.big, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
@@ -370,7 +360,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
       RUN(launch_cls_mean(v.cls_tmp, v.h, dtype, n_items, F, T, W, s));
       RUN(resid_proj(fold, v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, 0, s));
     } else {
-      RUN(attn_part_contig(fold, b, v.x, v.h, v.big, n_items, T, W, w->heads, 0, dtype, s));
+      RUN(attn_part_contig(fold, b, v.x, v.h, v.big, n_items, T, W, w->heads, 0, dtype, w->flags, s));
     }
     }
     RUN(mlp_part(fold, b, v.x, v.h, v.big, rows, W, dtype, s));
@@ -388,24 +378,46 @@ extern "C" size_t vtc_text_workspace_bytes(const vtc_text_w *w, int n_seq, int d
   return plan_text(n_seq * w->ctx, n_seq, w->width, dtype, nullptr).total;
 }
 
-extern "C" int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_seq, float *out, void *ws, size_t ws_bytes,
-                                int dtype, void *stream_) {
-  hipStream_t s = (hipStream_t)stream_;
-  VTC_CHECK(w && ids && out && ws, "text_forward: null argument");
-  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16 || dtype == VTC_F16, "text_forward: bad dtype %d", dtype);
-  VTC_CHECK(n_seq > 0, "text_forward: n_seq=%d", n_seq);
-  VTC_CHECK(w->ctx <= 80, "text_forward: context %d > 80 unsupported", w->ctx);
-  VTC_CHECK(w->width == w->heads * 64, "text_forward: head_dim must be 64");
-  const int W = w->width, rows = n_seq * w->ctx;
-  TextWs t = plan_text(rows, n_seq, W, dtype, ws);
-  VTC_CHECK(ws_bytes >= t.total, "text_forward: workspace too small (%zu < %zu)", ws_bytes, t.total);
-  RUN(launch_text_embed(ids, w->tok_emb, w->pos, t.x, t.eot, n_seq, w->ctx, W, w->vocab, s));
+namespace {
+// The text tower over the sequences of `ids` (two arrays back to back).  mode 0: dense, all ctx positions of every sequence;
+// 1: ragged with host-known prefix sums (seq_offsets, total_rows); 2: ragged with NOTHING known to the host -- EOT positions,
+// prefix sums and the row count are computed on the device (embed.hip text_prep) and every kernel reads the count there.
+// Ragged = only the rows [seq_offsets[s], seq_offsets[s+1]) = tokens 0..EOT of each sequence exist.  Identical outputs: under
+// the causal mask no token after EOT can influence the EOT feature, and every other op of the tower is per-row.
+int text_forward_impl(const vtc_text_w *w, const TextIds &ids, int mode, const int *seq_offsets, int total_rows, float *out, void *ws,
+                      size_t ws_bytes, int dtype, hipStream_t s, const char *who) {
+  const int n_seq = ids.n_a + ids.n_b;
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16 || dtype == VTC_F16, "%s: bad dtype %d", who, dtype);
+  VTC_CHECK(w->ctx <= 80, "%s: context %d > 80 unsupported", who, w->ctx);
+  VTC_CHECK(w->width == w->heads * 64, "%s: head_dim must be 64", who);
+  const int W = w->width;
+  const int rows_host = mode == 1 ? total_rows : n_seq * w->ctx;          // exact (modes 0, 1) or the dense upper bound (mode 2)
+  TextWs t = plan_text(rows_host, n_seq, W, dtype, ws);
+  VTC_CHECK(ws_bytes >= t.total, "%s: workspace too small (%zu < %zu)", who, ws_bytes, t.total);
+  const int *offs = seq_offsets;
+  Rows rows(rows_host);
+  if (mode == 2) {
+    RUN(launch_text_prep(ids, n_seq, w->ctx, t.lens, t.offs, t.mdev, s));
+    offs = t.offs;
+    rows = Rows(rows_host, t.mdev);
+  }
+  if (mode == 0) RUN(launch_text_embed(ids, w->tok_emb, w->pos, t.x, t.eot, n_seq, w->ctx, W, w->vocab, s));
+  else RUN(launch_text_embed_ragged(ids, w->tok_emb, w->pos, offs, t.x, t.eot, n_seq, w->ctx, W, w->vocab, s));
   Fold &fold = t.fold;
-  fold.on = fold_usable(w->blocks, w->layers, W, dtype, false);
+  fold.on = fold_usable(w->blocks, w->layers, W, dtype, false, w->flags);
+  // attention work of the ragged batch for the profiler (the lengths are not known here): rows x (mean length ~ ctx / 2)
+  const double attn_flops_per_row = 4.0 * (0.5 * w->ctx) * 64 * w->heads;
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
     const int dl = layer_dtype(w, l, dtype);
-    RUN(attn_part_contig(fold, b, t.x, t.h, t.big, n_seq, w->ctx, W, w->heads, 1, dl, s));
+    if (mode == 0) {
+      RUN(attn_part_contig(fold, b, t.x, t.h, t.big, n_seq, w->ctx, W, w->heads, 1, dl, w->flags, s));
+    } else {
+      ProfRegion region(VTC_PROF_REGION_ATTN);
+      RUN(ln_proj(fold, t.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, t.h, t.big, rows, 3 * W, W, dl, VTC_EPI_STORE, s));
+      RUN(launch_attention_ragged(t.big, t.h, n_seq, w->ctx, w->heads, 1, offs, attn_flops_per_row * (rows.dev ? 1.0 : rows.n), rows.dev, dl, s));
+      RUN(resid_proj(fold, t.h, b.out_w, b.out_b, t.x, rows, W, W, dl, 0, s));
+    }
     RUN(mlp_part(fold, b, t.x, t.h, t.big, rows, W, dl, s));
   }
   // ln_final on the EOT row only (LayerNorm is per-row, so gathering first is identical), then @ text_projection
@@ -415,44 +427,34 @@ extern "C" int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_s
   RUN(gemm(t.lnp, w->proj_t, nullptr, out, n_seq, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));
   return 0;
 }
+}  // namespace
 
-// Ragged variant: only the rows [seq_offsets[s], seq_offsets[s+1]) = tokens 0..EOT of each sequence are
-// computed (total_rows of them, known to the host).  Identical outputs: under the causal mask no token
-// after EOT can influence the EOT feature, and every other op of the tower is per-row.
+extern "C" int vtc_text_forward(const vtc_text_w *w, const int64_t *ids, int n_seq, float *out, void *ws, size_t ws_bytes,
+                                int dtype, void *stream_) {
+  VTC_CHECK(w && ids && out && ws, "text_forward: null argument");
+  VTC_CHECK(n_seq > 0, "text_forward: n_seq=%d", n_seq);
+  return text_forward_impl(w, TextIds{ids, nullptr, n_seq, 0}, 0, nullptr, 0, out, ws, ws_bytes, dtype, (hipStream_t)stream_, "text_forward");
+}
+
+extern "C" int vtc_text_forward2(const vtc_text_w *w, const int64_t *ids_a, int n_a, const int64_t *ids_b, int n_b, int ragged,
+                                 float *out, void *ws, size_t ws_bytes, int dtype, void *stream_) {
+  VTC_CHECK(w && ids_a && out && ws && (ids_b || n_b == 0), "text_forward2: null argument");
+  VTC_CHECK(n_a > 0 && n_b >= 0, "text_forward2: n_a=%d n_b=%d", n_a, n_b);
+  return text_forward_impl(w, TextIds{ids_a, ids_b, n_a, n_b}, ragged ? 2 : 0, nullptr, 0, out, ws, ws_bytes, dtype, (hipStream_t)stream_,
+                           "text_forward2");
+}
+
+// Ragged variant with host-known prefix sums: only the rows [seq_offsets[s], seq_offsets[s+1]) are computed (total_rows of them).
 extern "C" size_t vtc_text_ragged_workspace_bytes(const vtc_text_w *w, int n_seq, int total_rows, int dtype) {
   return plan_text(total_rows, n_seq, w->width, dtype, nullptr).total;
 }
 
 extern "C" int vtc_text_forward_ragged(const vtc_text_w *w, const int64_t *ids, int n_seq, const int *seq_offsets, int total_rows,
                                        float *out, void *ws, size_t ws_bytes, int dtype, void *stream_) {
-  hipStream_t s = (hipStream_t)stream_;
   VTC_CHECK(w && ids && seq_offsets && out && ws, "text_forward_ragged: null argument");
-  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16 || dtype == VTC_F16, "text_forward_ragged: bad dtype %d", dtype);
   VTC_CHECK(n_seq > 0 && total_rows >= n_seq && total_rows <= n_seq * w->ctx, "text_forward_ragged: n_seq=%d total_rows=%d", n_seq, total_rows);
-  VTC_CHECK(w->ctx <= 80 && w->width == w->heads * 64, "text_forward_ragged: unsupported shape");
-  const int W = w->width, rows = total_rows;
-  TextWs t = plan_text(rows, n_seq, W, dtype, ws);
-  VTC_CHECK(ws_bytes >= t.total, "text_forward_ragged: workspace too small (%zu < %zu)", ws_bytes, t.total);
-  RUN(launch_text_embed_ragged(ids, w->tok_emb, w->pos, seq_offsets, t.x, t.eot, n_seq, w->ctx, W, w->vocab, rows, s));
-  // attention work estimate for the profiler: mean-square length ~ (rows/n_seq)^2 is a lower bound; report rows*avg
-  const double avgL = (double)rows / n_seq;
-  Fold &fold = t.fold;
-  fold.on = fold_usable(w->blocks, w->layers, W, dtype, false);
-  for (int l = 0; l < w->layers; ++l) {
-    const vtc_block_w &b = w->blocks[l];
-    const int dl = layer_dtype(w, l, dtype);
-    {
-      ProfRegion region(VTC_PROF_REGION_ATTN);
-      RUN(ln_proj(fold, t.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, t.h, t.big, rows, 3 * W, W, dl, VTC_EPI_STORE, s));
-      RUN(launch_attention_ragged(t.big, t.h, n_seq, w->ctx, w->heads, 1, seq_offsets, 4.0 * avgL * rows * 64 * w->heads, dl, s));
-      RUN(resid_proj(fold, t.h, b.out_w, b.out_b, t.x, rows, W, W, dl, 0, s));
-    }
-    RUN(mlp_part(fold, b, t.x, t.h, t.big, rows, W, dl, s));
-  }
-  RUN(fold_merge_rows(fold, t.x, n_seq, W, t.eot, 1, s));
-  RUN(launch_layernorm(t.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, VTC_F32, t.eot, 1, false, s));
-  RUN(gemm(t.lnp, w->proj_t, nullptr, out, n_seq, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));
-  return 0;
+  return text_forward_impl(w, TextIds{ids, nullptr, n_seq, 0}, 1, seq_offsets, total_rows, out, ws, ws_bytes, dtype, (hipStream_t)stream_,
+                           "text_forward_ragged");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -476,7 +478,7 @@ extern "C" int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, cons
   Fold nofold;      // B (1 + nc) tokens: the LayerNorm kernels
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
-    RUN(attn_part_contig(nofold, b, t.x, t.h, t.big, B, Lc, D, w->heads, 0, dtype, s));
+    RUN(attn_part_contig(nofold, b, t.x, t.h, t.big, B, Lc, D, w->heads, 0, dtype, 0, s));
     RUN(mlp_part(nofold, b, t.x, t.h, t.big, rows, D, dtype, s));
   }
   if (!w->init_from_avg) {  // comm_res = final_linear(comm_tfm[0])   model/model.py:161

@@ -78,6 +78,11 @@ class _ReferenceNamedDataset(SyntheticPairs):
         if test:
             assert not train                                   # dataset_loaders.py:204-205
         n = int(n_pairs or os.environ.get("VTC_SYNTHETIC_PAIRS", self._default_pairs))
+        import warnings
+        warnings.warn(f"{type(self).__name__}: csv_file is empty -- {n} SYNTHETIC pairs (random pixels and tokens) of the reference's "
+                      "tensor contract stand in for the dataset; retrieval metrics on them say nothing about a real split "
+                      "(eval results carry \"synthetic\": true)", stacklevel=3)
+        self.synthetic = True
         self.train = train
         self.with_comments = _should_add_comments(add_comments, train)
         nc = int(num_comms) if self.with_comments else 0

@@ -93,6 +93,10 @@ def main(config: ConfigParser, args, checkpoint_path=None, device="cuda"):
     t_from_i, i_from_t = RecallAtK("images", "titles", [1, 5, 10]).compute_both(res_vis, res_text)
     out = {"R1_title_from_im": t_from_i[0][1], "R5_title_from_im": t_from_i[1][1], "R10_title_from_im": t_from_i[2][1],
            "R1_im_from_title": i_from_t[0][1], "R5_im_from_title": i_from_t[1][1], "R10_im_from_title": i_from_t[2][1]}
+    if getattr(dataset, "synthetic", False):
+        # beside the reference's six keys (evaluation/eval.py:131-138): the numbers are on synthetic stand-in data
+        out["synthetic"] = True
+        out["n_pairs"] = len(dataset)
     with open(save_path, "w") as f:
         json.dump(out, f)
     return out, res_vis, res_text

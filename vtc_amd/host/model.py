@@ -65,13 +65,26 @@ class PretrainedCLIPBase(nn.Module):
     # ---- packed-weight cache ---------------------------------------------------------------
     def _signature(self):
         """(storage, version) of every parameter and buffer: a changed weight re-packs.  The list of tensors itself is cached
-        (walking ~200 modules per forward cost 0.66 ms; 0.07 ms from the list) and rebuilt whenever ANY module anywhere registers
-        a parameter, buffer or submodule (global registration hooks below bump `_REG_EPOCH`): `.to()`, `load_state_dict` and
-        in-place updates keep the Parameter objects, re-assignment registers."""
-        if self.__dict__.get("_sig_epoch") != _REG_EPOCH[0]:
-            self.__dict__["_sig_list"] = list(self.parameters()) + list(self.buffers())
+        (walking ~200 modules per forward cost 0.66 ms; 0.07 ms from the list) together with WHERE each tensor is registered
+        (the owner module's `_parameters` / `_buffers` dict and its key): the list is rebuilt when any module anywhere registers
+        a parameter, buffer or submodule (global registration hooks below bump `_REG_EPOCH`) and ALSO when a registered slot no
+        longer holds the cached object -- paths that write `module._parameters[name]` directly (`.to()` under
+        torch.__future__.set_overwrite_module_params_on_conversion(True), parametrize / pruning utilities) fire no hook."""
+        ent = self.__dict__.get("_sig_list")
+        fresh = self.__dict__.get("_sig_epoch") == _REG_EPOCH[0] and ent is not None
+        if fresh:
+            for d, k, t in ent:
+                if d.get(k) is not t:
+                    fresh = False
+                    break
+        if not fresh:
+            ent = []
+            for mod in self.modules():
+                ent += [(mod._parameters, k, t) for k, t in mod._parameters.items() if t is not None]
+                ent += [(mod._buffers, k, t) for k, t in mod._buffers.items() if t is not None]
+            self.__dict__["_sig_list"] = ent
             self.__dict__["_sig_epoch"] = _REG_EPOCH[0]
-        return tuple((p.data_ptr(), p._version) for p in self.__dict__["_sig_list"]) + (self.compute_dtype, self.fuse_temporal)
+        return tuple((t.data_ptr(), t._version) for _, _, t in ent) + (self.compute_dtype, self.fuse_temporal)
 
     def _pack(self):
         sig = self._signature()
@@ -96,12 +109,13 @@ class PretrainedCLIPBase(nn.Module):
     overlap_towers = __import__("os").environ.get("VTC_OVERLAP", "1") != "0"
     _video_tower = False      # True: model.visual takes [B,F,3,H,W] (TimeSformer wrappers)
 
-    def _encode_both(self, vis, title):
-        """(visual features, title features); the two towers are independent until the CAM / similarity."""
+    def _encode_both(self, vis, title, texts_b=None):
+        """(visual features, text features); the two towers are independent until the CAM / similarity.  texts_b: a second
+        id array encoded in the same text-tower call (rows after the titles')."""
         pk = self._pack()        # ONE signature walk per forward; the towers below use the packed structs directly
         enc = pk["visual"].forward if self._video_tower else (lambda v: self._encode_vis(v, pk))
         if not self.overlap_towers or len(vis.shape) == 2:
-            return enc(vis), pk["text"].forward(title)
+            return enc(vis), pk["text"].forward(title, ids_b=texts_b)
         # The weights were packed (converted / transposed / fused) above, on the CALLER's stream, before the fork: the side stream inherits
         # the dependency through wait_stream, and the packed tensors belong to the caller stream's allocator pool.
         # (Packed lazily inside the fork, the conversions would be enqueued on the side stream only, and the text
@@ -115,7 +129,7 @@ class PretrainedCLIPBase(nn.Module):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 fv = enc(vis)
-            ft = pk["text"].forward(title)
+            ft = pk["text"].forward(title, ids_b=texts_b)
             cur.wait_stream(side)
             fv.record_stream(cur)
         return fv, ft
@@ -151,14 +165,14 @@ class PretrainedCLIPBase(nn.Module):
     def _encode_all(self, vis, title, comments):
         """Both towers for the *_finaltf wrappers.  The reference encodes the titles (model/model.py:472) and the
         comments (:210) in two text-tower calls; the sequences are independent, so here they go through ONE call
-        (1 + nc sequences per pair: bigger GEMMs, 7 launches per layer instead of 14) and are split afterwards --
-        bit-identical per sequence (tests/test_gpu_towers.py batch-independence test)."""
+        (1 + nc sequences per pair: bigger GEMMs, 7 launches per layer instead of 14; the library reads the two id arrays
+        where they lie -- no concatenated copy) and are split afterwards -- bit-identical per sequence
+        (tests/test_gpu_towers.py batch-independence test)."""
         if self.branch_to_adapt_val == "skip" or comments is None:
             fv, ft = self._encode_both(vis, title)
             return fv, ft, None
         b, ncomms, ntoks = comments.shape
-        texts = torch.cat([title, comments.reshape(b * ncomms, ntoks)], dim=0)
-        fv, ft_all = self._encode_both(vis, texts)
+        fv, ft_all = self._encode_both(vis, title, comments.reshape(b * ncomms, ntoks))
         return fv, ft_all[:b], ft_all[b:]
 
     def _encode_with_comments(self, feats_vis, feats_title, comments, feats_comm=None):
@@ -232,16 +246,16 @@ class PretrainedCLIP(PretrainedCLIPBase):
 
     def forward(self, vis, title, comments=None):
         self._check_mode(vis, title, comments)
-        feats_vis, feats_title = self._encode_both(vis, title)
         if comments is None or self.comment_fusion is None or self.comment_fusion == "None":
-            feats_text = feats_title
+            feats_vis, feats_text = self._encode_both(vis, title)
         else:
             if self.comment_fusion != "averaging":
                 raise Exception("Comment fusion method not specified.")
             b, ncomms, ntoks = comments.shape
-            feats_comm = self.encode_text(comments.reshape(b * ncomms, ntoks)).reshape(b, ncomms, self.feature_dim)
-            stacked = torch.cat([feats_title.unsqueeze(1), feats_comm], dim=1).reshape(b * (1 + ncomms), self.feature_dim)
-            feats_text = ops.mean_groups(stacked, 1 + ncomms)        # model/model.py:357-362
+            # titles and comments in ONE text-tower call (two id arrays, no concatenated copy), then the mean of a title's
+            # embedding and its comments' (model/model.py:357-362)
+            feats_vis, ft_all = self._encode_both(vis, title, comments.reshape(b * ncomms, ntoks))
+            feats_text = ops.mean_head_groups(ft_all[:b], ft_all[b:], ncomms)
         feats_text, feats_vis = normalize(feats_text), normalize(feats_vis)
         return feats_vis, feats_text, self._sim(feats_vis, feats_text)
 

@@ -42,7 +42,7 @@ def chunk_frames(frames: torch.Tensor, frame_stride: int = 16, nframes: int = 8,
     out = []
     for x in torch.split(frames, nframes, 0):
         if x.shape[0] != nframes:
-            idx = torch.floor(torch.linspace(0, x.shape[0] - 1, nframes)).to(torch.int64)
+            idx = torch.floor(torch.linspace(0, x.shape[0] - 1, nframes)).to(torch.int64).to(x.device)
             x = torch.index_select(x, 0, idx)
         out.append(x)
     chunks = torch.stack(out)

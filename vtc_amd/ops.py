@@ -174,6 +174,17 @@ def mean_groups(x: torch.Tensor, group: int) -> torch.Tensor:
 
 
 @on_device
+def mean_head_groups(a: torch.Tensor, b: torch.Tensor, group: int) -> torch.Tensor:
+    """out[g] = (a[g] + sum_k b[g * group + k]) / (1 + group)   (model/model.py:357-362)."""
+    a, b = _gpu(a, torch.float32, "a"), _gpu(b, torch.float32, "b")
+    n, d = a.shape
+    assert b.shape == (n * group, d)
+    out = torch.empty(n, d, dtype=torch.float32, device=a.device)
+    L.check(L.lib().vtc_mean_head_groups(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, group, d, _stream()), "vtc_mean_head_groups")
+    return out
+
+
+@on_device
 def segment_mean(x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     """Mean of rows [offsets[g], offsets[g+1]) per group g (int32 offsets on the GPU)."""
     x = _gpu(x, torch.float32, "x")

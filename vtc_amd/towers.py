@@ -38,8 +38,21 @@ TEXT_RAGGED = __import__("os").environ.get("VTC_TEXT_RAGGED", "1") != "0"
 # 0 = plain bf16 everywhere.
 TEXT_HALF_LAYERS = int(__import__("os").environ.get("VTC_TEXT_HALF_LAYERS", "12"))
 # 16-bit modes: pack the gamma-scaled projection weights of the folded LayerNorm next to the plain ones (include/vtc_hip.h,
-# vtc_block_w *_wf / *_s / *_c); whether a forward uses them is the library's switch (vtc_set_ln_fold / VTC_LN_FOLD).
+# vtc_block_w *_wf / *_s / *_c); whether a forward uses them is the packed model's own `flags` (VTC_TOWER_*).
 LN_FOLD_PACK = __import__("os").environ.get("VTC_LN_FOLD_PACK", "1") != "0"
+
+
+def tower_flags(ln_fold: bool = True, fused_attn: int = 0) -> int:
+    """vtc_vision_w.flags / vtc_text_w.flags: ln_fold False = the LayerNorm kernels; fused_attn bit 0 = QKV + attention core
+    in one kernel on contiguous sequences and the time branch, bit 1 = on the space branch (both bit-identical to the
+    LayerNorm-kernel path, measured slower: DESIGN.md 4.2)."""
+    return ((0 if ln_fold else L.TOWER_NO_LN_FOLD) | (L.TOWER_FUSED_ATTN if fused_attn & 1 else 0)
+            | (L.TOWER_FUSED_ATTN_SPACE if fused_attn & 2 else 0))
+
+
+# defaults of newly packed towers (env VTC_LN_FOLD=0 / VTC_FUSED_ATTN=mask: A/B runs); a packed tower's `w.flags` may be set per model
+DEFAULT_FLAGS = tower_flags(__import__("os").environ.get("VTC_LN_FOLD", "1") != "0",
+                            int(__import__("os").environ.get("VTC_FUSED_ATTN", "0")))
 _WS: Dict[tuple, torch.Tensor] = {}
 
 
@@ -53,19 +66,36 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return w
 
 
-class _Keep:
-    """Owns the converted tensors a packed struct points into."""
+def _host_sd(sd: SD, prefix: str, skip: str = ""):
+    """(the sub-dict under `prefix` with its tensors copied to the HOST, the device they lived on).  Packing -- casts,
+    transposes, the fp64 products of the fused temporal map and of the folded LayerNorm -- is format conversion done once per
+    set of weights: it runs on the CPU, and the GPU only receives the packed arrays (no torch kernel, no rocBLAS launch on
+    the card on behalf of this package)."""
+    dev = None
+    out = {}
+    for k, v in sd.items():
+        if not k.startswith(prefix) or (skip and k.startswith(skip)):
+            continue
+        if v.is_cuda and dev is None:
+            dev = v.device
+        out[k[len(prefix):]] = v.detach().cpu()
+    if dev is None:
+        raise RuntimeError("vtc_amd: weights must live on the GPU the model runs on (call .to('cuda') first); no CPU path")
+    return out, dev
 
-    def __init__(self):
+
+class _Keep:
+    """Owns the packed device arrays a struct points into; converts on the host, uploads once."""
+
+    def __init__(self, device):
+        self.device = device
         self.t: List[torch.Tensor] = []
 
     def f32(self, t: torch.Tensor) -> int:
-        t = t.detach().to(torch.float32).contiguous()
-        self.t.append(t)
-        return t.data_ptr()
+        return self.mat(t, torch.float32)
 
     def mat(self, t: torch.Tensor, dtype) -> int:
-        t = t.detach().to(dtype).contiguous()
+        t = t.detach().cpu().to(dtype).contiguous().to(self.device)
         self.t.append(t)
         return t.data_ptr()
 
@@ -129,8 +159,8 @@ def _pack_blocks(sd: SD, p: str, layers: int, dtype, keep: _Keep, timesformer: b
 
 class PackedVision:
     def __init__(self, sd: SD, prefix: str, dtype, fuse_temporal: bool = True):
-        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
-        self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep()
+        sd, dev = _host_sd(sd, prefix)
+        self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep(dev)
         k = self.keep
         conv = sd["conv1.weight"]
         w = L.VisionW()
@@ -142,6 +172,7 @@ class PackedVision:
         w.nframes = sd["temporal_embed"].shape[0] if "temporal_embed" in sd else 0
         # variant 1 = model/timesformer_clip.py (frames-major tokens, cls attends globally, no temporal_fc)
         w.variant = 1 if (w.nframes and not any("temporal_fc" in k for k in sd)) else 0
+        w.flags = DEFAULT_FLAGS
         # raw uint8 pixels: ToTensor + Normalize of CLIP_TRANSFORM (dataset_loaders/dataset_loaders.py:40-49)
         w.pix_mean = (C.c_float * 3)(0.48145466, 0.4578275, 0.40821073)
         w.pix_std = (C.c_float * 3)(0.26862954, 0.26130258, 0.27577711)
@@ -183,8 +214,8 @@ class PackedVision:
 
 class PackedText:
     def __init__(self, sd: SD, prefix: str, dtype, heads: Optional[int] = None, half_layers: Optional[int] = None):
-        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix) and not k.startswith(prefix + "visual.")}
-        self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep()
+        sd, dev = _host_sd(sd, prefix, skip=prefix + "visual.")
+        self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep(dev)
         k = self.keep
         w = L.TextW()
         w.vocab, w.width = sd["token_embedding.weight"].shape
@@ -196,38 +227,59 @@ class PackedText:
         w.ln_final_g, w.ln_final_b = k.f32(sd["ln_final.weight"]), k.f32(sd["ln_final.bias"])
         w.proj_t = k.mat(sd["text_projection"].t(), torch.float32)
         w.half_layers = min(w.layers, TEXT_HALF_LAYERS if half_layers is None else int(half_layers)) if dtype == torch.bfloat16 else 0
+        w.flags = DEFAULT_FLAGS
         self.blocks = _pack_blocks(sd, "transformer", w.layers, dtype, k, False, False, half_layers=w.half_layers,
                                    fold_ln=LN_FOLD_PACK)
         w.blocks = self.blocks
         self.w = w
 
     @ops.on_device
-    def forward(self, ids: torch.Tensor, ragged: Optional[bool] = None) -> torch.Tensor:
-        """ids [S, ctx] int64 -> [S, embed] fp32."""
+    def forward(self, ids: torch.Tensor, ragged: Optional[bool] = None, ids_b: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ids [S, ctx] int64 (+ ids_b [S2, ctx]: more sequences of the same call, e.g. titles + comments, without a
+        concatenated copy) -> [S (+ S2), embed] fp32.  One library call, no torch compute and no host sync: on the ragged
+        path the EOT positions, their prefix sums and the row count are computed on the device (vtc_text_forward2)."""
         w = self.w
         ids = ops._gpu(ids, torch.int64, "token ids")
         if ids.dim() != 2 or ids.shape[1] != w.ctx:
             raise ValueError(f"expected [S,{w.ctx}] token ids, got {tuple(ids.shape)}")
-        S = ids.shape[0]
-        out = torch.empty(S, w.embed_dim, dtype=torch.float32, device=ids.device)
+        S, Sb = ids.shape[0], 0
+        if ids_b is not None:
+            ids_b = ops._gpu(ids_b, torch.int64, "token ids (second array)")
+            if ids_b.dim() != 2 or ids_b.shape[1] != w.ctx:
+                raise ValueError(f"expected [S,{w.ctx}] token ids, got {tuple(ids_b.shape)}")
+            Sb = ids_b.shape[0]
+        out = torch.empty(S + Sb, w.embed_dim, dtype=torch.float32, device=ids.device)
         lib = L.lib()
-        if TEXT_RAGGED if ragged is None else ragged:
-            # lengths = position of the first maximum id (EOT) + 1; the prefix sum and its total are host
-            # bookkeeping (one small D2H), the tower itself runs on the packed rows
-            lens = ids.argmax(dim=-1).to(torch.int32) + 1
-            offsets = torch.zeros(S + 1, dtype=torch.int32, device=ids.device)
-            offsets[1:] = torch.cumsum(lens, 0)
-            total = int(offsets[-1].item())
-            ws = _ws(lib.vtc_text_ragged_workspace_bytes(C.byref(w), S, total, self.code), ids.device)
-            L.check(lib.vtc_text_forward_ragged(C.byref(w), ids.data_ptr(), S, offsets.data_ptr(), total, out.data_ptr(),
-                                                ws.data_ptr(), ws.numel(), self.code, ops._stream()), "vtc_text_forward_ragged")
+        rag = TEXT_RAGGED if ragged is None else ragged
+        chunk = TEXT_CHUNK if (TEXT_CHUNK > 0 and not rag and ids_b is None) else S + Sb
+        ws = _ws(lib.vtc_text_workspace_bytes(C.byref(w), min(chunk, S + Sb), self.code), ids.device)
+        if chunk >= S + Sb:
+            L.check(lib.vtc_text_forward2(C.byref(w), ids.data_ptr(), S, ids_b.data_ptr() if Sb else None, Sb, int(bool(rag)),
+                                          out.data_ptr(), ws.data_ptr(), ws.numel(), self.code, ops._stream()), "vtc_text_forward2")
             return out
-        chunk = TEXT_CHUNK if TEXT_CHUNK > 0 else S
-        ws = _ws(lib.vtc_text_workspace_bytes(C.byref(w), min(chunk, S), self.code), ids.device)
         for s0 in range(0, S, chunk):
             n = min(chunk, S - s0)
             L.check(lib.vtc_text_forward(C.byref(w), ids[s0:s0 + n].data_ptr(), n, out[s0:s0 + n].data_ptr(), ws.data_ptr(),
                                          ws.numel(), self.code, ops._stream()), "vtc_text_forward")
+        return out
+
+    @ops.on_device
+    def forward_host_offsets(self, ids: torch.Tensor) -> torch.Tensor:
+        """The ragged tower with the prefix sums computed by the HOST (vtc_text_forward_ragged: exact-size workspace and grids,
+        at the price of torch compute + one D2H sync before the launch) -- round 2's path, kept as an entry point and as the
+        cross-check of the device-side bookkeeping."""
+        w = self.w
+        ids = ops._gpu(ids, torch.int64, "token ids")
+        S = ids.shape[0]
+        out = torch.empty(S, w.embed_dim, dtype=torch.float32, device=ids.device)
+        lib = L.lib()
+        lens = ids.argmax(dim=-1).to(torch.int32) + 1
+        offsets = torch.zeros(S + 1, dtype=torch.int32, device=ids.device)
+        offsets[1:] = torch.cumsum(lens, 0)
+        total = int(offsets[-1].item())
+        ws = _ws(lib.vtc_text_ragged_workspace_bytes(C.byref(w), S, total, self.code), ids.device)
+        L.check(lib.vtc_text_forward_ragged(C.byref(w), ids.data_ptr(), S, offsets.data_ptr(), total, out.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), self.code, ops._stream()), "vtc_text_forward_ragged")
         return out
 
 
@@ -242,7 +294,9 @@ class PackedCam:
     def __init__(self, sd: SD, dtype, heads: int, init_from_avg: bool, residual_activation):
         if residual_activation not in _ACTS:
             raise ValueError(f"unknown residual_activation {residual_activation!r} (model/model.py:30-80)")
-        self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep()
+        sd, dev = _host_sd({k_: v for k_, v in sd.items() if k_.startswith(("final_transformer.", "final_linear.", "mask_embedding",
+                                                                               "mean_center_bn."))}, "")
+        self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep(dev)
         k = self.keep
         w = L.CamW()
         w.width = sd["final_linear.weight"].shape[0]

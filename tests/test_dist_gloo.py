@@ -136,3 +136,28 @@ def test_shard_bounds_cover_everything():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment must start its N ranks itself (a child
+    torch.distributed.run, 127.0.0.1 rendezvous) and relay rank 0's JSON line -- never print n_gpus: 1 for --gpus 2.  Here on
+    the CPU: gloo backend, and VTC_BENCH_RENDEZVOUS_ONLY=1 stops the ranks after the rendezvous + one all-reduce, before
+    anything needs the card."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VTC_DIST_BACKEND="gloo", VTC_BENCH_RENDEZVOUS_ONLY="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["backend"] == "gloo" and j["allreduce_check"] == 2.0
+    # a mismatch between --gpus and the launcher's world size is refused, not silently reported as the smaller job
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "refusing" in (r2.stderr + r2.stdout)

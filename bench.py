@@ -208,6 +208,15 @@ def best_of(fn, warm=2, runs=5, budget_s=40.0):
     return best, n, out
 
 
+def cgroup_throttle():
+    """(nr_throttled, throttled_usec) of this process's cgroup: CPU-bandwidth throttling stalls the launching thread"""
+    try:
+        kv = dict(ln.split() for ln in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
+    except (OSError, ValueError):
+        return 0, 0
+
+
 def cpu_baseline(device=None):
     """BASELINE.md section 4 on a bounded sample: the oracle (kind "port": plain PyTorch fp32 restatement of the reference,
     pinned by the reference-generated golden vectors) on the host cores this process may use.  With `device`, the same
@@ -437,6 +446,11 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     torch.set_grad_enabled(False)
+    # Host threads: torch sizes its intra-op pool by the cores it SEES (128 on a 1-GPU box) while the box's cgroup grants ~16;
+    # a CPU op then burns the CFS quota with spinning pool threads and the kernel throttles the whole process -- the launching
+    # thread included -- for the rest of the 100 ms period: whatever HIP call is in flight "takes" 5-90 ms.  That was the
+    # 12 ms `sweep_10000_ms` of BENCH_r02 (profiles/r03_sweep_stall_rootcause.md).  Bound the pool to the quota.
+    torch.set_num_threads(max(1, usable_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     import warnings
     warnings.filterwarnings("ignore", message=".*no pretrained weights.*")     # random-init weights are the stated workload
 
@@ -571,11 +585,15 @@ def main():
         Per repetition the max over ranks; reported = the MEDIAN, with min / max / p90 / outliers beside it (one mean over
         three repetitions let a single 30 ms stall own the number in round 2)."""
         lo, hi = vdist.shard_bounds(N, rank, world)
-        g2 = torch.Generator().manual_seed(123)
-        va = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
-        noise = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2), dim=-1)
-        tb = torch.nn.functional.normalize(va + 4.0 * noise * torch.rand(N, 1, generator=g2), dim=-1)
-        va_l, tb_l = va[lo:hi].to(device), tb[lo:hi].to(device)
+        # synthetic embeddings with planted positives, drawn ON THE GPU (same on every rank: seeded device generator); no host
+        # tensor work next to the timed region
+        g2 = torch.Generator(device=device).manual_seed(123)
+        va = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2, device=device), dim=-1)
+        noise = torch.nn.functional.normalize(torch.randn(N, 512, generator=g2, device=device), dim=-1)
+        tb = torch.nn.functional.normalize(va + 4.0 * noise * torch.rand(N, 1, generator=g2, device=device), dim=-1)
+        va_l, tb_l = va[lo:hi].contiguous(), tb[lo:hi].contiguous()
+        del va, tb, noise
+        th0 = cgroup_throttle()
         # caller-owned workspace, as a serving loop would hold it (a fresh multi-GiB allocation per call can land on a hipMalloc)
         need = vdist.sweep_workspace_bytes(N, hi - lo, 512, prec, world)
         ws = ops.workspace(need, device)
@@ -598,7 +616,9 @@ def main():
             x = torch.tensor([host_ms, gpu_ms], dtype=torch.float64, device=device)
             dist.all_reduce(x, op=dist.ReduceOp.MAX)
             host_ms, gpu_ms = x[0].tolist(), x[1].tolist()
+        th1 = cgroup_throttle()
         out = dict(host=rep_stats(host_ms), gpu=rep_stats(gpu_ms), mine=mine, r_ab=r_ab, r_ba=r_ba)
+        out["host"]["cgroup_throttled_periods"] = th1[0] - th0[0]       # host-side CFS throttling inside the timed repetitions (0 = clean)
         if profile:
             # kernel classes of one more repetition (HIP events around every launch): the distance GEMM against the rest
             pt = class_totals(prof_regions(lambda: vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec, ws=ws),

@@ -380,6 +380,75 @@ def secondary_points(m3, vid, title, comments, B, world, device, extra, k2):
                                        "what": "vtc_amd/host/retrieval_evaluation.py: ragged chunk batches + segment mean + R@K, instead of 64 batch-1 forwards"}
 
 
+def e2e_eval(m3, B, title, comments, world, device, extra):
+    """End to end through the loop of evaluation/eval.py:101-126 -- host batches in, embeddings stacked, R@1/5/10 both
+    directions out -- with the inputs where a loader leaves them: raw uint8 frames (before CLIP_TRANSFORM's ToTensor + Normalize,
+    dataset_loaders/dataset_loaders.py:40-49, which the vision tower applies itself) and int64 tokens in PINNED host memory.
+    Batch i + 1 is copied on a second stream while batch i is encoded (two device staging buffers); never part of `value`."""
+    from vtc_amd.host.metric import RecallAtK
+    Be, nb = min(B, 256), 8
+    log(f"extras: end-to-end eval loop, {nb} host batches of {Be} uint8 videos")
+    g = torch.Generator().manual_seed(77)
+    hv = [torch.randint(0, 256, (Be, 8, 3, 224, 224), dtype=torch.uint8, generator=g).pin_memory() for _ in range(2)]
+    ht, hc = title[:Be].cpu().pin_memory(), comments[:Be].cpu().pin_memory()
+    dv = [torch.empty_like(hv[0], device=device) for _ in range(2)]
+    dt_, dc = [torch.empty_like(ht, device=device) for _ in range(2)], [torch.empty_like(hc, device=device) for _ in range(2)]
+    copy = torch.cuda.Stream(device=device)
+    main = torch.cuda.current_stream(device)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    done = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(i):
+        k = i % 2
+        with torch.cuda.stream(copy):
+            copy.wait_event(done[k])                 # the forward that last read this staging buffer
+            dv[k].copy_(hv[k], non_blocking=True)
+            dt_[k].copy_(ht, non_blocking=True)
+            dc[k].copy_(hc, non_blocking=True)
+            ready[k].record(copy)
+
+    def run(overlap):
+        fv, ft = [], []
+        for k in range(2):
+            done[k].record(main)
+        upload(0)
+        for i in range(nb):
+            k = i % 2
+            if overlap and i + 1 < nb:
+                upload(i + 1)
+            main.wait_event(ready[k])
+            out = m3(dv[k], dt_[k], dc[k])
+            done[k].record(main)
+            fv.append(out[0]); ft.append(out[1])
+            if not overlap and i + 1 < nb:
+                torch.cuda.synchronize()
+                upload(i + 1)
+                torch.cuda.synchronize()
+        r = RecallAtK("videos", "titles", [1, 5, 10]).compute_both(torch.cat(fv), torch.cat(ft))
+        torch.cuda.synchronize()
+        return r
+
+    run(True)
+    res = {}
+    for name, overlap in (("overlapped", True), ("serialised", False)):
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        run(overlap)
+        d = max_over_ranks(time.perf_counter() - t0, world, device)
+        res[name + "_pairs_per_s"] = round(world * nb * Be / d, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(copy)
+    with torch.cuda.stream(copy):
+        dv[0].copy_(hv[0], non_blocking=True)
+    e1.record(copy)
+    torch.cuda.synchronize()
+    res["h2d_GBps_uint8_frames"] = round(hv[0].numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    res["what"] = (f"{nb} batches of {Be} pairs: pinned host uint8 frames [B, 8, 3, 224, 224] + int64 tokens -> H2D on a second stream -> "
+                   "forward (ToTensor + Normalize inside the vision tower) -> embeddings kept on the GPU -> R@1/5/10 both directions")
+    extra["eval_e2e_pairs_per_s"] = res["overlapped_pairs_per_s"]
+    extra["eval_e2e"] = res
+
+
 def spawn_ranks(n):
     """One process per GPU through torch.distributed.run, as the driver itself launches an N > 1 run."""
     import socket
@@ -563,6 +632,10 @@ def main():
             secondary_points(m3, vid, title, comments, B, world, device, extra, max(2, args.steps // 4))
         except Exception as e:   # noqa: BLE001
             extra["secondary_error"] = repr(e)[:300]
+        try:
+            e2e_eval(m3, B, title, comments, world, device, extra)
+        except Exception as e:   # noqa: BLE001
+            extra["eval_e2e_error"] = repr(e)[:300]
     adapter_sd = {k: v.detach().clone() for k, v in m3.state_dict().items()
                   if k.startswith("final_transformer.") or k in ("mask_embedding", "model.logit_scale")}
     del m3, vid, out

@@ -177,6 +177,10 @@ int vtc_mean_head_groups(const float *a, const float *b, float *out, int n_group
 /* out[g] = mean of rows [offsets[g], offsets[g+1]): per-video mean over a ragged number of 8-frame
  * chunks, NOT re-normalised (evaluation/retrieval_evaluation.py:254-259).  offsets: int32 [n_groups+1] */
 int vtc_segment_mean(const float *x, const int *offsets, float *out, int n_groups, int d, void *stream);
+/* flag[0] |= 1 when x[0..n) holds a non-finite value.  Range guard of the text tower's IEEE-half blocks (vtc_text_w.half_layers):
+ * an overflow of the half format (|v| > 65504) shows as inf / NaN in the tower's output.  `flag` is int32 in device memory or in
+ * pinned (device-visible) host memory, which the host can then poll without synchronising. */
+int vtc_nonfinite_flag(const float *x, size_t n, int *flag, void *stream);
 /* sim[nv,nt] = exp(*logit_scale) * v @ t^T, fp32 exact */
 int vtc_similarity(const float *v, const float *t, int nv, int nt, int d, const float *logit_scale, float *sim,
                    void *stream);

@@ -596,3 +596,56 @@ def test_config3_forward_is_free_of_host_syncs_and_torch_kernels():
     torch.cuda.synchronize()
     for x, y in zip(out, ref):
         assert torch.equal(x, y)
+
+
+def test_half_text_blocks_under_range_stress_and_overflow_fallback():
+    """the bf16 mode runs the text blocks on IEEE-half operands; half has 5 exponent bits.
+    (a) stress inside the range: an outlier channel planted in token_embedding (residual stream ~30 = 100x its usual size on that
+        channel, the 'massive activation' pattern of real checkpoints) and ln_2.weight x 30 on the first four blocks (c_fc
+        pre-activations and MLP hidden values in the hundreds to thousands) -- the embedding must stay within 1e-3 of the fp32
+        oracle, ragged and dense;
+    (b) a token whose embedding leaves the half range (1e5 > 65504): the FIRST forward after packing detects the non-finite
+        output synchronously, re-packs the blocks as bf16 and recomputes (finite, warning, `range_fallbacks`);
+    (c) the same token arriving in a LATER batch: that call returns NaN rows (nothing synchronises), the next call sees the
+        flag in pinned host memory, switches with a warning, and is finite."""
+    import warnings
+    from vtc_amd import towers
+    a = A.VIT_B32
+    sd = A.synth_text(a, 211, prefix="t.")
+    sd["t.token_embedding.weight"][:, 7] += 30.0
+    for l in range(4):
+        sd[f"t.transformer.resblocks.{l}.ln_2.weight"] *= 30.0
+    txt = A.synth_tokens(24, a, 212, empty_frac=0.2)
+    ref = unit(CR.encode_text(txt, sd, a, "t.").numpy())
+    pt = towers.PackedText(cuda_sd(sd), "t.", torch.bfloat16, heads=a.transformer_heads)
+    for ragged in (True, False):
+        got = pt.forward(txt.cuda(), ragged=ragged)
+        assert torch.isfinite(got).all() and pt.range_fallbacks == 0 and pt.w.half_layers == 12
+        report(f"half text blocks under range stress, ragged={ragged}", np.abs(unit(got.cpu().numpy()) - ref).max(), 1e-3)
+    # (b) overflow on the first forward
+    sd2 = A.synth_text(a, 213, prefix="t.")
+    sd2["t.token_embedding.weight"][777, 3] = 1.0e5
+    txt2 = A.synth_tokens(12, a, 214)
+    txt2[5, 2] = 777
+    ref2 = unit(CR.encode_text(txt2, sd2, a, "t.").numpy())
+    pt2 = towers.PackedText(cuda_sd(sd2), "t.", torch.bfloat16, heads=a.transformer_heads)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        got2 = pt2.forward(txt2.cuda())
+    assert pt2.range_fallbacks == 1 and pt2.w.half_layers == 0 and any("IEEE-half range" in str(w.message) for w in wlist)
+    assert torch.isfinite(got2).all()
+    d2 = np.abs(unit(got2.cpu().numpy()) - ref2)
+    print(f"[parity] bf16 fallback after a half overflow: max {d2.max():.3e} (rows without the outlier token: {np.delete(d2, 5, 0).max():.3e})")
+    assert np.delete(d2, 5, 0).max() < 2e-3          # all-bf16 blocks: the floor of DESIGN.md 2
+    # (c) overflow in a later batch
+    pt3 = towers.PackedText(cuda_sd(sd2), "t.", torch.bfloat16, heads=a.transformer_heads)
+    clean = A.synth_tokens(12, a, 215)
+    clean[clean == 777] = 778
+    assert torch.isfinite(pt3.forward(clean.cuda())).all() and pt3.range_fallbacks == 0
+    bad = pt3.forward(txt2.cuda())
+    torch.cuda.synchronize()
+    assert not torch.isfinite(bad[5]).all() and torch.isfinite(bad[:5]).all()      # only the sequence with the outlier token
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        again = pt3.forward(txt2.cuda())
+    assert pt3.range_fallbacks == 1 and any("earlier forward" in str(w.message) for w in wlist) and torch.isfinite(again).all()

@@ -72,6 +72,7 @@ SIGNATURES = {
     "vtc_cam_forward": (C.c_int, [C.POINTER(CamW), fp, fp, ip, C.c_int, C.c_int, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
     "vtc_normalize_rows": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),
     "vtc_mean_groups": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp]),
+    "vtc_nonfinite_flag": (C.c_int, [fp, C.c_size_t, vp, vp]),
     "vtc_mean_head_groups": (C.c_int, [fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]),
     "vtc_segment_mean": (C.c_int, [fp, ip, fp, C.c_int, C.c_int, vp]),
     "vtc_similarity": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, vp]),

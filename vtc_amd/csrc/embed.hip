@@ -34,6 +34,32 @@ __global__ __launch_bounds__(256) void im2row_u8_kernel(const unsigned char *__r
                      (u.w / 255.0f - mu) * is);
 }
 
+// raw uint8 pixels -> the same [frames, 3, res, res] tensor in the 16-bit operand format, ToTensor (/255) + per-channel Normalize
+// of CLIP_TRANSFORM (dataset_loaders/dataset_loaders.py:40-49) applied on the way: what the patch-gather GEMM (gemm.hip, EPI_PATCH
+// with `gather`) reads in place through its LDS-DMA source addressing.  16 pixels per thread: one 16-byte load, two 16-byte
+// stores (a plane is a multiple of 16 pixels, so a thread never straddles two channels).
+template <typename T>
+__global__ __launch_bounds__(256) void pixels_u8_to_operand_kernel(const unsigned char *__restrict__ px, T *__restrict__ out, size_t n16,
+                                                                   int plane16, PixNorm nrm) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n16) return;
+  const int c = (int)((idx / plane16) % 3);
+  const float mu = nrm.mean[c], is = nrm.inv_std[c];
+  const uint4 u = *reinterpret_cast<const uint4 *>(px + idx * 16);
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+  unsigned o[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = ((w[q] & 255u) / 255.0f - mu) * is, b = (((w[q] >> 8) & 255u) / 255.0f - mu) * is;
+    const float cc = (((w[q] >> 16) & 255u) / 255.0f - mu) * is, d = ((w[q] >> 24) / 255.0f - mu) * is;
+    o[2 * q] = (unsigned)cvt16<T>(a) | ((unsigned)cvt16<T>(b) << 16);
+    o[2 * q + 1] = (unsigned)cvt16<T>(cc) | ((unsigned)cvt16<T>(d) << 16);
+  }
+  uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(out) + idx * 16);
+  dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+  dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
 template <typename PixT, typename T>
 __global__ __launch_bounds__(256) void im2row_kernel(const PixT *__restrict__ px, T *__restrict__ out, int n_frames, int grid,
                                                      int patch, int res) {
@@ -337,6 +363,25 @@ int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_f
   else
     hipLaunchKernelGGL((im2row_kernel<bf16_t, float>), g, b, 0, stream, (const bf16_t *)px, (float *)out, n_frames, grid, patch, res);
   VTC_LAUNCH_CHECK("im2row");
+  return 0;
+}
+
+// uint8 pixels [n_frames, 3, res, res] -> normalised pixels in the 16-bit operand format `dtype`, same layout
+int launch_pixels_u8_to_operand(const void *px, void *out, int dtype, int n_frames, int res, const float *mean, const float *stdv,
+                                hipStream_t stream) {
+  VTC_CHECK((dtype == VTC_BF16 || dtype == VTC_F16) && (res * res) % 16 == 0 && ((uintptr_t)px & 15) == 0,
+            "pixels_u8_to_operand: dtype %d, resolution %d, pixel pointer alignment", dtype, res);
+  PixNorm nrm;
+  for (int c = 0; c < 3; ++c) { nrm.mean[c] = mean[c]; nrm.inv_std[c] = 1.0f / stdv[c]; }
+  const size_t n16 = (size_t)n_frames * 3 * res * res / 16;
+  ProfScope prof(VTC_PROF_EMBED, (double)n16 * 48, stream);
+  if (dtype == VTC_BF16)
+    hipLaunchKernelGGL((pixels_u8_to_operand_kernel<bf16_t>), dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream,
+                       (const unsigned char *)px, (bf16_t *)out, n16, res * res / 16, nrm);
+  else
+    hipLaunchKernelGGL((pixels_u8_to_operand_kernel<f16_t>), dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream,
+                       (const unsigned char *)px, (f16_t *)out, n16, res * res / 16, nrm);
+  VTC_LAUNCH_CHECK("pixels_u8_to_operand");
   return 0;
 }
 

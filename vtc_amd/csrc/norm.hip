@@ -3,6 +3,8 @@
 // group mean.  One 64-lane wave per row, float4 accesses, shuffle reductions.
 // Replaces LayerNorm (model/timesformer_clip_alt.py:22-28, upstream LayerNorm),
 // normalize (model/model.py:26-27) and the frame / title+comment means (:338, :357-362).
+#include <algorithm>
+
 #include "common.h"
 #include "ln_row.h"
 
@@ -249,6 +251,24 @@ extern "C" int vtc_normalize_rows(const float *x, float *out, int n, int d, void
   VTC_CHECK(n > 0 && d > 0, "normalize_rows: n=%d d=%d", n, d);
   hipLaunchKernelGGL(normalize_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x, out, n, d);
   VTC_LAUNCH_CHECK("normalize_rows");
+  return 0;
+}
+
+// flag[0] |= 1 when x holds a non-finite value.  `flag` may live in pinned host memory (the host then reads it without a sync).
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float *__restrict__ x, size_t n, int *flag) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned u = __float_as_uint(x[i]);
+    bad |= (u & 0x7F800000u) == 0x7F800000u;
+  }
+  if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+extern "C" int vtc_nonfinite_flag(const float *x, size_t n, int *flag, void *stream) {
+  VTC_CHECK(x && flag && n > 0, "nonfinite_flag: bad arguments");
+  const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, flag);
+  VTC_LAUNCH_CHECK("nonfinite_flag");
   return 0;
 }
 

@@ -33,6 +33,7 @@ void vtc_set_error(const char *fmt, ...) {
 extern "C" const char *vtc_last_error(void) { return g_err; }
 extern "C" int vtc_abi_version(void) { return 5; }
 int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res, const float *mean, const float *stdv, hipStream_t stream);
+int launch_pixels_u8_to_operand(const void *px, void *out, int dtype, int n_frames, int res, const float *mean, const float *stdv, hipStream_t stream);
 int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, int T, int W, hipStream_t stream);
 int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int F, int T, int W, hipStream_t stream);
 int launch_text_prep(const TextIds &ids, int n_seq, int ctx, int *lens, int *offsets, int *m_dev, hipStream_t stream);
@@ -294,6 +295,12 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
       // pixels already in the operand format: the GEMM's LDS-DMA reads the patches where they lie (no im2row matrix)
       e.gather = 1; e.grid = w->grid; e.res = res; e.patch = w->patch;
       act = pixels;
+    } else if (pixel_dtype == VTC_U8 && gemm_patch_gather_supported(n_items * F, w->grid, w->patch, res, dtype, dtype) && ((size_t)pixels & 15) == 0) {
+      // raw uint8 frames (the loader's ToTensor + Normalize, dataset_loaders/dataset_loaders.py:40-49, as the
+      // prologue of the patch GEMM): ONE pass turns them into normalised pixels in the operand format -- a quarter of the fp32
+      // H2D bytes arrived, no im2row matrix is built -- and the GEMM gathers the patches from that tensor as above
+      RUN(launch_pixels_u8_to_operand(pixels, v.big, dtype, n_items * F, res, w->pix_mean, w->pix_std, s));
+      e.gather = 1; e.grid = w->grid; e.res = res; e.patch = w->patch;
     } else {
       RUN(launch_im2row(pixels, pixel_dtype, v.big, dtype, n_items * F, w->grid, w->patch, res, w->pix_mean, w->pix_std, s));
     }

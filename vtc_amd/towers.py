@@ -214,6 +214,14 @@ class PackedVision:
 
 class PackedText:
     def __init__(self, sd: SD, prefix: str, dtype, heads: Optional[int] = None, half_layers: Optional[int] = None):
+        self._src = (sd, prefix, dtype, heads)          # references to the caller's tensors: the bf16 re-pack of the range guard
+        self._flag_dev = self._flag_host = None
+        self._calibrated = False
+        self.range_fallbacks = 0
+        self._build(half_layers)
+
+    def _build(self, half_layers):
+        sd, prefix, dtype, heads = self._src
         sd, dev = _host_sd(sd, prefix, skip=prefix + "visual.")
         self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep(dev)
         k = self.keep
@@ -232,12 +240,49 @@ class PackedText:
                                    fold_ln=LN_FOLD_PACK)
         w.blocks = self.blocks
         self.w = w
+        if w.half_layers > 0 and self._flag_dev is None:
+            self._flag_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+
+    # ---- range guard of the IEEE-half blocks ---------------------------------------------------------------------------------
+    # bf16 mode runs the text blocks on IEEE-half operands (the bf16 rounding floor of this tower is above 1e-3).
+    # Half has 5 exponent bits: a residual-stream or MLP-hidden value beyond +-65504 becomes inf and the embedding NaN.  Synthetic
+    # and typical CLIP weights stay orders of magnitude inside (tests push the stream to 1e3-1e4), but nothing in a checkpoint
+    # promises it, so: every forward ends with vtc_nonfinite_flag on the tower's output (one tiny launch) and an ASYNC copy of
+    # the flag to pinned host memory -- no sync.  The FIRST forward after packing (which synchronises anyway: the weights were
+    # just uploaded) checks the flag at once and, if set, re-packs the blocks as bf16 (more range, the same speed, a higher
+    # rounding floor) and recomputes; later forwards read the pinned flag on entry (the previous call's verdict) and do the
+    # same switch with a warning -- the overflowed call's NaN embeddings have been returned by then and say so themselves.
+    def _range_switch(self, why: str):
+        import warnings
+        warnings.warn(f"vtc_amd text tower: {why}: a value left the IEEE-half range (+-65504) in the half-operand blocks; "
+                      "re-packing the text blocks as bf16 operands (VTC_TEXT_HALF_LAYERS=0 semantics: wider range, rounding floor "
+                      "~1e-3 instead of ~1.5e-4)", RuntimeWarning, stacklevel=3)
+        self.range_fallbacks += 1
+        self._flag_dev.zero_()
+        self._flag_host.zero_()
+        self._build(0)
+
+    def _range_guard(self, out: torch.Tensor, run):
+        if self.w.half_layers <= 0 or self._flag_dev is None:
+            return out
+        L.check(L.lib().vtc_nonfinite_flag(out.data_ptr(), out.numel(), self._flag_dev.data_ptr(), ops._stream()), "vtc_nonfinite_flag")
+        if not self._calibrated:
+            self._calibrated = True
+            if int(self._flag_dev.item()) != 0:            # first call after packing: synchronous
+                self._range_switch("first forward after packing")
+                return run()
+            return out
+        self._flag_host.copy_(self._flag_dev, non_blocking=True)
+        return out
 
     @ops.on_device
     def forward(self, ids: torch.Tensor, ragged: Optional[bool] = None, ids_b: Optional[torch.Tensor] = None) -> torch.Tensor:
         """ids [S, ctx] int64 (+ ids_b [S2, ctx]: more sequences of the same call, e.g. titles + comments, without a
         concatenated copy) -> [S (+ S2), embed] fp32.  One library call, no torch compute and no host sync: on the ragged
         path the EOT positions, their prefix sums and the row count are computed on the device (vtc_text_forward2)."""
+        if self._flag_host is not None and self.w.half_layers > 0 and int(self._flag_host[0]) != 0:
+            self._range_switch("an earlier forward")       # pinned host memory: no synchronisation
         w = self.w
         ids = ops._gpu(ids, torch.int64, "token ids")
         if ids.dim() != 2 or ids.shape[1] != w.ctx:
@@ -252,16 +297,21 @@ class PackedText:
         lib = L.lib()
         rag = TEXT_RAGGED if ragged is None else ragged
         chunk = TEXT_CHUNK if (TEXT_CHUNK > 0 and not rag and ids_b is None) else S + Sb
-        ws = _ws(lib.vtc_text_workspace_bytes(C.byref(w), min(chunk, S + Sb), self.code), ids.device)
-        if chunk >= S + Sb:
-            L.check(lib.vtc_text_forward2(C.byref(w), ids.data_ptr(), S, ids_b.data_ptr() if Sb else None, Sb, int(bool(rag)),
-                                          out.data_ptr(), ws.data_ptr(), ws.numel(), self.code, ops._stream()), "vtc_text_forward2")
+
+        def run():
+            w = self.w                                     # (re-read: the range guard may have re-packed)
+            ws = _ws(lib.vtc_text_workspace_bytes(C.byref(w), min(chunk, S + Sb), self.code), ids.device)
+            if chunk >= S + Sb:
+                L.check(lib.vtc_text_forward2(C.byref(w), ids.data_ptr(), S, ids_b.data_ptr() if Sb else None, Sb, int(bool(rag)),
+                                              out.data_ptr(), ws.data_ptr(), ws.numel(), self.code, ops._stream()), "vtc_text_forward2")
+                return out
+            for s0 in range(0, S, chunk):
+                n = min(chunk, S - s0)
+                L.check(lib.vtc_text_forward(C.byref(w), ids[s0:s0 + n].data_ptr(), n, out[s0:s0 + n].data_ptr(), ws.data_ptr(),
+                                             ws.numel(), self.code, ops._stream()), "vtc_text_forward")
             return out
-        for s0 in range(0, S, chunk):
-            n = min(chunk, S - s0)
-            L.check(lib.vtc_text_forward(C.byref(w), ids[s0:s0 + n].data_ptr(), n, out[s0:s0 + n].data_ptr(), ws.data_ptr(),
-                                         ws.numel(), self.code, ops._stream()), "vtc_text_forward")
-        return out
+
+        return self._range_guard(run(), run)
 
     @ops.on_device
     def forward_host_offsets(self, ids: torch.Tensor) -> torch.Tensor:

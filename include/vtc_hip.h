@@ -121,7 +121,11 @@ typedef struct {
   const float *mask_embedding;    /* [D]                                                  */
   const vtc_block_w *blocks;      /* HOST array                                           */
   const float *bn_mean, *bn_var;  /* mean_center_bn.running_mean / running_var [D]; SUB_MEAN, BN only (else NULL) */
+  int flags;                      /* VTC_CAM_*                                            */
 } vtc_cam_w;
+/* vtc_cam_w.flags.  By default small batches (B (1 + nc) <= 512 tokens, fp32, init_from_avg) run the whole CAM -- token build,
+ * both layers, finalisation -- as ONE cooperative launch (cam.hip) instead of ~30 generic ones; same arithmetic, fp32. */
+enum { VTC_CAM_NO_FUSED = 1 };   /* always the multi-launch path */
 
 const char *vtc_last_error(void);          /* thread-local message of the last failure   */
 int vtc_abi_version(void);

@@ -649,3 +649,38 @@ def test_half_text_blocks_under_range_stress_and_overflow_fallback():
         warnings.simplefilter("always")
         again = pt3.forward(txt2.cuda())
     assert pt3.range_fallbacks == 1 and any("earlier forward" in str(w.message) for w in wlist) and torch.isfinite(again).all()
+
+
+def test_one_launch_cam_equals_the_multi_launch_path():
+    """cam.hip: small batches run the whole Context Adapter Module (model/model.py:141-214: token build with the empty-comment
+    mask, two transformer layers over the 1 + nc tokens of an item, avg-of-normalised, residual activation, final normalise) as
+    ONE cooperative launch, spread over the CUs by output columns with grid barriers between the phases.  Same fp32
+    arithmetic up to summation order as the ~30 generic launches (vtc_cam_w.flags = VTC_CAM_NO_FUSED): <= 2e-6 on unit
+    vectors, for every residual activation, trained-like (non-zero) projections, 1 / 3 / 50 / 85 items, and 2 comments instead
+    of 5; the goldens of the wrappers (wrap_03..09,14,15: B = 2..4) pin both against the reference.  Launch count: 1 (+ the
+    memset of the barrier word) against 16."""
+    from vtc_amd import _lib as L
+    from vtc_amd import towers
+    a = A.VIT_B32
+    lib = L.lib()
+    for act in (None, "normalize", "squash", "tanh"):
+        sd = A.synth_cam(a, 31)
+        for nc, sizes in ((5, (1, 3, 50, 85)), (2, (7,))):
+            for B in sizes:
+                g = torch.Generator().manual_seed(1000 + B)
+                main = torch.randn(B, 512, generator=g).cuda()
+                comm = torch.randn(B * nc, 512, generator=g).cuda()
+                comments = A.synth_tokens(B * nc, a, 5 + B, empty_frac=0.3).reshape(B, nc, -1).cuda()
+                pk = towers.PackedCam(cuda_sd(sd), torch.float32, 8, True, act)
+                n0 = lib.vtc_debug_launch_count()
+                fused = pk.forward(main, comm, comments)
+                n_fused = lib.vtc_debug_launch_count() - n0
+                pk.w.flags = L.CAM_NO_FUSED
+                n0 = lib.vtc_debug_launch_count()
+                multi = pk.forward(main, comm, comments)
+                n_multi = lib.vtc_debug_launch_count() - n0
+                d = (fused - multi).abs().max().item()
+                assert torch.isfinite(fused).all() and d < 2e-6, (act, nc, B, d)
+                assert n_fused == 1 and n_multi >= 10, (n_fused, n_multi)
+        if act is None:
+            print(f"[parity] one-launch CAM vs multi-launch, B=85: max |diff| {d:.2e}; launches {n_fused} vs {n_multi}")

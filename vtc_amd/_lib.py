@@ -22,6 +22,7 @@ PROF_REGIONS = ("other", "attn", "mlp")
 VTC_F16 = 3
 # vtc_vision_w.flags / vtc_text_w.flags (include/vtc_hip.h VTC_TOWER_*): per-model path switches
 TOWER_NO_LN_FOLD, TOWER_FUSED_ATTN, TOWER_FUSED_ATTN_SPACE = 1, 2, 4
+CAM_NO_FUSED = 1
 ABI_VERSION = 5
 
 vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
@@ -54,7 +55,7 @@ class CamW(C.Structure):
     _fields_ = [("width", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("init_from_avg", C.c_int),
                 ("residual_activation", C.c_int), ("squash_scale", C.c_float),
                 ("final_linear", C.c_void_p), ("mask_embedding", C.c_void_p), ("blocks", C.POINTER(BlockW)),
-                ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p)]
+                ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p), ("flags", C.c_int)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol include/vtc_hip.h declares

@@ -1123,6 +1123,7 @@ int run_phased(GemmParams p, hipStream_t stream) {
   return 0;
 }
 
+int g_resid_small_k = 0; // residual epilogues with K <= this take the 128 x 128 kernel (two workgroups per CU: one's epilogue under the other's K loop); 0 = heuristic only (VTC_GEMM_RESID_SMALL_K)
 int g_force_tile = 0;   // 0 = heuristic, 1 = 128x128, 2 = 256x256 free-running, 4 = 256x256 phased, 5 = 64x64 (diagnostics: VTC_GEMM_TILE)
 
 template <typename T, int MODE, typename OutT>
@@ -1134,6 +1135,9 @@ int run_cfg(const GemmParams &p, hipStream_t stream) {
     const long tb = (long)cdiv(p.M, 256) * cdiv(p.N, 256), ts = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
     const long rb = (tb + num_cus() - 1) / num_cus(), rs = (ts + 2 * num_cus() - 1) / (2 * num_cus());
     bool big = rb * 100 <= rs * 65;
+    if constexpr (MODE == VTC_EPI_RESID || MODE == EPI_RESID_FOLD || MODE == EPI_RESID_FOLD_C) {
+      if (g_resid_small_k > 0 && p.K <= g_resid_small_k) big = false;
+    }
     if (g_force_tile == 1) big = false;
     if (g_force_tile == 2) big = true;
     if (g_force_tile == 4) big = true;
@@ -1244,15 +1248,17 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
               "gemm: folded LayerNorm arguments do not go with epilogue %d", epi.mode);
   }
   // diagnostics knobs, read once (C++11 static initialisation is thread-safe; never written afterwards)
-  struct Env { int tile = 0, sg = 0, st = 0, cg = -1; };
+  struct Env { int tile = 0, sg = 0, st = 0, cg = -1, rsk = 0; };
   static const Env env = [] {
     Env v;
     if (const char *e = getenv("VTC_GEMM_TILE")) v.tile = atoi(e);
     if (const char *e = getenv("VTC_GEMM_CG")) v.cg = atoi(e);
+    if (const char *e = getenv("VTC_GEMM_RESID_SMALL_K")) v.rsk = atoi(e);
     if (const char *e = getenv("VTC_GEMM_STAGGER")) sscanf(e, "%d,%d", &v.sg, &v.st);
     return v;
   }();
   g_force_tile = env.tile;
+  g_resid_small_k = env.rsk;
   GemmParams p;
   p.A = (const char *)A; p.W = (const char *)W; p.bias = bias; p.out = out;
   p.M = M; p.N = N; p.K = K;

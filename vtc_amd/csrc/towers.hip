@@ -44,6 +44,10 @@ int launch_cam_tokens(const float *main_f, const float *comm, const int64_t *com
 int launch_cls_global_attention(const void *qkv, void *out, int n_items, int Ttok, int heads, int dtype, hipStream_t stream);
 int launch_cam_finalize(const float *Y, const float *lin, const float *main_f, float *out, int B, int Lc, int D, int init_from_avg, int act, float scale, const float *bn_mean, const float *bn_var, hipStream_t stream);
 
+bool cam_fused_supported(const vtc_cam_w *w, int B, int nc, int dtype);
+size_t cam_fused_bar_bytes();
+int launch_cam_fused(const vtc_cam_w *w, const float *main_feats, const float *comm_feats, const int64_t *comments, int ctx, int B, int nc,
+                     float *adapted, float *x, float *big, float *att, int *bar, hipStream_t stream);
 bool qkv_attention_supported(int L, int heads, int W, int dtype, size_t rows);
 int launch_qkv_attention(const void *h, const void *w_qkv, const float *b_qkv, void *out, float *cls_out, int n_seq, int L, int heads,
                          int causal, int s2, int a0, int a1, int a2, int a3, int pstride, size_t rows, int dtype, hipStream_t stream);
@@ -467,7 +471,7 @@ extern "C" int vtc_text_forward_ragged(const vtc_text_w *w, const int64_t *ids, 
 // ------------------------------------------------------------------------------------------
 extern "C" size_t vtc_cam_workspace_bytes(const vtc_cam_w *w, int B, int nc, int dtype) {
   TextWs t = plan_text(B * (1 + nc), B, w->width, dtype, nullptr);
-  return t.total + align_up((size_t)B * w->width * 4, 256);
+  return t.total + align_up((size_t)B * w->width * 4, 256) + align_up(cam_fused_bar_bytes(), 256);
 }
 
 extern "C" int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, const float *comm_feats, const int64_t *comments,
@@ -481,6 +485,10 @@ extern "C" int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, cons
   TextWs t = plan_text(rows, B, D, dtype, ws);
   float *lin = (float *)((char *)ws + t.total);
   VTC_CHECK(ws_bytes >= vtc_cam_workspace_bytes(w, B, nc, dtype), "cam_forward: workspace too small");
+  // small batches: the whole module as one cooperative launch (cam.hip)
+  if (cam_fused_supported(w, B, nc, dtype))
+    return launch_cam_fused(w, main_feats, comm_feats, comments, ctx, B, nc, adapted, t.x, (float *)t.big, (float *)t.h,
+                            (int *)((char *)ws + t.total + align_up((size_t)B * w->width * 4, 256)), s);
   RUN(launch_cam_tokens(main_feats, comm_feats, comments, w->mask_embedding, t.x, B, nc, ctx, D, s));
   Fold nofold;      // B (1 + nc) tokens: the LayerNorm kernels
   for (int l = 0; l < w->layers; ++l) {

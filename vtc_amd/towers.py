@@ -87,15 +87,28 @@ def _host_sd(sd: SD, prefix: str, skip: str = ""):
 class _Keep:
     """Owns the packed device arrays a struct points into; converts on the host, uploads once."""
 
-    def __init__(self, device):
+    def __init__(self, device, arena_bytes: int = 0):
+        """arena_bytes > 0: every packed array is carved out of ONE device allocation (256-byte aligned pieces).  The one-launch
+        CAM reads each weight matrix once per call, in 32 KB slices, with nothing to amortise an address translation over:
+        dozens of separate small allocations cost it TLB misses on every phase."""
         self.device = device
         self.t: List[torch.Tensor] = []
+        self.arena = torch.empty(arena_bytes, dtype=torch.uint8, device=device) if arena_bytes > 0 else None
+        self.used = 0
 
     def f32(self, t: torch.Tensor) -> int:
         return self.mat(t, torch.float32)
 
     def mat(self, t: torch.Tensor, dtype) -> int:
-        t = t.detach().cpu().to(dtype).contiguous().to(self.device)
+        t = t.detach().cpu().to(dtype).contiguous()
+        nbytes = t.numel() * t.element_size()
+        if self.arena is not None and self.used + nbytes <= self.arena.numel():
+            dst = self.arena[self.used:self.used + nbytes].view(dtype).view(t.shape)
+            dst.copy_(t)
+            self.used = (self.used + nbytes + 255) // 256 * 256
+            self.t.append(dst)
+            return dst.data_ptr()
+        t = t.to(self.device)
         self.t.append(t)
         return t.data_ptr()
 
@@ -115,10 +128,11 @@ def _fold_ln(keep: "_Keep", w: torch.Tensor, bias: torch.Tensor, gamma: torch.Te
 
 
 def _pack_blocks(sd: SD, p: str, layers: int, dtype, keep: _Keep, timesformer: bool, fuse_temporal: bool,
-                 half_layers: int = 0, fold_ln: bool = False):
+                 half_layers: int = 0, fold_ln: bool = False, fold_fp32: bool = False):
     arr = (L.BlockW * layers)()
     base_dtype = dtype
-    fold_ln = fold_ln and base_dtype in (torch.bfloat16, torch.float16)
+    # (fp32: the one-launch CAM folds its LayerNorms too -- cam.hip -- so that a token row streams past the weights once)
+    fold_ln = fold_ln and (base_dtype in (torch.bfloat16, torch.float16) or (fold_fp32 and base_dtype == torch.float32))
     for i in range(layers):
         q, b = f"{p}.resblocks.{i}", arr[i]
         dtype = torch.float16 if (base_dtype == torch.bfloat16 and i < half_layers) else base_dtype
@@ -346,7 +360,9 @@ class PackedCam:
             raise ValueError(f"unknown residual_activation {residual_activation!r} (model/model.py:30-80)")
         sd, dev = _host_sd({k_: v for k_, v in sd.items() if k_.startswith(("final_transformer.", "final_linear.", "mask_embedding",
                                                                                "mean_center_bn."))}, "")
-        self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep(dev)
+        # one arena for the module's weights (plain + folded copies of the projections): see _Keep
+        arena = int(2.1 * sum(v.numel() for v in sd.values()) * 4) + (1 << 20)
+        self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep(dev, arena_bytes=arena)
         k = self.keep
         w = L.CamW()
         w.width = sd["final_linear.weight"].shape[0]
@@ -358,7 +374,7 @@ class PackedCam:
         w.residual_activation, w.squash_scale = _ACTS[residual_activation]
         w.final_linear = k.mat(sd["final_linear.weight"], dtype)
         w.mask_embedding = k.f32(sd["mask_embedding"].reshape(-1))
-        self.blocks = _pack_blocks(sd, "final_transformer", w.layers, dtype, k, False, False)
+        self.blocks = _pack_blocks(sd, "final_transformer", w.layers, dtype, k, False, False, fold_ln=True, fold_fp32=True)
         w.blocks = self.blocks
         if residual_activation in ("sub_mean", "bn"):
             if "mean_center_bn.running_mean" not in sd:

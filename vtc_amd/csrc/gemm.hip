@@ -522,8 +522,24 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
               pl.x = (unsigned)cvt16<T>(y.x - up16<T>(q0)) | ((unsigned)cvt16<T>(y.y - up16<T>(q1)) << 16);
               pl.y = (unsigned)cvt16<T>(y.z - up16<T>(q2)) | ((unsigned)cvt16<T>(y.w - up16<T>(q3)) << 16);
               const size_t e = (size_t)m * ldo + ncolh + cc;
-              *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(p.epi.y16) + e) = pk;
-              *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(p.epi.y16lo) + e) = pl;
+              // cache policy of the (hi, lo) stores: the wave's next x loads sit behind them in the in-order vmcnt queue, so how
+              // soon a store is ACKNOWLEDGED sets the pace of the pass loop (0 plain, 1 nt, 2 sc1 write-through; measured: DESIGN 4.1)
+#ifndef VTC_SPLIT_ST
+#define VTC_SPLIT_ST 0
+#endif
+              uint2 *ph = reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(p.epi.y16) + e);
+              uint2 *pq = reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(p.epi.y16lo) + e);
+              if constexpr (VTC_SPLIT_ST == 1) {
+                typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+                __builtin_nontemporal_store((v2u_t){pk.x, pk.y}, reinterpret_cast<v2u_t *>(ph));
+                __builtin_nontemporal_store((v2u_t){pl.x, pl.y}, reinterpret_cast<v2u_t *>(pq));
+              } else if constexpr (VTC_SPLIT_ST == 2) {
+                asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(ph), "v"(pk) : "memory");
+                asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(pq), "v"(pl) : "memory");
+              } else {
+                *ph = pk;
+                *pq = pl;
+              }
               // (sum, sum of squared deviations from the 64-column mean): merged exactly like a two-pass variance
               // (fold_stats_kernel).  Over the 16 lanes of the row: xor 1, 2 in the quad, then half-row and row mirrors.
               float s1 = (y.x + y.y) + (y.z + y.w);

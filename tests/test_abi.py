@@ -250,3 +250,20 @@ def test_packed_weight_signature_tracks_updates_and_reassignment():
     m.model.visual._parameters["proj"] = torch.nn.Parameter(m.model.visual.proj.detach().clone())
     s4 = m._signature()
     assert s4 != s3 and m.model.visual.proj.data_ptr() in {p for p, _ in s4[:-2]}
+
+
+def test_build_refuses_probe_macros():
+    """one stray -D must not ship a diagnostic (or, formerly, a wrong-answer) library: build() refuses VTC_* macros
+    from the environment, the sources #error on the removed timing probes, and the product Makefile defines none."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, capture_output=True, text=True,
+                       env=dict(os.environ, CXXFLAGS="-DVTC_GEMM_STAMPS"))
+    assert r.returncode != 0 and "refusing to build" in r.stderr
+    src = open(os.path.join(ROOT, "vtc_amd", "csrc", "gemm.hip")).read()
+    assert "#error" in src and "VTC_PROBE_MFMA32" in src.split("#error")[0][-800:]       # named only in the guard
+    for probe in ("VTC_ABLATE_STORES", "VTC_PROBE_MFMA32", "VTC_ABLATE_DMA", "VTC_GEMM_EXP", "VTC_QKVA_SKIP"):
+        for f in ("gemm.hip", "gemm_common.h", "qkv_attn.hip"):
+            body = open(os.path.join(ROOT, "vtc_amd", "csrc", f)).read()
+            uses = [ln for ln in body.splitlines() if probe in ln and "defined(" not in ln and not ln.lstrip().startswith("//")]
+            assert not uses, (f, probe, uses[:2])

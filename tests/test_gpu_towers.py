@@ -684,3 +684,42 @@ def test_one_launch_cam_equals_the_multi_launch_path():
                 assert n_fused == 1 and n_multi >= 10, (n_fused, n_multi)
         if act is None:
             print(f"[parity] one-launch CAM vs multi-launch, B=85: max |diff| {d:.2e}; launches {n_fused} vs {n_multi}")
+
+
+def test_one_launch_cam_from_two_streams_at_once():
+    """Two cooperative CAM launches on one card at the same time would starve each other's grid barrier (a width-512 workgroup
+    takes a whole CU's LDS).  cam.hip's launcher keeps a completion event of the last one-launch CAM per device and sends a call
+    that arrives on ANOTHER stream while it may still run to the multi-launch path: interleaved calls on two streams from two
+    threads must all give the single-stream result (and none may take the seconds a starved barrier would)."""
+    import threading
+    import time
+    from vtc_amd import towers
+    a = A.VIT_B32
+    sd = A.synth_cam(a, 41)
+    B, nc = 40, 5
+    g = torch.Generator().manual_seed(9)
+    main = torch.randn(B, 512, generator=g).cuda()
+    comm = torch.randn(B * nc, 512, generator=g).cuda()
+    comments = A.synth_tokens(B * nc, a, 6, empty_frac=0.3).reshape(B, nc, -1).cuda()
+    pk = [towers.PackedCam(cuda_sd(sd), torch.float32, 8, True, None) for _ in range(2)]
+    ref = pk[0].forward(main, comm, comments).clone()
+    torch.cuda.synchronize()
+    outs = [[], []]
+
+    def work(i):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for _ in range(40):
+                outs[i].append(pk[i].forward(main, comm, comments))
+        st.synchronize()
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 5.0
+    for o in outs[0] + outs[1]:
+        assert (o - ref).abs().max().item() < 2e-6

@@ -493,10 +493,40 @@ bool cam_fused_supported(const vtc_cam_w *w, int B, int nc, int dtype) {
          w->width == w->heads * 64 && w->layers >= 1 && w->layers <= CAM_MAX_LAYERS && Lc <= 15 && B * Lc <= cam_fused_max_rows();
 }
 
-// x [rows, D], big [rows, 4 D], att [rows, D] fp32; bar: CAM_BAR_BYTES (17 words on 128-byte lines of their own)
+// Two cooperative launches on ONE device at the same time (two streams, two host threads) would split the CUs between them and
+// each would wait at its first barrier for workgroups that cannot become resident (a width-512 workgroup takes a whole CU's
+// LDS): the bounded spin would end it after seconds, with garbage.  So the launcher remembers, per device, the stream and a
+// completion event of the last one-launch CAM: same stream -> ordered behind it; another stream and the event not yet complete
+// -> this call reports "busy" and vtc_cam_forward takes the multi-launch path (same results).  No synchronisation.
+#include <mutex>
+namespace {
+struct CamInFlight { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool any = false; };
+CamInFlight g_cam_inflight[64];
+std::mutex g_cam_mu;
+}  // namespace
+// (check, launch and mark happen under one lock: see launch_cam_fused)
+static bool cam_fused_busy_locked(int dev, hipStream_t stream) {
+  CamInFlight &f = g_cam_inflight[dev];
+  if (!f.any || f.stream == stream) return false;
+  return hipEventQuery(f.done) != hipSuccess;
+}
+static void cam_fused_mark_locked(int dev, hipStream_t stream) {
+  CamInFlight &f = g_cam_inflight[dev];
+  if (!f.done && hipEventCreateWithFlags(&f.done, hipEventDisableTiming) != hipSuccess) { f.done = nullptr; f.any = false; return; }
+  f.stream = stream; f.any = true;
+  (void)hipEventRecord(f.done, stream);
+}
+
+// x [rows, D], big [rows, 4 D], att [rows, D] fp32; bar: CAM_BAR_BYTES (17 words on 128-byte lines of their own).
+// Returns 0 on success, 1 on error, -1 when another stream's one-launch CAM may still be running on this device (nothing was
+// enqueued: the caller takes the multi-launch path).
 size_t cam_fused_bar_bytes() { return CAM_BAR_BYTES; }
 int launch_cam_fused(const vtc_cam_w *w, const float *main_feats, const float *comm_feats, const int64_t *comments, int ctx, int B, int nc,
                      float *adapted, float *x, float *big, float *att, int *bar, hipStream_t stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  std::lock_guard<std::mutex> lk(g_cam_mu);
+  if (cam_fused_busy_locked(dev, stream)) return -1;
   CamFusedParams p;
   p.main_f = main_feats; p.comm = comm_feats; p.mask_emb = w->mask_embedding; p.comments = comments;
   p.B = B; p.nc = nc; p.ctx = ctx; p.Lc = 1 + nc; p.rows = B * (1 + nc); p.ntiles = cdiv(p.rows, 16); p.layers = w->layers; p.heads = w->heads;
@@ -529,6 +559,7 @@ int launch_cam_fused(const vtc_cam_w *w, const float *main_feats, const float *c
     hipLaunchKernelGGL((cam_fused_kernel<128>), dim3(grid), dim3(256), shmem, stream, p);
   }
   VTC_LAUNCH_CHECK("cam_fused");
+  cam_fused_mark_locked(dev, stream);
   if (want_stamps && stamps) {     // diagnostics: synchronises
     unsigned long long h[64];
     (void)hipStreamSynchronize(stream);

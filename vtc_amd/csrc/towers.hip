@@ -486,9 +486,11 @@ extern "C" int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, cons
   float *lin = (float *)((char *)ws + t.total);
   VTC_CHECK(ws_bytes >= vtc_cam_workspace_bytes(w, B, nc, dtype), "cam_forward: workspace too small");
   // small batches: the whole module as one cooperative launch (cam.hip)
-  if (cam_fused_supported(w, B, nc, dtype))
-    return launch_cam_fused(w, main_feats, comm_feats, comments, ctx, B, nc, adapted, t.x, (float *)t.big, (float *)t.h,
-                            (int *)((char *)ws + t.total + align_up((size_t)B * w->width * 4, 256)), s);
+  if (cam_fused_supported(w, B, nc, dtype)) {
+    const int rc = launch_cam_fused(w, main_feats, comm_feats, comments, ctx, B, nc, adapted, t.x, (float *)t.big, (float *)t.h,
+                                    (int *)((char *)ws + t.total + align_up((size_t)B * w->width * 4, 256)), s);
+    if (rc >= 0) return rc;      // -1: another stream's cooperative launch may still be running: the multi-launch path below
+  }
   RUN(launch_cam_tokens(main_feats, comm_feats, comments, w->mask_embedding, t.x, B, nc, ctx, D, s));
   Fold nofold;      // B (1 + nc) tokens: the LayerNorm kernels
   for (int l = 0; l < w->layers; ++l) {

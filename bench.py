@@ -636,6 +636,9 @@ def main():
             e2e_eval(m3, B, title, comments, world, device, extra)
         except Exception as e:   # noqa: BLE001
             extra["eval_e2e_error"] = repr(e)[:300]
+    # the ragged headline and the dense-text figure (all 77 positions: exactly the reference's work) side by side
+    if f"config3_B{B}_dense_text_pairs_per_s" in extra:
+        result["value_dense_text"] = extra[f"config3_B{B}_dense_text_pairs_per_s"]
     adapter_sd = {k: v.detach().clone() for k, v in m3.state_dict().items()
                   if k.startswith("final_transformer.") or k in ("mask_embedding", "model.logit_scale")}
     del m3, vid, out

@@ -1163,7 +1163,10 @@ int run_cfg(const GemmParams &p, hipStream_t stream) {
   // few 128x128 tiles (CAM: 1536 x 512, the output projections): 64x64 tiles, two waves, put 4x the workgroups
   // on the chip -- these launches are bounded by one tile's serial K loop, not by throughput
   const long ts128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
-  if ((ts128 * 2 <= num_cus() && g_force_tile == 0) || g_force_tile == 5) return run<T, MODE, OutT, 2, 1, 2, 4, 2>(p, stream);
+#ifndef VTC_SMALL_NSTAGE
+#define VTC_SMALL_NSTAGE 3      // LDS stages of the 64 x 64 configuration: two K-steps of LDS-DMA in flight (these launches are one tile's serial K loop: B = 1 forward 2.36 -> 1.98 ms; 2 = round 2)
+#endif
+  if ((ts128 * 2 <= num_cus() && g_force_tile == 0) || g_force_tile == 5) return run<T, MODE, OutT, 2, 1, 2, 4, VTC_SMALL_NSTAGE>(p, stream);
   return run<T, MODE, OutT, 2, 2, 4, 4, 2>(p, stream);
 }
 

@@ -295,11 +295,14 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
     e.mode = EPI_PATCH; e.out_dtype = VTC_F32; e.pos = w->pos; e.temporal = tsf ? w->temporal : nullptr;
     e.P = P; e.F = F; e.T = T; e.ldo = W; e.frames_major = w->variant == 1;
     const void *act = v.big;
-    if (gemm_patch_gather_supported(n_items * F, w->grid, w->patch, res, pixel_dtype, dtype) && ((size_t)pixels & 15) == 0) {
+    // (few patches: the gather only exists on the 256 x 256 phased kernel, whose single tile would walk K = 3 072 alone -- 113 us
+    // at B <= 8 videos; the im2row matrix + 64 x 64 / 128 x 128 tiles take 30-60 us there)
+    const bool few = (long)n_items * F * P < 4096;
+    if (!few && gemm_patch_gather_supported(n_items * F, w->grid, w->patch, res, pixel_dtype, dtype) && ((size_t)pixels & 15) == 0) {
       // pixels already in the operand format: the GEMM's LDS-DMA reads the patches where they lie (no im2row matrix)
       e.gather = 1; e.grid = w->grid; e.res = res; e.patch = w->patch;
       act = pixels;
-    } else if (pixel_dtype == VTC_U8 && gemm_patch_gather_supported(n_items * F, w->grid, w->patch, res, dtype, dtype) && ((size_t)pixels & 15) == 0) {
+    } else if (!few && pixel_dtype == VTC_U8 && gemm_patch_gather_supported(n_items * F, w->grid, w->patch, res, dtype, dtype) && ((size_t)pixels & 15) == 0) {
       // raw uint8 frames (the loader's ToTensor + Normalize, dataset_loaders/dataset_loaders.py:40-49, as the
       // prologue of the patch GEMM): ONE pass turns them into normalised pixels in the operand format -- a quarter of the fp32
       // H2D bytes arrived, no im2row matrix is built -- and the GEMM gathers the patches from that tensor as above

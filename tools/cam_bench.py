@@ -3,18 +3,25 @@ usage: python tools/cam_bench.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import arch as A
+import warnings
+warnings.filterwarnings("ignore")
 from vtc_amd import _lib as L, towers
+from vtc_amd.host import model as HM
+from vtc_amd.host.datasets import synth_tokens
 torch.set_grad_enabled(False)
-a = A.VIT_B32
-sd = A.synth_cam(a, 3)
+torch.manual_seed(3)
+m = HM.PretrainedCLIP_finaltf(model_type="ViT-B/32", branch_to_adapt_val="text")
+for blk in m.final_transformer.resblocks:       # trained-like (non-zero) projections
+    torch.nn.init.normal_(blk.attn.out_proj.weight, std=0.02)
+    torch.nn.init.normal_(blk.mlp.c_proj.weight, std=0.02)
+sd = {k: v.detach() for k, v in m.state_dict().items() if k.startswith(("final_transformer.", "final_linear.", "mask_embedding"))}
 pk = towers.PackedCam({k: v.cuda() for k, v in sd.items()}, torch.float32, 8, True, None)
 lib = L.lib()
 for B in (1, 8, 50, 128, 256, 1024):
     g = torch.Generator().manual_seed(B)
     main = torch.randn(B, 512, generator=g).cuda()
     comm = torch.randn(B * 5, 512, generator=g).cuda()
-    comments = A.synth_tokens(B * 5, a, 5, empty_frac=0.2).reshape(B, 5, -1).cuda()
+    comments = synth_tokens(B * 5, 77, g, empty_frac=0.2).reshape(B, 5, -1).cuda()
     for _ in range(5):
         out = pk.forward(main, comm, comments)
     torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 """Fused QKV+attention kernel vs QKV GEMM + attention kernel, per attention-branch shape (one process, interleaved).
-usage: python tools/qkva_bench.py [B]      env VTC_QKVA_SKIP=bits ablates phases of the fused kernel (timing only)"""
+usage: python tools/qkva_bench.py [B]      (the VTC_QKVA_SKIP phase ablations of round 2 are gone from the kernel: round 3 removed the wrong-answer knobs)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -4,16 +4,17 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench as BN
-from oracle import arch as A
+import warnings
+warnings.filterwarnings("ignore")
 from vtc_amd import towers
+from vtc_amd.host import model as HM
 torch.set_grad_enabled(False)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-a = A.VIT_B32
-sd = A.synth_visual(a, 65, nframes=8, prefix="v.")
-g = torch.Generator().manual_seed(1)
-for k in list(sd):
-    if k.endswith("temporal_fc.weight"):
-        sd[k] = torch.randn(sd[k].shape, generator=g) * 0.02
+torch.manual_seed(65)
+m = HM.PretrainedCLIP_TimeSformer(model_type="ViT-B/32")
+for blk in m.model.visual.transformer.resblocks:       # trained weights are not the init's zeros
+    torch.nn.init.normal_(blk.temporal_fc.weight, std=0.02)
+sd = {"v." + k[len("model.visual."):]: v.detach() for k, v in m.state_dict().items() if k.startswith("model.visual.")}
 pv = towers.PackedVision({k: v.cuda() for k, v in sd.items()}, "v.", torch.bfloat16)
 vid = torch.randn(B, 8, 3, 224, 224, device="cuda").bfloat16()
 for _ in range(2):

@@ -336,6 +336,7 @@ def secondary_points(m3, vid, title, comments, B, world, device, extra, k2):
       * the batch-1 loop of evaluation/retrieval_evaluation.py:136,174-233 (one video = one 8-frame chunk + caption + 5 comments
         per forward) and the same videos through the ragged-chunk path (vtc_amd/host/retrieval_evaluation.py);
     each with the library's kernel launches per forward (at small batch the launch count is the cost)."""
+    from vtc_amd import _lib as L
     from vtc_amd import towers as TW
     from vtc_amd.host import retrieval_evaluation as RE
     was_ragged, was_half = TW.TEXT_RAGGED, TW.TEXT_HALF_LAYERS
@@ -352,6 +353,17 @@ def secondary_points(m3, vid, title, comments, B, world, device, extra, k2):
         extra[f"config3_B{B}_text_bf16_blocks_pairs_per_s"] = round(world * B / d, 1)
     finally:
         TW.TEXT_RAGGED, TW.TEXT_HALF_LAYERS = was_ragged, was_half
+        m3._packed = {}
+    # every row of the last block computed, as the reference does (default: its out_proj + MLP on the rows that reach the output)
+    log("extras: full last block (VTC_TOWER_FULL_LAST_LAYER)")
+    was_flags = TW.DEFAULT_FLAGS
+    try:
+        TW.DEFAULT_FLAGS = was_flags | L.TOWER_FULL_LAST_LAYER
+        m3._packed = {}
+        d = timed(lambda: m3(vid, title, comments), k2, world, device, warm=1)
+        extra[f"config3_B{B}_full_last_block_pairs_per_s"] = round(world * B / d, 1)
+    finally:
+        TW.DEFAULT_FLAGS = was_flags
         m3._packed = {}
     for b in (50, 1):
         v, t, c = vid[:b].contiguous(), title[:b].contiguous(), comments[:b].contiguous()
@@ -588,8 +600,16 @@ def main():
     tot = class_totals(p_all)
     g = tot[gk]
     achieved = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-    # the video tower alone: its ATTN region = the time + space attention branches
-    pv = prof_regions(lambda: m3._pack()["visual"].forward(vid), stream_ptr)
+    # the video tower alone: its ATTN region = the time + space attention branches.  Measured with EVERY row of the last block
+    # computed (VTC_TOWER_FULL_LAST_LAYER), so that the time covers exactly the work the algorithmic count below prices
+    pk_v = m3._pack()["visual"]
+    was_v = pk_v.w.flags
+    pk_v.w.flags = was_v | L.TOWER_FULL_LAST_LAYER
+    try:
+        pk_v.forward(vid)
+        pv = prof_regions(lambda: pk_v.forward(vid), stream_ptr)
+    finally:
+        pk_v.w.flags = was_v
     m3.overlap_towers = type(m3).overlap_towers
     attn_ms = sum(v["attn"]["ms"] for v in pv.values())
     attn_launches = sum(v["attn"]["launches"] for v in pv.values())
@@ -614,11 +634,15 @@ def main():
                    "pairs_per_gpu": B, "frames": 8,
                    "text_tower": ("ragged: tokens after EOT are not computed, identical outputs" if TW.TEXT_RAGGED else "dense: all 77 positions"),
                    "text_tokens_computed_frac": round(n_tok / (6 * B * 77), 4) if TW.TEXT_RAGGED else 1.0,
+                   "last_block": ("out_proj + MLP of each tower's LAST block on the rows that reach the output only (x[:, 0] / the EOT row; the other rows "
+                                  "of that block are read by nothing) -- identical embeddings; extra.config3_B*_full_last_block_pairs_per_s computes them anyway"
+                                  if not (TW.DEFAULT_FLAGS & L.TOWER_FULL_LAST_LAYER) else "every row"),
                    "parallelism": f"dp{world} (one process per GPU, no collective in the encode path)"},
         "roofline": roofline,
         "timesformer_attention_mfma_frac": round(attn_frac, 4),
         "timesformer_attention": {"ms_per_step": round(attn_ms, 3), "launches": attn_launches,
                                   "algorithmic_gflop_per_layer_video": TSF_ATTN_GFLOP_PER_LAYER_VIDEO,
+                                  "measured_on": "the video tower with every row of the last block computed (VTC_TOWER_FULL_LAST_LAYER)",
                                   "tflops": round(attn_flop / (attn_ms * 1e-3) / 1e12, 1) if attn_ms > 0 else 0.0},
         "kernel_ms_per_step": {k: round(v["ms"] / n_prof, 3) for k, v in tot.items() if v["launches"]},
         "region_ms_per_step": {r: round(sum(v[r]["ms"] for v in p_all.values()) / n_prof, 3) for r in L.PROF_REGIONS},

@@ -485,6 +485,59 @@ def test_folded_layernorm_and_layernorm_kernels_agree_with_the_oracle():
         assert 0 < d < 1e-3, (name, d)          # two rounding regimes of the same tower: different bits, same embedding
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_last_block_on_the_output_rows_only_equals_the_full_last_block(dtype):
+    """Behind the last block a tower reads one row per item (x[:, 0] -> ln_post, model/timesformer_clip_alt.py:281,
+    model/timesformer_clip.py:433; the EOT row -> ln_final), so that block's out_proj + MLP run on those rows only by default
+    (towers.hip last_block_tail).  VTC_TOWER_FULL_LAST_LAYER computes every row as the reference does: same embeddings -- fp32
+    to summation order, bf16 within the tolerance both hold against the oracle -- for the alt / v1 video towers, the image tower
+    and the ragged, dense and two-array text tower; folded and LayerNorm-kernel paths; odd batch sizes."""
+    from vtc_amd import towers
+    a = A.VIT_B32
+    sd_alt = A.synth_visual(a, 201, nframes=8, prefix="v.")
+    sd_v1 = A.synth_visual(a, 203, nframes=8, prefix="v.", variant="v1")
+    sd_img = A.synth_visual(a, 204, prefix="v.")
+    sd_txt = A.synth_text(a, 205, prefix="t.")
+    vid = A.synth_pixels((3, 8, 3, 224, 224), 206)
+    img = A.synth_pixels((5, 3, 224, 224), 207)
+    txt = A.synth_tokens(7, a, 208, empty_frac=0.2)
+    refs = {
+        "alt": T.timesformer_alt(vid, sd_alt, a, "v.").numpy(),
+        "v1": T.timesformer_v1(vid, sd_v1, a, "v.").numpy(),
+        "img": CR.encode_image(img, sd_img, a, "v.").numpy(),
+        "txt": CR.encode_text(txt, sd_txt, a, "t.").numpy(),
+    }
+    packed = {
+        "alt": (towers.PackedVision(cuda_sd(sd_alt), "v.", dtype), vid),
+        "v1": (towers.PackedVision(cuda_sd(sd_v1), "v.", dtype), vid),
+        "img": (towers.PackedVision(cuda_sd(sd_img), "v.", dtype), img),
+        "txt": (towers.PackedText(cuda_sd(sd_txt), "t.", dtype, heads=a.transformer_heads), txt),
+    }
+    tol = tol_for(dtype)
+    from vtc_amd import _lib as L
+    lib = L.lib()
+    for fold in ((1, 0) if dtype == torch.bfloat16 else (1,)):
+        outs, launches = {}, {}
+        for full in (0, 1):
+            for name, (pk, x) in packed.items():
+                pk.w.flags = towers.tower_flags(ln_fold=bool(fold), full_last_layer=bool(full))
+                n0 = lib.vtc_debug_launch_count()
+                outs[(name, full)] = pk.forward(x.cuda()).cpu().numpy()
+                launches[(name, full)] = lib.vtc_debug_launch_count() - n0
+                if name == "txt":
+                    outs[("txt_dense", full)] = pk.forward(x.cuda(), ragged=False).cpu().numpy()
+                    both = pk.forward(x[:4].cuda(), ids_b=x[4:].cuda()).cpu().numpy()
+                    outs[("txt_two", full)] = both
+        for (name, full), got in outs.items():
+            report(f"{name} fold={fold} full_last={full} vs oracle", np.abs(unit(got) - unit(refs[name.split('_')[0]])).max(), tol)
+        for name in ("alt", "v1", "img", "txt", "txt_dense", "txt_two"):
+            d = np.abs(unit(outs[(name, 0)]) - unit(outs[(name, 1)])).max()
+            print(f"[parity] {name} fold={fold}: output rows only vs full last block {d:.3e}")
+            assert d < (2e-6 if dtype == torch.float32 else tol), (name, fold, d)
+        for pk, _ in packed.values():
+            pk.w.flags = towers.DEFAULT_FLAGS
+
+
 def test_folded_layernorm_is_insensitive_to_a_row_mean():
     """The folded LayerNorm rounds x itself (not LN(x)) to the operand format, so a row mean large against the row's spread
     would cost precision -- the (hi, lo) stream is therefore stored centred (every reader is a LayerNorm: a per-row constant

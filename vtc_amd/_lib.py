@@ -21,7 +21,7 @@ PROF_CLASSES = ("gemm_bf16", "gemm_f32", "attention", "norm", "embed", "topk")
 PROF_REGIONS = ("other", "attn", "mlp")
 VTC_F16 = 3
 # vtc_vision_w.flags / vtc_text_w.flags (include/vtc_hip.h VTC_TOWER_*): per-model path switches
-TOWER_NO_LN_FOLD, TOWER_FUSED_ATTN, TOWER_FUSED_ATTN_SPACE = 1, 2, 4
+TOWER_NO_LN_FOLD, TOWER_FUSED_ATTN, TOWER_FUSED_ATTN_SPACE, TOWER_FULL_LAST_LAYER = 1, 2, 4, 8
 CAM_NO_FUSED = 1
 ABI_VERSION = 5
 

@@ -230,6 +230,8 @@ int launch_layernorm(const float *x, const float *g, const float *b, void *y, in
 int launch_fold_stats(const float *part, int nb, int rows, float *stat, hipStream_t stream, const int *rows_dev = nullptr);
 int launch_cast_rowstats(const float *x, void *y16, void *y16lo, float *stat, int rows, int width, int dtype, hipStream_t stream,
                          const int *rows_dev = nullptr);
+// dst[i] = src row (row_index[i], or i * row_mul): rows of row_bytes (a multiple of 16) bytes
+int launch_gather_rows(const void *src, void *dst, int n, int row_bytes, const int *row_index, int row_mul, hipStream_t stream);
 int launch_split_merge_rows(const void *hi, const void *lo, float *x, int n, int width, const int *row_index, int row_mul, int dtype,
                             hipStream_t stream, const int *rows_dev = nullptr);
 // token ids of a text-tower call: sequences [0, n_a) are rows of `a`, [n_a, n_a + n_b) rows of `b` (titles + comments without a

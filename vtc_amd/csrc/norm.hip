@@ -136,6 +136,17 @@ __global__ __launch_bounds__(256) void split_merge_rows_kernel(const T *__restri
   }
 }
 
+// dst[i] = src row (row_index[i] or i * row_mul): the compact copy of the rows that reach a tower's output (towers.hip, last block)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char *__restrict__ src, char *__restrict__ dst, int n, int row_bytes,
+                                                          const int *__restrict__ row_index, int row_mul) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const size_t r = row_index ? (size_t)row_index[i] : (size_t)i * row_mul;
+  for (int c = lane * 16; c < row_bytes; c += 1024)
+    *reinterpret_cast<uint4 *>(dst + (size_t)i * row_bytes + c) = *reinterpret_cast<const uint4 *>(src + r * row_bytes + c);
+}
+
 __global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict__ x, float *__restrict__ out, int n, int d) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -227,6 +238,14 @@ int launch_cast_rowstats(const float *x, void *y16, void *y16lo, float *stat, in
   else
     hipLaunchKernelGGL((cast_rowstats_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, (bf16_t *)y16, (bf16_t *)y16lo, (float2 *)stat, rows, width, rows_dev);
   VTC_LAUNCH_CHECK("cast_rowstats");
+  return 0;
+}
+
+int launch_gather_rows(const void *src, void *dst, int n, int row_bytes, const int *row_index, int row_mul, hipStream_t stream) {
+  VTC_CHECK(n > 0 && row_bytes > 0 && row_bytes % 16 == 0, "gather_rows: n=%d row_bytes=%d", n, row_bytes);
+  ProfScope prof(VTC_PROF_NORM, (double)n * row_bytes * 2, stream);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, stream, (const char *)src, (char *)dst, n, row_bytes, row_index, row_mul);
+  VTC_LAUNCH_CHECK("gather_rows");
   return 0;
 }
 

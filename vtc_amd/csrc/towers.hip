@@ -180,20 +180,60 @@ int mlp_part(Fold &f, const vtc_block_w &b, float *x, void *h, void *big, const 
 }
 
 // x += MHA(ln_1 x) over n_seq contiguous sequences of L tokens
+// (tail_src: stop behind the attention core and say where its output lies -- the last block, whose out_proj runs on the output
+// rows only: last_block_tail)
 int attn_part_contig(Fold &f, const vtc_block_w &b, float *x, void *h, void *big, int n_seq, int L, int W, int heads, int causal,
-                     int dtype, int flags, hipStream_t s) {
+                     int dtype, int flags, hipStream_t s, const void **tail_src = nullptr) {
   const int rows = n_seq * L;
   ProfRegion region(VTC_PROF_REGION_ATTN);
   if (!f.on && fused_attn_enabled(flags) && qkv_attention_supported(L, heads, W, dtype, (size_t)rows)) {
     RUN(launch_layernorm(x, b.ln1_g, b.ln1_b, h, rows, W, dtype, nullptr, 1, false, s));
     RUN(launch_qkv_attention(h, b.qkv_w, b.qkv_b, big, nullptr, n_seq, L, heads, causal, 1, 0, L, 0, 0, 1, (size_t)rows, dtype, s));
+    if (tail_src) { *tail_src = big; return 0; }
     RUN(gemm(big, b.out_w, b.out_b, x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
     return 0;
   }
   RUN(ln_proj(f, x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, h, big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));
   RUN(launch_attention(big, h, nullptr, n_seq, L, heads, causal, 1, 0, L, 0, 0, 1, dtype, s));
+  if (tail_src) { *tail_src = h; return 0; }
   RUN(resid_proj(f, h, b.out_w, b.out_b, x, rows, W, W, dtype, 0, s));
   return 0;
+}
+
+// ---- the last block: only the rows that reach the output --------------------------------------------------------------------
+// Behind the last block a tower reads ONE row per item (x[:, 0] into ln_post, model/timesformer_clip_alt.py:281 and
+// model/timesformer_clip.py:433; the EOT row into ln_final, upstream CLIP encode_text).  That block's attention still needs K and V
+// of every row, but its out_proj, its residual update and its whole MLP are per-row maps: on any other row they produce values
+// nothing ever reads.  So after the last attention core the n output rows are gathered into a compact fp32 stream and
+// out_proj / ln_2 / c_fc / QuickGELU / c_proj run on those n rows only (LayerNorm kernels, the reference's own order of
+// operations).  Exact, not an approximation: every value that can influence an embedding is computed as before.
+// flags & VTC_TOWER_FULL_LAST_LAYER computes the dead rows anyway.
+struct Tail {
+  float *x = nullptr;      // [n, W] fp32: the output rows of the residual stream
+  void *a = nullptr;       // [n, W] operand format: their attention outputs
+  void *h = nullptr;       // [n, W] operand format: LayerNorm output
+  void *big = nullptr;     // [n, 4 W] operand format: c_fc output
+};
+void plan_tail(Bump &b, Tail &t, int n, int W) {      // sized for fp32 operands (the largest format)
+  t.x = (float *)b.take((size_t)n * W * 4);
+  t.a = b.take((size_t)n * W * 4);
+  t.h = b.take((size_t)n * W * 4);
+  t.big = b.take((size_t)n * 4 * W * 4);
+}
+inline bool prune_last(int flags) { return (flags & VTC_TOWER_FULL_LAST_LAYER) == 0; }
+// attn_out: [rows, W] operand format, the attention core's output (cls rows already averaged over frames for the TimeSformer);
+// the output row of item i is row_index[i] (or i * row_mul) of the stream
+int last_block_tail(Fold &f, const vtc_block_w &b, float *x, const void *attn_out, Tail &t, int n, int W, const int *row_index, int row_mul,
+                    int dtype, hipStream_t s) {
+  {
+    ProfRegion region(VTC_PROF_REGION_ATTN);
+    RUN(fold_merge_rows(f, x, n, W, row_index, row_mul, s));      // (hi, lo) -> fp32, those rows only
+    RUN(launch_gather_rows(x, t.x, n, W * 4, row_index, row_mul, s));
+    RUN(launch_gather_rows(attn_out, t.a, n, W * esz(dtype), row_index, row_mul, s));
+    RUN(gemm(t.a, b.out_w, b.out_b, t.x, n, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+  }
+  Fold nofold;
+  return mlp_part(nofold, b, t.x, t.h, t.big, Rows(n), W, dtype, s);
 }
 
 // operand format of text block l: with dtype == VTC_BF16 the first half_layers blocks run on IEEE half
@@ -205,6 +245,7 @@ struct VisionWs {
   float *x, *cls_tmp;
   void *h, *big, *lnp;
   Fold fold;
+  Tail tail;
   size_t total;
 };
 
@@ -228,6 +269,7 @@ VisionWs plan_vision(const vtc_vision_w *w, int n_items, int F, int dtype, void 
     v.fold.part = (float *)b.take((size_t)(W / 64 + 1) * rows * 8);
     v.fold.stat = (float *)b.take(rows * 8);
   }
+  plan_tail(b, v.tail, n_items, W);
   v.total = b.off;
   return v;
 }
@@ -238,6 +280,7 @@ struct TextWs {
   int *eot;
   int *lens, *offs, *mdev;     // vtc_text_forward2, ragged: per-sequence lengths, their prefix sums, (rows, rows padded to 256)
   Fold fold;
+  Tail tail;
   size_t total;
 };
 
@@ -260,6 +303,7 @@ TextWs plan_text(int rows_, int n_seq, int W, int dtype, void *ws) {
     t.fold.part = (float *)b.take((size_t)(W / 64 + 1) * rows * 8);
     t.fold.stat = (float *)b.take(rows * 8);
   }
+  plan_tail(b, t.tail, n_seq, W);
   t.total = b.off;
   return t;
 }
@@ -318,8 +362,11 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
 
   Fold &fold = v.fold;
   fold.on = fold_usable(w->blocks, w->layers, W, dtype, tsf, w->flags);
+  const bool prune = prune_last(w->flags);
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
+    const bool tail = prune && l == w->layers - 1;      // out_proj + MLP of the last block: the cls rows only (last_block_tail)
+    const void *tail_src = v.h;                         // where the last attention core's output lies
     {
     ProfRegion region(VTC_PROF_REGION_ATTN);   // time + space branches: what BASELINE.md calls "TimeSformer attention"
     if (tsf && w->variant == 1) {
@@ -335,7 +382,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
       RUN(ln_proj(fold, v.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, v.h, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));
       RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, P, 1, dtype, s));
       RUN(launch_cls_global_attention(v.big, v.h, n_items, T, w->heads, dtype, s));
-      RUN(resid_proj(fold, v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, 0, s));
+      if (!tail) RUN(resid_proj(fold, v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, 0, s));
     } else if (tsf && fused_attn_enabled(w->flags) && qkv_attention_supported(1 + P, w->heads, W, dtype, (size_t)rows)) {
       // Same two branches with QKV + attention core in one kernel each (qkv_attn.hip): the attention output lands in
       // `big` (as [rows, W]); the packed qkv matrix never exists.
@@ -351,12 +398,13 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
       if (w->flags & VTC_TOWER_FUSED_ATTN_SPACE) {
         RUN(launch_qkv_attention(v.h, b.qkv_w, b.qkv_b, v.big, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, 1, F, (size_t)rows, dtype, s));
         RUN(launch_cls_mean(v.cls_tmp, v.big, dtype, n_items, F, T, W, s));
-        RUN(gemm(v.big, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+        tail_src = v.big;
+        if (!tail) RUN(gemm(v.big, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
       } else {
         RUN(gemm(v.h, b.qkv_w, b.qkv_b, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
         RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, 1, F, dtype, s));
         RUN(launch_cls_mean(v.cls_tmp, v.h, dtype, n_items, F, T, W, s));
-        RUN(gemm(v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+        if (!tail) RUN(gemm(v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
       }
     } else if (tsf) {
       // temporal branch (timesformer_clip_alt.py:142-149): sequences = the F frames of one (item, patch)
@@ -372,17 +420,22 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
       RUN(ln_proj(fold, v.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, v.h, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));
       RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, 1, F, dtype, s));
       RUN(launch_cls_mean(v.cls_tmp, v.h, dtype, n_items, F, T, W, s));
-      RUN(resid_proj(fold, v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, 0, s));
+      if (!tail) RUN(resid_proj(fold, v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, 0, s));
     } else {
-      RUN(attn_part_contig(fold, b, v.x, v.h, v.big, n_items, T, W, w->heads, 0, dtype, w->flags, s));
+      RUN(attn_part_contig(fold, b, v.x, v.h, v.big, n_items, T, W, w->heads, 0, dtype, w->flags, s, tail ? &tail_src : nullptr));
     }
     }
-    RUN(mlp_part(fold, b, v.x, v.h, v.big, rows, W, dtype, s));
+    if (tail) RUN(last_block_tail(fold, b, v.x, tail_src, v.tail, n_items, W, nullptr, T, dtype, s));
+    else RUN(mlp_part(fold, b, v.x, v.h, v.big, rows, W, dtype, s));
   }
   // ln_post(x[:,0]) @ proj -- always fp32 (n_items rows only): the embedding the sweep ranks on
   // does not pick up a last bf16 rounding
-  RUN(fold_merge_rows(fold, v.x, n_items, W, nullptr, T, s));
-  RUN(launch_layernorm(v.x, w->ln_post_g, w->ln_post_b, v.lnp, n_items, W, VTC_F32, nullptr, T, false, s));
+  if (prune && w->layers > 0) {
+    RUN(launch_layernorm(v.tail.x, w->ln_post_g, w->ln_post_b, v.lnp, n_items, W, VTC_F32, nullptr, 1, false, s));
+  } else {
+    RUN(fold_merge_rows(fold, v.x, n_items, W, nullptr, T, s));
+    RUN(launch_layernorm(v.x, w->ln_post_g, w->ln_post_b, v.lnp, n_items, W, VTC_F32, nullptr, T, false, s));
+  }
   RUN(gemm(v.lnp, w->proj_t, nullptr, out, n_items, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));
   return 0;
 }
@@ -421,23 +474,31 @@ int text_forward_impl(const vtc_text_w *w, const TextIds &ids, int mode, const i
   fold.on = fold_usable(w->blocks, w->layers, W, dtype, false, w->flags);
   // attention work of the ragged batch for the profiler (the lengths are not known here): rows x (mean length ~ ctx / 2)
   const double attn_flops_per_row = 4.0 * (0.5 * w->ctx) * 64 * w->heads;
+  const bool prune = prune_last(w->flags);
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
     const int dl = layer_dtype(w, l, dtype);
+    const bool tail = prune && l == w->layers - 1;      // out_proj + MLP of the last block: the EOT rows only (last_block_tail)
+    const void *tail_src = t.h;
     if (mode == 0) {
-      RUN(attn_part_contig(fold, b, t.x, t.h, t.big, n_seq, w->ctx, W, w->heads, 1, dl, w->flags, s));
+      RUN(attn_part_contig(fold, b, t.x, t.h, t.big, n_seq, w->ctx, W, w->heads, 1, dl, w->flags, s, tail ? &tail_src : nullptr));
     } else {
       ProfRegion region(VTC_PROF_REGION_ATTN);
       RUN(ln_proj(fold, t.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, t.h, t.big, rows, 3 * W, W, dl, VTC_EPI_STORE, s));
       RUN(launch_attention_ragged(t.big, t.h, n_seq, w->ctx, w->heads, 1, offs, attn_flops_per_row * (rows.dev ? 1.0 : rows.n), rows.dev, dl, s));
-      RUN(resid_proj(fold, t.h, b.out_w, b.out_b, t.x, rows, W, W, dl, 0, s));
+      if (!tail) RUN(resid_proj(fold, t.h, b.out_w, b.out_b, t.x, rows, W, W, dl, 0, s));
     }
-    RUN(mlp_part(fold, b, t.x, t.h, t.big, rows, W, dl, s));
+    if (tail) RUN(last_block_tail(fold, b, t.x, tail_src, t.tail, n_seq, W, t.eot, 1, dl, s));
+    else RUN(mlp_part(fold, b, t.x, t.h, t.big, rows, W, dl, s));
   }
   // ln_final on the EOT row only (LayerNorm is per-row, so gathering first is identical), then @ text_projection
   // (always fp32, as for the vision tower)
-  RUN(fold_merge_rows(fold, t.x, n_seq, W, t.eot, 1, s));
-  RUN(launch_layernorm(t.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, VTC_F32, t.eot, 1, false, s));
+  if (prune && w->layers > 0) {
+    RUN(launch_layernorm(t.tail.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, VTC_F32, nullptr, 1, false, s));
+  } else {
+    RUN(fold_merge_rows(fold, t.x, n_seq, W, t.eot, 1, s));
+    RUN(launch_layernorm(t.x, w->ln_final_g, w->ln_final_b, t.lnp, n_seq, W, VTC_F32, t.eot, 1, false, s));
+  }
   RUN(gemm(t.lnp, w->proj_t, nullptr, out, n_seq, w->embed_dim, W, VTC_F32, VTC_EPI_STORE, VTC_F32, 0, s));
   return 0;
 }

@@ -538,6 +538,37 @@ def test_last_block_on_the_output_rows_only_equals_the_full_last_block(dtype):
             pk.w.flags = towers.DEFAULT_FLAGS
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_single_block_towers_and_single_items_through_the_last_block_tail(dtype):
+    """The last block is also the FIRST one (layers = 1: the residual stream reaches the tail without ever having been through a
+    residual GEMM), width 256 (the smallest that folds the LayerNorms), one item per call: alt / v1 video towers, image tower
+    and text tower against the oracle."""
+    from dataclasses import replace
+    from vtc_amd import towers
+    a = replace(A.TINY, embed_dim=128, vision_layers=1, vision_width=256, transformer_width=256, transformer_heads=4, transformer_layers=1)
+    sd_alt = A.synth_visual(a, 301, nframes=4, prefix="v.")
+    for k in list(sd_alt):
+        if k.endswith("temporal_fc.weight"):
+            sd_alt[k] = torch.randn(sd_alt[k].shape, generator=torch.Generator().manual_seed(302)) * 0.02
+    sd_v1 = A.synth_visual(a, 303, nframes=4, prefix="v.", variant="v1")
+    sd_img = A.synth_visual(a, 304, prefix="v.")
+    sd_txt = A.synth_text(a, 305, prefix="t.")
+    tol = tol_for(dtype, a.embed_dim)
+    for n in (1, 3):
+        vid = A.synth_pixels((n, 4, 3, 64, 64), 306 + n)
+        img = A.synth_pixels((n, 3, 64, 64), 307 + n)
+        txt = A.synth_tokens(n, a, 308 + n)
+        cases = [("alt", towers.PackedVision(cuda_sd(sd_alt), "v.", dtype), vid, T.timesformer_alt(vid, sd_alt, a, "v.")),
+                 ("v1", towers.PackedVision(cuda_sd(sd_v1), "v.", dtype), vid, T.timesformer_v1(vid, sd_v1, a, "v.")),
+                 ("img", towers.PackedVision(cuda_sd(sd_img), "v.", dtype), img, CR.encode_image(img, sd_img, a, "v.")),
+                 ("txt", towers.PackedText(cuda_sd(sd_txt), "t.", dtype, heads=a.transformer_heads), txt, CR.encode_text(txt, sd_txt, a, "t."))]
+        for name, pk, x, ref in cases:
+            for full in (0, 1):
+                pk.w.flags = towers.tower_flags(full_last_layer=bool(full))
+                got = pk.forward(x.cuda()).cpu().numpy()
+                report(f"1-block {name} n={n} full_last={full}", np.abs(unit(got) - unit(ref.numpy())).max(), tol)
+
+
 def test_folded_layernorm_is_insensitive_to_a_row_mean():
     """The folded LayerNorm rounds x itself (not LN(x)) to the operand format, so a row mean large against the row's spread
     would cost precision -- the (hi, lo) stream is therefore stored centred (every reader is a LayerNorm: a per-row constant

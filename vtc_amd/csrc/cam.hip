@@ -117,7 +117,7 @@ __device__ __forceinline__ void grid_barrier(int *bar, int phase) {
     } else {
       while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase && ++spins <= CAM_SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
     }
-    if (spins > CAM_SPIN_LIMIT) __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // a barrier did not complete
+    if (spins > CAM_SPIN_LIMIT) __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // a barrier did not complete: the finalisation writes NaN
   }
   __syncthreads();                                        // nobody loads before the poll has matched
 }
@@ -418,7 +418,15 @@ __global__ __launch_bounds__(256, 1) void cam_fused_kernel(const CamFusedParams 
   // ---- finalisation, one wave per item (as embed.hip cam_finalize_kernel, init_from_avg):
   // r = normalize(mean_i normalize(Y_i)); r = act(r); adapted = normalize(normalize(main) + r)       model/model.py:157-159,65-77,203
   constexpr int MD = D / 64;
+  // A grid barrier that gave up (bar[1], CAM_SPIN_LIMIT: this launch did not have the chip to itself for ~0.4 s) means rows of x
+  // may be stale.  Fail LOUDLY: the items this wave owns come out as NaN, which no similarity, loss or R@K survives quietly.
+  const bool dead = __hip_atomic_load(p.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   for (int b = gw; b < p.B; b += TW) {
+    if (dead) {
+#pragma unroll
+      for (int k = 0; k < MD; ++k) p.out[(size_t)b * D + lane + 64 * k] = __uint_as_float(0x7FC00000u);
+      continue;
+    }
     float r[MD];
 #pragma unroll
     for (int k = 0; k < MD; ++k) r[k] = 0.f;

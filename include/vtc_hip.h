@@ -79,10 +79,11 @@ enum { VTC_TOWER_NO_LN_FOLD = 1,       /* run the LayerNorm kernels even when th
        VTC_TOWER_FUSED_ATTN = 2,       /* QKV projection + attention core as ONE kernel (vtc_qkv_attention) on contiguous
                                           sequences (ViT, dense text) and the TimeSformer time branch; implies NO_LN_FOLD   */
        VTC_TOWER_FUSED_ATTN_SPACE = 4, /* ... and on the TimeSformer space branch                                               */
-       VTC_TOWER_FULL_LAST_LAYER = 8   /* By default the LAST block's out_proj and MLP run only on the rows that reach the output
-                                          (x[:, 0] behind ln_post, model/timesformer_clip_alt.py:281; the EOT row behind ln_final):
-                                          every other row of that block is dead -- nothing reads it.  This flag computes them
-                                          anyway (same embeddings within rounding; for measurements against the unpruned path) */ };
+       VTC_TOWER_FULL_LAST_LAYER = 8   /* By default the LAST block's queries, out_proj and MLP run only on the rows that reach the
+                                          output (x[:, 0] behind ln_post, model/timesformer_clip_alt.py:281; the EOT row behind
+                                          ln_final): on every other row of that block they are dead -- nothing reads them (its keys
+                                          and values are computed for every row).  This flag computes them anyway (same embeddings
+                                          within rounding; for measurements against the unpruned path)                          */ };
 
 /* Vision tower: upstream VisionTransformer (nframes == 0) or
  * model/timesformer_clip_alt.py:203-286 VisualTransformer (nframes > 0). */

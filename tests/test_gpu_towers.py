@@ -405,7 +405,8 @@ def test_towers_with_fused_qkv_attention_are_bit_identical():
         runs = []
         for mask in (0, 3):
             # per-model flags (ABI 5): two models in one process choose differently, nothing is process-wide
-            fl = towers.tower_flags(ln_fold=False, fused_attn=mask)
+            # (every row of the last block on both sides: the kernels are what is compared, and the two paths drop different dead rows)
+            fl = towers.tower_flags(ln_fold=False, fused_attn=mask, full_last_layer=True)
             packs = [(towers.PackedVision(sdv, "v.", dtype), vid), (towers.PackedVision(sd16, "v.", dtype), vid16),
                      (towers.PackedVision(sdi, "v.", dtype), img),
                      (towers.PackedText(sdt, "model.", dtype, heads=a.transformer_heads), txt),
@@ -516,11 +517,14 @@ def test_last_block_on_the_output_rows_only_equals_the_full_last_block(dtype):
     tol = tol_for(dtype)
     from vtc_amd import _lib as L
     lib = L.lib()
-    for fold in ((1, 0) if dtype == torch.bfloat16 else (1,)):
+    # fold 1 / 0: folded LayerNorm / LayerNorm kernels, both with the last block's queries pruned as well (K and V projected for every
+    # row, one query per sequence: sq_attn_kernel); "fused": the one-kernel QKV + attention path, which prunes out_proj + MLP only
+    for fold in ((1, 0, "fused") if dtype == torch.bfloat16 else (1,)):
         outs, launches = {}, {}
         for full in (0, 1):
             for name, (pk, x) in packed.items():
-                pk.w.flags = towers.tower_flags(ln_fold=bool(fold), full_last_layer=bool(full))
+                pk.w.flags = (towers.tower_flags(ln_fold=False, fused_attn=3, full_last_layer=bool(full)) if fold == "fused"
+                              else towers.tower_flags(ln_fold=bool(fold), full_last_layer=bool(full)))
                 n0 = lib.vtc_debug_launch_count()
                 outs[(name, full)] = pk.forward(x.cuda()).cpu().numpy()
                 launches[(name, full)] = lib.vtc_debug_launch_count() - n0

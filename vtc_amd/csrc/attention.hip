@@ -254,6 +254,131 @@ __global__ __launch_bounds__(256) void cls_global_attn_kernel(const T *__restric
   if (active) ElemOps<T>::store(out + (size_t)item * Ttok * W + h * 64 + lane, o / sum);
 }
 
+// ---- one query per sequence: the LAST block of a tower, where only the row that reaches the output asks (towers.hip, last_block_tail) ----
+// Sequence o attends with the ONE projected query q[o / s2] (compact [n_q, W], operand format) over its keys and values in the packed
+// qkv buffer (the Q third of qkv is never read -- for this block it is never computed); out[o] [W] fp32.  Key rows: the affine map of
+// launch_attention, or (eot != NULL) the text tower's rows base .. eot[o] with base = offs ? offs[o] : o ctx (the EOT query sees its
+// whole causal prefix).  One wave per (sequence, head).  A 64-lane pass covers 64 / NCH keys x NCH 16-byte chunks of the head's 64
+// dimensions: scores = 8-element partial dots reduced over a key's NCH lanes, probabilities through LDS, P.V accumulated per chunk and
+// reduced over the passes' key slots at the end.  fp32 throughout (the all-rows kernel rounds P to the operand format for its MFMAs).
+struct SqParams {
+  const char *qkv, *q;
+  float *out;
+  int n_out, heads, W;
+  int L, s2, a0, a1, a2, a3, pstride;
+  const int *eot, *offs;
+  int ctx;
+};
+
+template <typename T>
+__device__ __forceinline__ void unpack_chunk(const uint4 &raw, float (&f)[AT<T>::EPC]) {
+  if constexpr (sizeof(T) == 4) {
+    f[0] = __uint_as_float(raw.x); f[1] = __uint_as_float(raw.y); f[2] = __uint_as_float(raw.z); f[3] = __uint_as_float(raw.w);
+  } else {
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[2 * e] = up16<T>((unsigned short)(w[e] & 0xFFFFu));
+      f[2 * e + 1] = up16<T>((unsigned short)(w[e] >> 16));
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sq_attn_kernel(const SqParams p) {
+  constexpr int SZ = sizeof(T), NCH = AT<T>::NCH, EPC = AT<T>::EPC, KP = 64 / NCH;
+  __shared__ float pl[4][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw = blockIdx.x * 4 + wave;
+  if (gw >= p.n_out * p.heads) return;              // no workgroup barrier below: waves are independent
+  const int o = gw / p.heads, h = gw - o * p.heads;
+  long base;
+  int first, pstride, L, qi;
+  if (p.eot) {
+    base = p.offs ? (long)p.offs[o] : (long)o * p.ctx;
+    L = p.eot[o] - (int)base + 1;
+    first = 1; pstride = 1; qi = o;
+  } else {
+    const int s_hi = o / p.s2, s_lo = o - s_hi * p.s2;
+    base = (long)s_hi * p.a1 + (long)s_lo * p.a2 + p.a0;
+    first = 1 + s_lo * p.a3; pstride = p.pstride; L = p.L; qi = s_hi;
+  }
+  L = min(max(L, 1), 128);
+  auto row_of = [&](int tok) -> long { return tok == 0 ? base : base + first + (long)(tok - 1) * pstride; };
+  const size_t ld = (size_t)3 * p.W * SZ;
+  const int ch = lane % NCH, kq = lane / NCH;
+  float qf[EPC];
+  unpack_chunk<T>(*reinterpret_cast<const uint4 *>(p.q + ((size_t)qi * p.W + h * 64) * SZ + ch * 16), qf);
+  float *pw = pl[wave];
+  // scores
+  const char *kbase = p.qkv + (size_t)(p.W + h * 64) * SZ + ch * 16;
+  for (int k0 = 0; k0 < L; k0 += KP) {
+    const int tok = k0 + kq;
+    float d = 0.f;
+    if (tok < L) {
+      float kf[EPC];
+      unpack_chunk<T>(*reinterpret_cast<const uint4 *>(kbase + (size_t)row_of(tok) * ld), kf);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) d = fmaf(qf[e], kf[e], d);
+    }
+#pragma unroll
+    for (int x = 1; x < NCH; x <<= 1) d += __shfl_xor(d, x, 64);
+    if (ch == 0 && tok < L) pw[tok] = d * 0.125f;       // q * head_dim^-0.5 (timesformer_clip_alt.py:48,52)
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // softmax over the L keys (two per lane)
+  const float s0 = lane < L ? pw[lane] : -INFINITY, s1 = lane + 64 < L ? pw[lane + 64] : -INFINITY;
+  const float mx = wave_max(fmaxf(s0, s1));
+  const float e0 = lane < L ? __expf(s0 - mx) : 0.f, e1 = lane + 64 < L ? __expf(s1 - mx) : 0.f;
+  const float inv = 1.0f / wave_sum(e0 + e1);
+  __builtin_amdgcn_wave_barrier();
+  pw[lane] = e0 * inv;
+  pw[lane + 64] = e1 * inv;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // out[d] = sum_key P[key] V[key][d]
+  float acc[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+  const char *vbase = p.qkv + (size_t)(2 * p.W + h * 64) * SZ + ch * 16;
+#pragma unroll 4
+  for (int k0 = 0; k0 < L; k0 += KP) {
+    const int tok = k0 + kq;
+    if (tok < L) {
+      float vf[EPC];
+      unpack_chunk<T>(*reinterpret_cast<const uint4 *>(vbase + (size_t)row_of(tok) * ld), vf);
+      const float pk = pw[tok];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[e] = fmaf(pk, vf[e], acc[e]);
+    }
+  }
+#pragma unroll
+  for (int x = NCH; x < 64; x <<= 1)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] += __shfl_xor(acc[e], x, 64);
+  if (kq == 0) {
+    float *dst = p.out + (size_t)o * p.W + h * 64 + ch * EPC;
+    *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if constexpr (EPC == 8) *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
+// out[i] = mean_f x[i F + f] in the operand format (F = 1: a conversion)
+template <typename T>
+__global__ __launch_bounds__(256) void mean_cast_kernel(const float *__restrict__ x, T *__restrict__ out, int n, int F, int W) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)n * W) return;
+  const size_t i = idx / W, c = idx - i * W;
+  float s = 0.f;
+  for (int f = 0; f < F; ++f) s += x[(i * F + f) * W + c];
+  s /= (float)F;
+  if constexpr (sizeof(T) == 4) out[idx] = s;
+  else reinterpret_cast<unsigned short *>(out)[idx] = cvt16<T>(s);
+}
+
 template <typename T, int NT>
 int run(const AttnParams &p, hipStream_t stream) {
   constexpr int VS = 16 * NT + 4;
@@ -308,6 +433,35 @@ int launch_attention_ragged(const void *qkv, void *out, int n_seq, int max_L, in
   ProfScope prof(VTC_PROF_ATTN, flops, stream, rows_dev);      // rows_dev: `flops` is per row
   if (dtype == VTC_F16) return dispatch<f16_t>(p, stream);
   return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
+}
+
+// One query per sequence (struct SqParams): affine key map as launch_attention (eot == NULL) or the text tower's EOT query.
+int launch_single_query_attention(const void *qkv, const void *q, float *out, int n_out, int L, int heads, int s2, int a0, int a1, int a2,
+                                  int a3, int pstride, const int *eot, const int *offs, int ctx, int dtype, hipStream_t stream) {
+  VTC_CHECK(n_out > 0 && heads > 0 && s2 > 0 && (eot || (L > 0 && L <= 128)), "single_query_attention: bad sizes n_out=%d L=%d", n_out, L);
+  VTC_CHECK(!eot || ctx <= 128, "single_query_attention: context %d > 128", ctx);
+  SqParams p;
+  p.qkv = (const char *)qkv; p.q = (const char *)q; p.out = out;
+  p.n_out = n_out; p.heads = heads; p.W = heads * 64;
+  p.L = L; p.s2 = s2; p.a0 = a0; p.a1 = a1; p.a2 = a2; p.a3 = a3; p.pstride = pstride;
+  p.eot = eot; p.offs = offs; p.ctx = ctx;
+  ProfScope prof(VTC_PROF_ATTN, 4.0 * (eot ? 0.5 * ctx : L) * 64 * (double)n_out * heads, stream);
+  const dim3 grid(cdiv(n_out * heads, 4));
+  if (dtype == VTC_F16) hipLaunchKernelGGL((sq_attn_kernel<f16_t>), grid, dim3(256), 0, stream, p);
+  else if (dtype == VTC_BF16) hipLaunchKernelGGL((sq_attn_kernel<bf16_t>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((sq_attn_kernel<float>), grid, dim3(256), 0, stream, p);
+  VTC_LAUNCH_CHECK("single_query_attention");
+  return 0;
+}
+
+int launch_mean_cast(const float *x, void *out, int n, int F, int W, int dtype, hipStream_t stream) {
+  VTC_CHECK(n > 0 && F > 0 && W > 0, "mean_cast: n=%d F=%d W=%d", n, F, W);
+  const dim3 grid(cdiv(n * W, 256));
+  if (dtype == VTC_F16) hipLaunchKernelGGL((mean_cast_kernel<f16_t>), grid, dim3(256), 0, stream, x, (f16_t *)out, n, F, W);
+  else if (dtype == VTC_BF16) hipLaunchKernelGGL((mean_cast_kernel<bf16_t>), grid, dim3(256), 0, stream, x, (bf16_t *)out, n, F, W);
+  else hipLaunchKernelGGL((mean_cast_kernel<float>), grid, dim3(256), 0, stream, x, (float *)out, n, F, W);
+  VTC_LAUNCH_CHECK("mean_cast");
+  return 0;
 }
 
 int launch_cls_global_attention(const void *qkv, void *out, int n_items, int Ttok, int heads, int dtype, hipStream_t stream) {

@@ -241,5 +241,8 @@ struct TextIds {
   int n_a, n_b;
   __host__ __device__ const int64_t *row(int s, int ctx) const { return s < n_a ? a + (size_t)s * ctx : b + (size_t)(s - n_a) * ctx; }
 };
+int launch_single_query_attention(const void *qkv, const void *q, float *out, int n_out, int L, int heads, int s2, int a0, int a1, int a2,
+                                  int a3, int pstride, const int *eot, const int *offs, int ctx, int dtype, hipStream_t stream);
+int launch_mean_cast(const float *x, void *out, int n, int F, int W, int dtype, hipStream_t stream);
 int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2,
                      int a0, int a1, int a2, int a3, int pstride, int dtype, hipStream_t stream);

@@ -1260,7 +1260,9 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
     VTC_CHECK(epi.ln_g && epi.ln_b && epi.ln_out && epi.ln_cnt && (epi.ldo == 0 || epi.ldo == N), "gemm: fused LayerNorm arguments");
   }
   if (epi.y16 || epi.fold_stat) {     // folded LayerNorm: only the interior fast epilogues carry it
-    VTC_CHECK(esz == 2 && M % 256 == 0 && N % 256 == 0 && (epi.ldo == 0 || epi.ldo == N),
+    // (the consumer may write its N columns into a wider output -- ldo > N: a column window of a projection; the producer's (hi, lo)
+    // arrays are indexed with ldo too, so there ldo == N)
+    VTC_CHECK(esz == 2 && M % 256 == 0 && N % 256 == 0 && (epi.ldo == 0 || epi.ldo == N || (!epi.y16 && epi.ldo > N && epi.ldo % 8 == 0)),
               "gemm: folded LayerNorm needs 16-bit operands and M, N multiples of 256 (M=%d N=%d dtype=%d)", M, N, dtype);
     VTC_CHECK(epi.y16 ? (epi.mode == VTC_EPI_RESID && epi.fold_part != nullptr && epi.y16lo != nullptr)
                       : ((epi.mode == VTC_EPI_STORE || epi.mode == VTC_EPI_GELU) && epi.out_dtype != VTC_F32 && epi.fold_s != nullptr),

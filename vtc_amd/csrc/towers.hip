@@ -130,8 +130,22 @@ struct Rows {
 };
 
 // out = epi(LN(x; g, bt) w^T + bias)
+// (col0, ncols: only the output columns [col0, col0 + ncols) -- rows col0.. of the weight -- are computed, at their places in the
+// N-wide output: the K and V thirds of a QKV projection whose queries come from elsewhere; ncols == 0: all N)
 int ln_proj(Fold &f, const float *x, const float *g, const float *bt, const void *w, const float *bias, const void *wf, const float *fs,
-            const float *fc, void *h, void *out, const Rows &rows, int N, int W, int dtype, int mode, hipStream_t s) {
+            const float *fc, void *h, void *out, const Rows &rows, int N, int W, int dtype, int mode, hipStream_t s, int col0 = 0,
+            int ncols = 0) {
+  const int ldo = N;
+  if (ncols > 0) {
+    const size_t wo = (size_t)col0 * W * esz(dtype);
+    w = (const char *)w + wo;
+    if (wf) wf = (const char *)wf + wo;
+    if (bias) bias += col0;
+    if (fs) fs += col0;
+    if (fc) fc += col0;
+    out = (char *)out + (size_t)col0 * esz(dtype);
+    N = ncols;
+  }
   if (f.on) {
     if (f.fmt != dtype) {       // no residual GEMM of this format in front: layer 0, or a format boundary (back through fp32)
       if (f.fmt >= 0) RUN(launch_split_merge_rows(f.xb, f.xl, const_cast<float *>(x), rows.n, W, nullptr, 1, f.fmt, s, rows.dev));
@@ -139,12 +153,12 @@ int ln_proj(Fold &f, const float *x, const float *g, const float *bt, const void
       f.fmt = dtype;
     }
     GemmEpi e;
-    e.mode = mode; e.out_dtype = dtype; e.fold_stat = f.stat; e.fold_s = fs; e.m_dev = rows.dev_pad();
+    e.mode = mode; e.out_dtype = dtype; e.fold_stat = f.stat; e.fold_s = fs; e.m_dev = rows.dev_pad(); e.ldo = ldo;
     return launch_gemm(f.xb, wf, fc, out, f.rows_pad, N, W, dtype, e, s);
   }
   RUN(launch_layernorm(x, g, bt, h, rows.n, W, dtype, nullptr, 1, false, s, rows.dev));
   GemmEpi e;
-  e.mode = mode; e.out_dtype = dtype; e.m_dev = rows.dev;
+  e.mode = mode; e.out_dtype = dtype; e.m_dev = rows.dev; e.ldo = ldo;
   return launch_gemm(h, w, bias, out, rows.n, N, W, dtype, e, s);
 }
 
@@ -212,15 +226,37 @@ struct Tail {
   float *x = nullptr;      // [n, W] fp32: the output rows of the residual stream
   void *a = nullptr;       // [n, W] operand format: their attention outputs
   void *h = nullptr;       // [n, W] operand format: LayerNorm output
-  void *big = nullptr;     // [n, 4 W] operand format: c_fc output
+  void *big = nullptr;     // [n, 4 W] operand format: c_fc output (before that, [n, W]: the output rows' projected queries)
+  float *sq = nullptr;     // [n, W] fp32: single-query attention output (text tower; the vision towers use cls_tmp)
 };
 void plan_tail(Bump &b, Tail &t, int n, int W) {      // sized for fp32 operands (the largest format)
   t.x = (float *)b.take((size_t)n * W * 4);
   t.a = b.take((size_t)n * W * 4);
   t.h = b.take((size_t)n * W * 4);
   t.big = b.take((size_t)n * 4 * W * 4);
+  t.sq = (float *)b.take((size_t)n * W * 4);
 }
 inline bool prune_last(int flags) { return (flags & VTC_TOWER_FULL_LAST_LAYER) == 0; }
+// ... and on the two-kernel attention path the last block's QUERIES are per-row maps too: only the output rows' queries are
+// projected (tail_query: LayerNorm kernel + the Q third of in_proj on n rows), the all-rows projection computes the K and V thirds
+// only (ln_proj's column window) and the attention core runs one query per sequence (attention.hip, sq_attn_kernel).
+inline bool prune_last_queries(int flags) { return prune_last(flags) && (flags & (VTC_TOWER_FUSED_ATTN | VTC_TOWER_FUSED_ATTN_SPACE)) == 0; }
+// the n output rows of the stream -> t.x (fp32, compact); their queries ln_1(x) Wq^T + bq -> t.big [n, W] (operand format)
+int tail_query(Fold &f, const vtc_block_w &b, float *x, Tail &t, int n, int W, const int *row_index, int row_mul, int dtype, hipStream_t s) {
+  RUN(fold_merge_rows(f, x, n, W, row_index, row_mul, s));
+  RUN(launch_gather_rows(x, t.x, n, W * 4, row_index, row_mul, s));
+  RUN(launch_layernorm(t.x, b.ln1_g, b.ln1_b, t.h, n, W, dtype, nullptr, 1, false, s));
+  return gemm(t.h, b.qkv_w, b.qkv_b, t.big, n, W, W, dtype, VTC_EPI_STORE, dtype, 0, s);
+}
+// t.x += out_proj(t.a) ; t.x += MLP(ln_2 t.x)      (t.a: the output rows' attention outputs, operand format)
+int tail_finish(const vtc_block_w &b, Tail &t, int n, int W, int dtype, hipStream_t s) {
+  {
+    ProfRegion region(VTC_PROF_REGION_ATTN);
+    RUN(gemm(t.a, b.out_w, b.out_b, t.x, n, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
+  }
+  Fold nofold;
+  return mlp_part(nofold, b, t.x, t.h, t.big, Rows(n), W, dtype, s);
+}
 // attn_out: [rows, W] operand format, the attention core's output (cls rows already averaged over frames for the TimeSformer);
 // the output row of item i is row_index[i] (or i * row_mul) of the stream
 int last_block_tail(Fold &f, const vtc_block_w &b, float *x, const void *attn_out, Tail &t, int n, int W, const int *row_index, int row_mul,
@@ -363,6 +399,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
   Fold &fold = v.fold;
   fold.on = fold_usable(w->blocks, w->layers, W, dtype, tsf, w->flags);
   const bool prune = prune_last(w->flags);
+  const bool tail_q = prune_last_queries(w->flags) && !(tsf && w->variant == 1);   // ... and its queries (not on the v1 tower's global cls attention)
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
     const bool tail = prune && l == w->layers - 1;      // out_proj + MLP of the last block: the cls rows only (last_block_tail)
@@ -417,15 +454,30 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
         RUN(resid_proj(fold, v.h, b.tfc_w, b.tfc_b, v.x, rows, W, W, dtype, T, s));
       }
       // spatial branch (:152-168): sequences = (item, frame): [cls, the P patches of that frame]
-      RUN(ln_proj(fold, v.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, v.h, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));
-      RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, 1, F, dtype, s));
-      RUN(launch_cls_mean(v.cls_tmp, v.h, dtype, n_items, F, T, W, s));
-      if (!tail) RUN(resid_proj(fold, v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, 0, s));
+      if (tail && tail_q) {
+        // last block: the cls query only (one per item, the same in each of its F sequences), K and V of every row
+        RUN(tail_query(fold, b, v.x, v.tail, n_items, W, nullptr, T, dtype, s));
+        RUN(ln_proj(fold, v.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, v.h, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s, W, 2 * W));
+        RUN(launch_single_query_attention(v.big, v.tail.big, v.cls_tmp, n_items * F, 1 + P, w->heads, F, 0, T, 0, 1, F, nullptr, nullptr, 0, dtype, s));
+        RUN(launch_mean_cast(v.cls_tmp, v.tail.a, n_items, F, W, dtype, s));      // cls output = mean over the frames (:166-167)
+      } else {
+        RUN(ln_proj(fold, v.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, v.h, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));
+        RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, 1, F, dtype, s));
+        RUN(launch_cls_mean(v.cls_tmp, v.h, dtype, n_items, F, T, W, s));
+        if (!tail) RUN(resid_proj(fold, v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, 0, s));
+      }
+    } else if (tail && tail_q) {
+      // image tower, last block: the cls query only
+      RUN(tail_query(fold, b, v.x, v.tail, n_items, W, nullptr, T, dtype, s));
+      RUN(ln_proj(fold, v.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, v.h, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s, W, 2 * W));
+      RUN(launch_single_query_attention(v.big, v.tail.big, v.cls_tmp, n_items, T, w->heads, 1, 0, T, 0, 0, 1, nullptr, nullptr, 0, dtype, s));
+      RUN(launch_mean_cast(v.cls_tmp, v.tail.a, n_items, 1, W, dtype, s));
     } else {
       RUN(attn_part_contig(fold, b, v.x, v.h, v.big, n_items, T, W, w->heads, 0, dtype, w->flags, s, tail ? &tail_src : nullptr));
     }
     }
-    if (tail) RUN(last_block_tail(fold, b, v.x, tail_src, v.tail, n_items, W, nullptr, T, dtype, s));
+    if (tail && tail_q && w->variant == 0) RUN(tail_finish(b, v.tail, n_items, W, dtype, s));
+    else if (tail) RUN(last_block_tail(fold, b, v.x, tail_src, v.tail, n_items, W, nullptr, T, dtype, s));
     else RUN(mlp_part(fold, b, v.x, v.h, v.big, rows, W, dtype, s));
   }
   // ln_post(x[:,0]) @ proj -- always fp32 (n_items rows only): the embedding the sweep ranks on
@@ -474,13 +526,20 @@ int text_forward_impl(const vtc_text_w *w, const TextIds &ids, int mode, const i
   fold.on = fold_usable(w->blocks, w->layers, W, dtype, false, w->flags);
   // attention work of the ragged batch for the profiler (the lengths are not known here): rows x (mean length ~ ctx / 2)
   const double attn_flops_per_row = 4.0 * (0.5 * w->ctx) * 64 * w->heads;
-  const bool prune = prune_last(w->flags);
+  const bool prune = prune_last(w->flags), tail_q = prune_last_queries(w->flags);
   for (int l = 0; l < w->layers; ++l) {
     const vtc_block_w &b = w->blocks[l];
     const int dl = layer_dtype(w, l, dtype);
     const bool tail = prune && l == w->layers - 1;      // out_proj + MLP of the last block: the EOT rows only (last_block_tail)
     const void *tail_src = t.h;
-    if (mode == 0) {
+    if (tail && tail_q) {
+      // last block: the EOT query only (it sees its whole causal prefix), K and V of every row
+      ProfRegion region(VTC_PROF_REGION_ATTN);
+      RUN(tail_query(fold, b, t.x, t.tail, n_seq, W, t.eot, 1, dl, s));
+      RUN(ln_proj(fold, t.x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, t.h, t.big, rows, 3 * W, W, dl, VTC_EPI_STORE, s, W, 2 * W));
+      RUN(launch_single_query_attention(t.big, t.tail.big, t.tail.sq, n_seq, 0, w->heads, 1, 0, 0, 0, 0, 1, t.eot, mode == 0 ? nullptr : offs, w->ctx, dl, s));
+      RUN(launch_mean_cast(t.tail.sq, t.tail.a, n_seq, 1, W, dl, s));
+    } else if (mode == 0) {
       RUN(attn_part_contig(fold, b, t.x, t.h, t.big, n_seq, w->ctx, W, w->heads, 1, dl, w->flags, s, tail ? &tail_src : nullptr));
     } else {
       ProfRegion region(VTC_PROF_REGION_ATTN);
@@ -488,7 +547,8 @@ int text_forward_impl(const vtc_text_w *w, const TextIds &ids, int mode, const i
       RUN(launch_attention_ragged(t.big, t.h, n_seq, w->ctx, w->heads, 1, offs, attn_flops_per_row * (rows.dev ? 1.0 : rows.n), rows.dev, dl, s));
       if (!tail) RUN(resid_proj(fold, t.h, b.out_w, b.out_b, t.x, rows, W, W, dl, 0, s));
     }
-    if (tail) RUN(last_block_tail(fold, b, t.x, tail_src, t.tail, n_seq, W, t.eot, 1, dl, s));
+    if (tail && tail_q) RUN(tail_finish(b, t.tail, n_seq, W, dl, s));
+    else if (tail) RUN(last_block_tail(fold, b, t.x, tail_src, t.tail, n_seq, W, t.eot, 1, dl, s));
     else RUN(mlp_part(fold, b, t.x, t.h, t.big, rows, W, dl, s));
   }
   // ln_final on the EOT row only (LayerNorm is per-row, so gathering first is identical), then @ text_projection

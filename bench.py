@@ -634,7 +634,7 @@ def main():
                    "pairs_per_gpu": B, "frames": 8,
                    "text_tower": ("ragged: tokens after EOT are not computed, identical outputs" if TW.TEXT_RAGGED else "dense: all 77 positions"),
                    "text_tokens_computed_frac": round(n_tok / (6 * B * 77), 4) if TW.TEXT_RAGGED else 1.0,
-                   "last_block": ("out_proj + MLP of each tower's LAST block on the rows that reach the output only (x[:, 0] / the EOT row; the other rows "
+                   "last_block": ("queries, out_proj + MLP of each tower's LAST block on the rows that reach the output only (x[:, 0] / the EOT row; keys and values for every row; the other rows "
                                   "of that block are read by nothing) -- identical embeddings; extra.config3_B*_full_last_block_pairs_per_s computes them anyway"
                                   if not (TW.DEFAULT_FLAGS & L.TOWER_FULL_LAST_LAYER) else "every row"),
                    "parallelism": f"dp{world} (one process per GPU, no collective in the encode path)"},

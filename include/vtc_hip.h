@@ -74,7 +74,8 @@ typedef struct {
 
 /* Per-model path switches (vtc_vision_w.flags / vtc_text_w.flags).  They live in the weight struct -- two models in one
  * process may choose differently, nothing is process-wide -- and never change results beyond the stated tolerance
- * (FUSED_*: bit-identical to the LayerNorm-kernel path). */
+ * (FUSED_*: bit-identical to the LayerNorm-kernel path when both compute every row of the last block, FULL_LAST_LAYER: the two
+ * paths drop different dead rows there -- see below). */
 enum { VTC_TOWER_NO_LN_FOLD = 1,       /* run the LayerNorm kernels even when the blocks carry folded weights (*_wf)              */
        VTC_TOWER_FUSED_ATTN = 2,       /* QKV projection + attention core as ONE kernel (vtc_qkv_attention) on contiguous
                                           sequences (ViT, dense text) and the TimeSformer time branch; implies NO_LN_FOLD   */

@@ -181,6 +181,12 @@ int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, const float *co
 int vtc_normalize_rows(const float *x, float *out, int n, int d, void *stream);
 /* out[g] = mean over `group` consecutive rows (frames -> video, title+comments -> text) */
 int vtc_mean_groups(const float *x, float *out, int n_groups, int group, int d, void *stream);
+/* Token packing: the array-building half of `_tokenise` (dataset_loaders/dataset_loaders.py:224-248; the BPE encoder and the RAKE
+ * summariser in front of it stay host text processing).  tokens: the batch's BPE ids back to back (int32, device), offsets [n_seq + 1]
+ * their prefix sums (device).  ids [n_seq, ctx] int64 = [sot] + tokens of the sequence + [eot], zero padded; a sequence that reaches
+ * ctx keeps its first ctx - 1 ids and ends in eot (:240-243).  The output is what vtc_text_forward* take. */
+int vtc_pack_tokens(const int *tokens, const int *offsets, int n_seq, int ctx, int sot, int eot, int64_t *ids, void *stream);
+
 /* out[g] = (a[g] + sum_k b[g * group + k]) / (1 + group): the "averaging" comment fusion, mean of a title embedding and its
  * comments' (model/model.py:357-362), without stacking them first */
 int vtc_mean_head_groups(const float *a, const float *b, float *out, int n_groups, int group, int d, void *stream);

@@ -1,0 +1,44 @@
+"""Token packing: the array-building half of the reference's `_tokenise`
+(dataset_loaders/dataset_loaders.py:224-248).  CPU: the oracle restatement against hand-written known answers of that code's
+rules; GPU: vtc_pack_tokens (through the C ABI) against the oracle on ragged batches, empty / exactly-full / over-long texts."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tokens_ref as TR
+
+
+def test_oracle_packing_rules():
+    # short: [sot] + ids + [eot] + zeros (:244-247)
+    out = TR.pack_tokens([[5, 6, 7], []], max_len=8)
+    assert out.tolist() == [[TR.SOT, 5, 6, 7, TR.EOT, 0, 0, 0], [TR.SOT, TR.EOT, 0, 0, 0, 0, 0, 0]]
+    # len(tokens) == max_len takes the truncation branch and comes out unchanged; longer keeps max_len - 1 ids + eot (:236-243)
+    full = list(range(10, 16))                # 6 ids + sot + eot = 8
+    over = list(range(10, 30))
+    out = TR.pack_tokens([full, over], max_len=8)
+    assert out[0].tolist() == [TR.SOT] + full + [TR.EOT]
+    assert out[1].tolist() == [TR.SOT] + over[:6] + [TR.EOT]
+    # the text tower finds the EOT with argmax: it is the largest id and the first maximum of every row
+    assert (out.argmax(-1) == np.array([7, 7])).all()
+    assert TR.pack_tokens([[1]] * 3).shape == (3, 77) and TR.pack_tokens([[1]]).dtype == np.int64
+
+
+@pytest.mark.gpu
+def test_pack_tokens_kernel_matches_the_oracle():
+    from vtc_amd import ops
+    from vtc_amd.host import datasets as DS
+    rng = np.random.default_rng(11)
+    for ctx in (77, 24, 8):
+        lens = [0, 1, ctx - 3, ctx - 2, ctx - 1, ctx, 3 * ctx] + [int(v) for v in rng.integers(0, ctx + 5, size=200)]
+        lists = [[int(v) for v in rng.integers(1, 49405, size=n)] for n in lens]
+        want = TR.pack_tokens(lists, max_len=ctx)
+        got = DS.pack_token_lists(lists, max_len=ctx, device="cuda")
+        assert got.dtype == torch.int64 and got.is_cuda and np.array_equal(got.cpu().numpy(), want)
+        # device-resident inputs through the op itself
+        flat = torch.tensor([v for t in lists for v in t], dtype=torch.int32, device="cuda")
+        offs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device="cuda")
+        assert np.array_equal(ops.pack_tokens(flat, offs, ctx).cpu().numpy(), want)
+    # an all-empty batch (no token at all)
+    assert np.array_equal(DS.pack_token_lists([[], []], device="cuda").cpu().numpy(), TR.pack_tokens([[], []]))
+    # and the packed ids run through the text tower like any other (EOT position = argmax)
+    assert (got.argmax(-1).cpu().numpy() == want.argmax(-1)).all()

@@ -399,6 +399,24 @@ int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int
   return 0;
 }
 
+// ---- token packing (dataset_loaders/dataset_loaders.py:224-248 `_tokenise`, its array-building half: the BPE
+// encoder and the RAKE summariser in front of it are host text processing) ------------------------------------------------------
+// ids[s] = [SOT] + tokens[offsets[s] : offsets[s + 1]] + [EOT], zero padded to ctx; a sequence whose SOT + tokens + EOT reach ctx
+// keeps its first ctx - 1 ids and ends in EOT (:240-243 `tokens[: max_len - 1] + [eot_token]`).  One thread per output id.
+__global__ __launch_bounds__(256) void pack_tokens_kernel(const int *__restrict__ tokens, const int *__restrict__ offsets, int n_seq, int ctx,
+                                                          int sot, int eot, int64_t *__restrict__ ids) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)n_seq * ctx) return;
+  const int s = (int)(idx / ctx), p = (int)(idx - (size_t)s * ctx);
+  const int lo = offsets[s], n = offsets[s + 1] - lo;
+  const int len = min(n + 2, ctx);                       // packed length, EOT included
+  int64_t v = 0;
+  if (p == 0) v = sot;
+  else if (p == len - 1) v = eot;
+  else if (p < len - 1) v = tokens[lo + p - 1];
+  ids[idx] = v;
+}
+
 int launch_text_prep(const TextIds &ids, int n_seq, int ctx, int *lens, int *offsets, int *m_dev, hipStream_t stream) {
   ProfScope prof(VTC_PROF_EMBED, (double)n_seq * ctx * 8, stream);
   hipLaunchKernelGGL(seq_len_kernel, dim3(cdiv(n_seq, 4)), dim3(256), 0, stream, ids, lens, n_seq, ctx);
@@ -445,5 +463,12 @@ int launch_cam_finalize(const float *Y, const float *lin, const float *main_f, f
   hipLaunchKernelGGL((cam_finalize_kernel<16>), dim3(cdiv(B, 4)), dim3(256), 0, stream, Y, lin, main_f, out, B, Lc, D, init_from_avg,
                      act, scale, bn_mean, bn_var);
   VTC_LAUNCH_CHECK("cam_finalize");
+  return 0;
+}
+
+extern "C" int vtc_pack_tokens(const int *tokens, const int *offsets, int n_seq, int ctx, int sot, int eot, int64_t *ids, void *stream) {
+  VTC_CHECK(offsets && ids && n_seq > 0 && ctx >= 2, "pack_tokens: bad arguments (n_seq=%d ctx=%d)", n_seq, ctx);
+  hipLaunchKernelGGL(pack_tokens_kernel, dim3(cdiv(n_seq * ctx, 256)), dim3(256), 0, (hipStream_t)stream, tokens, offsets, n_seq, ctx, sot, eot, ids);
+  VTC_LAUNCH_CHECK("pack_tokens");
   return 0;
 }

@@ -24,6 +24,19 @@ from torch.utils.data import Dataset
 SOT, EOT = 49406, 49407
 
 
+def pack_token_lists(token_lists, max_len=77, device=None):
+    """The array-building half of the reference's `_tokenise` (dataset_loaders/dataset_loaders.py:224-248) on the GPU: one list of
+    BPE ids per text (the encoder's output; the encoder itself and the RAKE summariser stay host text processing) -> ids
+    [n, max_len] int64 on `device`, as `PretrainedCLIP*.forward` takes them.  One ragged H2D copy + one kernel."""
+    from .. import ops
+    device = torch.device(device if device is not None else "cuda")
+    lens = torch.tensor([len(t) for t in token_lists], dtype=torch.int32)
+    offsets = torch.zeros(len(token_lists) + 1, dtype=torch.int32)
+    offsets[1:] = torch.cumsum(lens, 0)
+    flat = torch.tensor([int(v) for t in token_lists for v in t] or [0], dtype=torch.int32)
+    return ops.pack_tokens(flat.to(device), offsets.to(device), max_len, SOT, EOT)
+
+
 def synth_tokens(n, ctx, gen, empty_frac=0.0):
     out = torch.zeros(n, ctx, dtype=torch.int64)
     lens = torch.randint(1, ctx - 1, (n,), generator=gen)

@@ -185,6 +185,17 @@ def mean_head_groups(a: torch.Tensor, b: torch.Tensor, group: int) -> torch.Tens
 
 
 @on_device
+def pack_tokens(tokens: torch.Tensor, offsets: torch.Tensor, ctx: int = 77, sot: int = 49406, eot: int = 49407) -> torch.Tensor:
+    """[n_seq, ctx] int64 ids = [sot] + tokens[offsets[s]:offsets[s+1]] + [eot], zero padded; truncated to ctx - 1 ids + eot
+    (dataset_loaders/dataset_loaders.py:224-248).  tokens int32 [total], offsets int32 [n_seq + 1], both on the GPU."""
+    tokens, offsets = _gpu(tokens, torch.int32, "tokens"), _gpu(offsets, torch.int32, "offsets")
+    n = offsets.numel() - 1
+    ids = torch.empty(n, ctx, dtype=torch.int64, device=offsets.device)
+    L.check(L.lib().vtc_pack_tokens(tokens.data_ptr(), offsets.data_ptr(), n, ctx, sot, eot, ids.data_ptr(), _stream()), "vtc_pack_tokens")
+    return ids
+
+
+@on_device
 def segment_mean(x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     """Mean of rows [offsets[g], offsets[g+1]) per group g (int32 offsets on the GPU)."""
     x = _gpu(x, torch.float32, "x")

@@ -392,6 +392,7 @@ int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, 
 }
 
 int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int F, int T, int W, hipStream_t stream) {
+  VTC_CHECK(dtype == VTC_BF16 || dtype == VTC_F32, "cls_mean: dtype %d (the vision towers run bf16 or fp32)", dtype);
   const dim3 g(cdiv(n_items * W, 256)), b(256);
   if (dtype == VTC_BF16) hipLaunchKernelGGL((cls_mean_kernel<bf16_t>), g, b, 0, stream, cls_tmp, (bf16_t *)out, n_items, F, T, W);
   else hipLaunchKernelGGL((cls_mean_kernel<float>), g, b, 0, stream, cls_tmp, (float *)out, n_items, F, T, W);

@@ -276,6 +276,13 @@ int vtc_layernorm(const float *x, const float *g, const float *b, void *y, int r
 int vtc_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, int heads, int causal, int s2, int a0,
                   int a1, int a2, int a3, int pstride, int dtype, void *stream);
 
+/* ONE query per sequence (the last block of a tower, where only the row that reaches the output asks): sequence o attends
+ * with the projected query q[o / s2] (q: [n_q, W], operand format, compact) over its keys and values in the packed qkv buffer (key rows:
+ * the map of vtc_attention; the Q third of qkv is not read).  eot != NULL instead: the text tower's rows base .. eot[o], base =
+ * offs ? offs[o] : o * ctx, query q[o].  out [n_out, W] fp32.  fp32 arithmetic throughout. */
+int vtc_single_query_attention(const void *qkv, const void *q, float *out, int n_out, int L, int heads, int s2, int a0, int a1, int a2,
+                               int a3, int pstride, const int *eot, const int *offs, int ctx, int dtype, void *stream);
+
 /* QKV projection + attention core in one kernel (16-bit operand formats only): what vtc_gemm(h, w_qkv, b_qkv) followed by
  * vtc_attention computes, bit for bit, without the packed qkv matrix in HBM.  h: LayerNorm output [rows, W]; w_qkv
  * in_proj_weight [3W, W]; out [rows, W] (operand format; same row map as vtc_attention); rows = row count of h / out.

@@ -103,6 +103,72 @@ def test_attention_contiguous(dtype, L_, causal):
     assert (out - ref).abs().max() < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_single_query_attention_vs_fp32_reference(dtype):
+    """vtc_single_query_attention (the last block's attention): one projected query per sequence over the keys / values of
+    the packed qkv buffer -- contiguous sequences (image tower), the space branch's [cls, frame patches] map with the query shared by
+    an item's F sequences, and the text tower's EOT query over rows base .. eot (ragged offsets and dense) -- against
+    softmax(q k^T / 8) v in fp32 on the same (rounded) operands.  The Q third of the buffer is poisoned: it must not be read."""
+    L, ops = _ops()
+    heads = 3
+    W = heads * 64
+    tol = 2e-5
+    g = torch.Generator().manual_seed(3)
+
+    def ref(qrow, krows, vrows):             # [W], [n, W], [n, W] -> [W]
+        out = []
+        for h in range(heads):
+            sl = slice(64 * h, 64 * h + 64)
+            p = ((krows[:, sl] @ qrow[sl]) * 0.125).softmax(0)
+            out.append(p @ vrows[:, sl])
+        return torch.cat(out)
+
+    # contiguous sequences of L tokens, query = row o of q
+    for L_ in (1, 7, 50, 77):
+        n = 5
+        qkv = torch.randn(n * L_, 3 * W, generator=g)
+        qkv[:, :W] = float("nan")
+        q = torch.randn(n, W, generator=g)
+        qd, kd = q.cuda().to(dtype), qkv.cuda().to(dtype)
+        got = ops.single_query_attention(kd, qd, n, L_, heads).cpu()
+        kf = kd.float().cpu()
+        want = torch.stack([ref(qd.float().cpu()[o], kf[o * L_:(o + 1) * L_, W:2 * W], kf[o * L_:(o + 1) * L_, 2 * W:]) for o in range(n)])
+        assert torch.isfinite(got).all() and (got - want).abs().max() < tol, (L_, (got - want).abs().max())
+    # space branch: item b, frame t: keys = cls row b T, then rows b T + 1 + n F + t; the query of (b, t) is q[b]
+    B, P, F = 3, 4, 8
+    T = 1 + P * F
+    qkv = torch.randn(B * T, 3 * W, generator=g)
+    qkv[:, :W] = float("nan")
+    q = torch.randn(B, W, generator=g)
+    qd, kd = q.cuda().to(dtype), qkv.cuda().to(dtype)
+    got = ops.single_query_attention(kd, qd, B * F, 1 + P, heads, s2=F, a0=0, a1=T, a2=0, a3=1, pstride=F).cpu()
+    kf = kd.float().cpu()
+    for b in range(B):
+        for t in range(F):
+            rows = [b * T] + [b * T + 1 + n_ * F + t for n_ in range(P)]
+            want = ref(qd.float().cpu()[b], kf[rows, W:2 * W], kf[rows, 2 * W:])
+            assert (got[b * F + t] - want).abs().max() < tol
+    # text: sequence o = rows base .. eot[o] (ragged: base = offs[o]; dense: base = o ctx)
+    ctx = 24
+    lens = torch.tensor([1, 24, 5, 17], dtype=torch.int32)
+    offs = torch.zeros(5, dtype=torch.int32)
+    offs[1:] = torch.cumsum(lens, 0)
+    for dense in (False, True):
+        rows_total = 4 * ctx if dense else int(offs[-1])
+        qkv = torch.randn(rows_total, 3 * W, generator=g)
+        qkv[:, :W] = float("nan")
+        q = torch.randn(4, W, generator=g)
+        base = torch.arange(4, dtype=torch.int32) * ctx if dense else offs[:4]
+        eot = (base + lens - 1).to(torch.int32)
+        qd, kd = q.cuda().to(dtype), qkv.cuda().to(dtype)
+        got = ops.single_query_attention(kd, qd, 4, 0, heads, eot=eot.cuda(), offs=None if dense else offs.cuda(), ctx=ctx).cpu()
+        kf = kd.float().cpu()
+        for o in range(4):
+            r = slice(int(base[o]), int(eot[o]) + 1)
+            want = ref(qd.float().cpu()[o], kf[r, W:2 * W], kf[r, 2 * W:])
+            assert (got[o] - want).abs().max() < tol
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("F", [1, 2, 8, 16])
 def test_attention_time_and_space_row_maps(dtype, F):

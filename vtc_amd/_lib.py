@@ -76,6 +76,7 @@ SIGNATURES = {
     "vtc_nonfinite_flag": (C.c_int, [fp, C.c_size_t, vp, vp]),
     "vtc_mean_head_groups": (C.c_int, [fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]),
     "vtc_pack_tokens": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "vtc_single_query_attention": (C.c_int, [vp, vp, fp] + [C.c_int] * 9 + [vp, vp, C.c_int, C.c_int, vp]),
     "vtc_segment_mean": (C.c_int, [fp, ip, fp, C.c_int, C.c_int, vp]),
     "vtc_similarity": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, fp, fp, vp]),
     "vtc_clip_loss_workspace_bytes": (C.c_size_t, [C.c_int]),

@@ -485,3 +485,10 @@ extern "C" int vtc_attention(const void *qkv, void *out, float *cls_out, int n_s
   return launch_attention(qkv, out, cls_out, n_seq, L, heads, causal, s2, a0, a1, a2, a3, pstride, dtype,
                           (hipStream_t)stream);
 }
+
+extern "C" int vtc_single_query_attention(const void *qkv, const void *q, float *out, int n_out, int L, int heads, int s2, int a0, int a1,
+                                          int a2, int a3, int pstride, const int *eot, const int *offs, int ctx, int dtype, void *stream) {
+  VTC_CHECK(qkv && q && out, "single_query_attention: null argument");
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16 || dtype == VTC_F16, "single_query_attention: bad dtype %d", dtype);
+  return launch_single_query_attention(qkv, q, out, n_out, L, heads, s2, a0, a1, a2, a3, pstride, eot, offs, ctx, dtype, (hipStream_t)stream);
+}

@@ -136,6 +136,25 @@ def attention(qkv: torch.Tensor, n_seq: int, L_: int, heads: int, causal: bool =
 
 
 @on_device
+def single_query_attention(qkv: torch.Tensor, q: torch.Tensor, n_out: int, L_: int, heads: int, s2: int = 1, a0: int = 0,
+                           a1: Optional[int] = None, a2: int = 0, a3: int = 0, pstride: int = 1, eot: Optional[torch.Tensor] = None,
+                           offs: Optional[torch.Tensor] = None, ctx: int = 0) -> torch.Tensor:
+    """One query per sequence over the keys / values of a packed qkv buffer (same row map as ``attention``; or, with ``eot``, the
+    text tower's rows base .. eot[o]) -> [n_out, W] fp32.  The last block of a tower: only the output row asks."""
+    qkv, q = _gpu(qkv, name="qkv"), _gpu(q, qkv.dtype, "q")
+    W = qkv.shape[1] // 3
+    assert W == heads * 64 and q.shape[1] == W
+    if a1 is None:
+        a1 = L_
+    out = torch.empty(n_out, W, dtype=torch.float32, device=qkv.device)
+    eot_p = _gpu(eot, torch.int32, "eot").data_ptr() if eot is not None else None
+    offs_p = _gpu(offs, torch.int32, "offs").data_ptr() if offs is not None else None
+    L.check(L.lib().vtc_single_query_attention(qkv.data_ptr(), q.data_ptr(), out.data_ptr(), n_out, L_, heads, s2, a0, a1, a2, a3, pstride,
+                                               eot_p, offs_p, ctx, _TDT[qkv.dtype], _stream()), "vtc_single_query_attention")
+    return out
+
+
+@on_device
 def qkv_attention(h: torch.Tensor, w_qkv: torch.Tensor, b_qkv: torch.Tensor, n_seq: int, L_: int, heads: int, causal: bool = False,
                   s2: int = 1, a0: int = 0, a1: Optional[int] = None, a2: int = 0, a3: int = 0, pstride: int = 1,
                   cls_out: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

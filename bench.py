@@ -461,6 +461,43 @@ def e2e_eval(m3, B, title, comments, world, device, extra):
     extra["eval_e2e"] = res
 
 
+def headline_independence(m3, vid, title, comments, B):
+    """the headline batch held to what the tests hold to the oracle.  Items [0:16] and [B-16:B] of the B-pair
+    forward against the same items encoded as two B = 16 batches (the shape `cpu_baseline.gpu_vs_oracle_max_err` and
+    tests/test_gpu_towers.py compare with the oracle): max abs error of the unit-norm embeddings and of the cosine similarity
+    block (sim / exp(logit_scale)), for the default forward and with every row of the last block computed.  No op of the path
+    mixes items (model/model.py:596-623), so these must agree within the 16-bit tolerance 1e-3; the run FAILS otherwise."""
+    from vtc_amd import _lib as L
+    from vtc_amd import towers as TW
+    scale = float(m3.model.logit_scale.detach().exp())
+    n = min(16, B)
+    res = {}
+    was = TW.DEFAULT_FLAGS
+    try:
+        for name, flags in (("default", was), ("full_last_block", was | L.TOWER_FULL_LAST_LAYER)):
+            TW.DEFAULT_FLAGS = flags
+            m3._packed = {}
+            big = m3(vid, title, comments)
+            e = {"feats_vis": 0.0, "feats_text": 0.0, "cosine_sim_block": 0.0}
+            for lo in sorted({0, B - n}):
+                sl = slice(lo, lo + n)
+                small = m3(vid[sl].contiguous(), title[sl].contiguous(), comments[sl].contiguous())
+                e["feats_vis"] = max(e["feats_vis"], float((big[0][sl] - small[0]).abs().max()))
+                e["feats_text"] = max(e["feats_text"], float((big[1][sl] - small[1]).abs().max()))
+                e["cosine_sim_block"] = max(e["cosine_sim_block"], float((big[2][sl, sl] - small[2]).abs().max()) / scale)
+            # every row of the batch similarity against the batch's own embeddings in fp64
+            e["sim_vs_own_embeddings_fp64"] = float((big[2].double() / scale - big[0].double() @ big[1].double().T).abs().max())
+            e["finite"] = bool(all(torch.isfinite(t).all() for t in big))
+            res[name] = {k: (round(v, 9) if isinstance(v, float) else v) for k, v in e.items()}
+    finally:
+        TW.DEFAULT_FLAGS = was
+        m3._packed = {}
+    worst = max(v for d in res.values() for k, v in d.items() if k in ("feats_vis", "feats_text", "cosine_sim_block"))
+    res.update(items=f"[0:{n}] and [{B - n}:{B}] of the B={B} forward vs the same items at B={n}", tolerance=1e-3, max_err=round(worst, 9),
+               ok=bool(worst <= 1e-3 and all(d["finite"] and d["sim_vs_own_embeddings_fp64"] <= 1e-5 for d in res.values() if isinstance(d, dict))))
+    return res
+
+
 def spawn_ranks(n):
     """One process per GPU through torch.distributed.run, as the driver itself launches an N > 1 run."""
     import socket
@@ -587,6 +624,10 @@ def main():
     log(f"timed region: {dt:.2f} s for {args.steps} steps")
     assert torch.isfinite(out[2]).all()
     value = world * B * args.steps / dt
+    log("headline batch independence (items of the timed batch vs B=16 forwards)")
+    indep = headline_independence(m3, vid, title, comments, B)
+    if not indep["ok"]:
+        raise SystemExit(f"bench.py: the headline batch does not reproduce its own items at B=16 within 1e-3: {json.dumps(indep)}")
 
     # instrumented steps: every launch bracketed by HIP events on the launch stream, towers back to back on ONE stream
     # (two kernels sharing the chip would each look slower)
@@ -647,6 +688,8 @@ def main():
         "kernel_ms_per_step": {k: round(v["ms"] / n_prof, 3) for k, v in tot.items() if v["launches"]},
         "region_ms_per_step": {r: round(sum(v[r]["ms"] for v in p_all.values()) / n_prof, 3) for r in L.PROF_REGIONS},
         "ms_per_step_with_events": round(1e3 * dt_instr / n_prof, 3),
+        "headline_batch_independence_max_err": indep["max_err"],
+        "headline_batch_independence": indep,
     }
     if rccl:
         result["rccl"] = rccl
@@ -719,6 +762,18 @@ def main():
         th1 = cgroup_throttle()
         out = dict(host=rep_stats(host_ms), gpu=rep_stats(gpu_ms), mine=mine, r_ab=r_ab, r_ba=r_ba)
         out["host"]["cgroup_throttled_periods"] = th1[0] - th0[0]       # host-side CFS throttling inside the timed repetitions (0 = clean)
+        # one more repetition with HIP events between the phases (all-gather / distance GEMM + selection / exchange / column
+        # selection / all-reduce), per rank: what a scaling line is read from
+        ph = {}
+        vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec, ws=ws, phases=ph)
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            allph = [None] * world
+            dist.all_gather_object(allph, ph)
+            out["phases"] = allph
+        else:
+            out["phases"] = [ph]
         if profile:
             # kernel classes of one more repetition (HIP events around every launch): the distance GEMM against the rest
             pt = class_totals(prof_regions(lambda: vdist.sharded_recall(va_l, tb_l, N, [1, 5, 10], rank, world, precision=prec, ws=ws),
@@ -743,6 +798,7 @@ def main():
                 result[f"sweep_{N}_ms"] = round(sw["host"]["median"], 3)
                 result[f"sweep_{N}_ms_stats"] = sw["host"]
                 result[f"sweep_{N}_gpu_ms_stats"] = sw["gpu"]
+                result[f"sweep_{N}_phases_ms_per_rank"] = sw["phases"]
                 # algorithmic HBM bytes with the fp32 matrix materialised: 8 N^2 per direction, whole job -- a
                 # CONVENTION (BASELINE's 60 % target is stated on it); the block-minima path moves far fewer bytes, and what
                 # binds it is the distance GEMM + its VALU epilogue: see sweep_N_roofline

@@ -7,14 +7,18 @@ import numpy as np
 SOT, EOT = 49406, 49407
 
 
-def pack_tokens(token_lists, max_len=77, sot=SOT, eot=EOT):
-    """:228-231 `[sot] + encode(text) + [eot]`; :233 zeros [n, max_len]; :236-243 a sequence with len >= max_len (after the
-    summarisation attempt, which this restatement does not model) becomes `tokens[: max_len - 1] + [eot]`; :244-247 otherwise
-    the ids followed by zeros."""
+def pack_tokens(token_lists, max_len=77, sot=SOT, eot=EOT, summarise=None):
+    """:228-231 `[sot] + encode(text) + [eot]`; :233 zeros [n, max_len]; :235-239 a sequence with len >= max_len is first
+    replaced by `[sot] + encode(" ".join(rake phrases of text i)) + [eot]` -- `summarise(i)` returns that re-encoding's ids (the
+    RAKE + BPE steps themselves are host text processing; None: no summariser, the ids stay); :240-243 if still >= max_len it
+    becomes `tokens[: max_len - 1] + [eot]`; :244-247 otherwise the ids followed by zeros."""
     out = np.zeros((len(token_lists), max_len), dtype=np.int64)
     for i, enc in enumerate(token_lists):
         tokens = [sot] + [int(t) for t in enc] + [eot]
         if len(tokens) >= max_len:
-            tokens = tokens[: max_len - 1] + [eot]
+            if summarise is not None:
+                tokens = [sot] + [int(t) for t in summarise(i)] + [eot]
+            if len(tokens) >= max_len:
+                tokens = tokens[: max_len - 1] + [eot]
         out[i, : len(tokens)] = tokens
     return out

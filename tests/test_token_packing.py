@@ -21,6 +21,19 @@ def test_oracle_packing_rules():
     # the text tower finds the EOT with argmax: it is the largest id and the first maximum of every row
     assert (out.argmax(-1) == np.array([7, 7])).all()
     assert TR.pack_tokens([[1]] * 3).shape == (3, 77) and TR.pack_tokens([[1]]).dtype == np.int64
+    # :235-239 an over-long text is first replaced by the re-encoded keyword summary (hook), and truncated only if still too long
+    summ = {1: [7, 8], 2: list(range(40, 60))}
+    out = TR.pack_tokens([[5], over, over], max_len=8, summarise=lambda i: summ[i])
+    assert out[0].tolist() == [TR.SOT, 5, TR.EOT, 0, 0, 0, 0, 0]
+    assert out[1].tolist() == [TR.SOT, 7, 8, TR.EOT, 0, 0, 0, 0]
+    assert out[2].tolist() == [TR.SOT] + summ[2][:6] + [TR.EOT]
+
+
+def test_pack_token_lists_flags_overlong_texts_without_a_summariser():
+    """silently truncating the original ids differs from the reference for texts that reach max_len."""
+    from vtc_amd.host import datasets as DS
+    with pytest.raises(ValueError, match="summaris"):
+        DS.pack_token_lists([[1, 2], list(range(1, 100))], max_len=77, device="cpu", strict=True)
 
 
 @pytest.mark.gpu
@@ -32,7 +45,11 @@ def test_pack_tokens_kernel_matches_the_oracle():
         lens = [0, 1, ctx - 3, ctx - 2, ctx - 1, ctx, 3 * ctx] + [int(v) for v in rng.integers(0, ctx + 5, size=200)]
         lists = [[int(v) for v in rng.integers(1, 49405, size=n)] for n in lens]
         want = TR.pack_tokens(lists, max_len=ctx)
-        got = DS.pack_token_lists(lists, max_len=ctx, device="cuda")
+        with pytest.warns(UserWarning, match="summaris"):
+            got = DS.pack_token_lists(lists, max_len=ctx, device="cuda")
+        summ = {i: [int(v) for v in rng.integers(1, 49405, size=int(rng.integers(0, ctx + 3)))] for i, t in enumerate(lists) if len(t) + 2 >= ctx}
+        got_s = DS.pack_token_lists(lists, max_len=ctx, device="cuda", summarise=lambda i: summ[i])
+        assert np.array_equal(got_s.cpu().numpy(), TR.pack_tokens(lists, max_len=ctx, summarise=lambda i: summ[i]))
         assert got.dtype == torch.int64 and got.is_cuda and np.array_equal(got.cpu().numpy(), want)
         # device-resident inputs through the op itself
         flat = torch.tensor([v for t in lists for v in t], dtype=torch.int32, device="cuda")

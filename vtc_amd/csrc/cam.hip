@@ -46,6 +46,7 @@ struct CamFusedParams {
   const float *fc_wf[CAM_MAX_LAYERS], *fc_s[CAM_MAX_LAYERS], *fc_c[CAM_MAX_LAYERS], *proj_w[CAM_MAX_LAYERS], *proj_b[CAM_MAX_LAYERS];
   float *x, *big, *att;       // residual stream [rows, D]; qkv [rows, 3 D] / MLP hidden [rows, 4 D] (never live together); attention output
   int *bar;                   // grid-barrier words (grid_barrier; CAM_BAR_BYTES, zeroed before the launch); bar[1]: error word
+  int *err_host;              // device-visible pinned host word (never reset): a barrier that gave up sets it, the next launch reports it
   unsigned long long *stamps; // diagnostics (VTC_CAM_STAMPS=1): s_memrealtime of workgroup 0 at the start and after every barrier; else NULL
   int act;
   float scale;
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(256, 1) void cam_fused_kernel(const CamFusedParams 
   // A grid barrier that gave up (bar[1], CAM_SPIN_LIMIT: this launch did not have the chip to itself for ~0.4 s) means rows of x
   // may be stale.  Fail LOUDLY: the items this wave owns come out as NaN, which no similarity, loss or R@K survives quietly.
   const bool dead = __hip_atomic_load(p.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  if (dead && p.err_host && threadIdx.x == 0) __hip_atomic_store(p.err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   for (int b = gw; b < p.B; b += TW) {
     if (dead) {
 #pragma unroll
@@ -534,8 +536,26 @@ int launch_cam_fused(const vtc_cam_w *w, const float *main_feats, const float *c
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
   std::lock_guard<std::mutex> lk(g_cam_mu);
+  // the error word of this device: pinned, device-visible, allocated once.  A grid barrier that gave up (the launch lost its
+  // residency guarantee: it cannot under a cooperative launch, so this is a defect report, not a mode) wrote NaN embeddings AND
+  // set this word; every later call on the device fails with a message instead of returning rc 0 beside NaN.
+  static int *err_words[64] = {};
+  if (!err_words[dev]) {
+    int *h = nullptr;
+    if (hipHostMalloc((void **)&h, 64, hipHostMallocMapped) != hipSuccess || !h) return -1;     // no error word: take the multi-launch path
+    *h = 0;
+    err_words[dev] = h;
+  }
+  VTC_CHECK(*(volatile int *)err_words[dev] == 0,
+            "cam_fused: an earlier one-launch CAM on device %d gave up at a grid barrier (its embeddings were written as NaN); "
+            "re-run with VTC_CAM_NO_FUSED in the model flags", dev);
   if (cam_fused_busy_locked(dev, stream)) return -1;
   CamFusedParams p;
+  {
+    void *dptr = nullptr;
+    if (hipHostGetDevicePointer(&dptr, err_words[dev], 0) != hipSuccess) return -1;
+    p.err_host = (int *)dptr;
+  }
   p.main_f = main_feats; p.comm = comm_feats; p.mask_emb = w->mask_embedding; p.comments = comments;
   p.B = B; p.nc = nc; p.ctx = ctx; p.Lc = 1 + nc; p.rows = B * (1 + nc); p.ntiles = cdiv(p.rows, 16); p.layers = w->layers; p.heads = w->heads;
   for (int l = 0; l < w->layers; ++l) {
@@ -554,19 +574,29 @@ int launch_cam_fused(const vtc_cam_w *w, const float *main_feats, const float *c
   p.act = w->residual_activation; p.scale = w->squash_scale; p.bn_mean = w->bn_mean; p.bn_var = w->bn_var;
   p.out = adapted;
   VTC_CHECK(hipMemsetAsync(bar, 0, CAM_BAR_BYTES, stream) == hipSuccess, "cam_fused: barrier reset failed");
-  // every workgroup must be resident for the grid barrier: one per CU (width 512: 136 KiB of LDS each, so exactly one fits)
+  // Every workgroup must be resident for the grid barrier: one per CU (width 512: 136 KiB of LDS each, so exactly one fits), and
+  // the launch is COOPERATIVE (hipLaunchCooperativeKernel): the runtime checks that the grid fits the device with this kernel's
+  // resources and orders cooperative grids among themselves, so no workgroup waits for one that cannot become resident because
+  // something else (a persistent GEMM on a side stream, RCCL, a CU mask) holds its CU.  A launch the
+  // runtime refuses (too large for the CUs this process may use) is not an error: -1 sends the caller down the multi-launch path.
   const int grid = vtcgemm::num_cus();
   ProfScope prof(VTC_PROF_GEMM_F32, 2.0 * p.rows * 12.0 * w->width * w->width * w->layers, stream);
+  void *kargs[] = {&p};
+  hipError_t le;
+  vtc_count_launch();
   if (w->width == 512) {
     constexpr int shmem = (4 * 16 * WLD<512> + 4 * 2 * 15 * 64) * 4;
     static PerDeviceOnce attr;
     if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&cam_fused_kernel<512>), shmem, "cam_fused")) return 1;
-    hipLaunchKernelGGL((cam_fused_kernel<512>), dim3(grid), dim3(256), shmem, stream, p);
+    le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&cam_fused_kernel<512>), dim3(grid), dim3(256), kargs, shmem, stream);
   } else {
     constexpr int shmem = (4 * 16 * WLD<128> + 4 * 2 * 15 * 64) * 4;
-    hipLaunchKernelGGL((cam_fused_kernel<128>), dim3(grid), dim3(256), shmem, stream, p);
+    le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&cam_fused_kernel<128>), dim3(grid), dim3(256), kargs, shmem, stream);
   }
-  VTC_LAUNCH_CHECK("cam_fused");
+  if (le != hipSuccess) {
+    (void)hipGetLastError();      // (the profiler then holds one empty record for this call)
+    return -1;
+  }
   cam_fused_mark_locked(dev, stream);
   if (want_stamps && stamps) {     // diagnostics: synchronises
     unsigned long long h[64];

@@ -46,6 +46,10 @@
 #endif
 #include "gemm_stamps.h"
 
+#ifndef VTC_GEMM_DEEP_DEFAULT
+#define VTC_GEMM_DEEP_DEFAULT 1     // the 256 x 256 kernel's LDS-DMA pipeline: 1 = deep (round 4), 0 = one quarter in flight (rounds 1-3)
+#endif
+
 using namespace vtcgemm;
 
 namespace {
@@ -832,16 +836,36 @@ __device__ __attribute__((noinline)) void fused_ln_rows(const float *out, int M,
 // in a quarter per phase with one quarter always in flight across the barriers (counted vmcnt, never 0).  Quadrant walk (0,0) (0,1) (1,1) (1,0): 12 / 4 / 8 / 4 fragment reads; a quarter is the
 // 128 activation rows or weight rows the next K-tile's phase needs first: A0, W0, W1, A1.
 // (structure after the 8-phase schedule of the CDNA HIP guide, section 5.)
-template <int MODE, typename OutT, typename T>
+//
+// DEEP (round 4) -- the same phases on a deeper LDS-DMA pipeline, after the guide's template ("three half-tiles in flight, counted
+// vmcnt once per K-tile"): a quarter is issued THREE to FIVE phases before the wait that retires it instead of one, so a quarter that
+// misses the L2 (every activation quarter's first touch does) no longer parks the workgroup.  With two stages the depth comes from
+// re-filling the stage that is being READ, quarter by quarter, as the walk frees it:
+//     K-tile t reads stage X (t even/odd), stage Y holds K-tile t+1:
+//       ph0: read A0, W0 (12)   issue QA(t+1) -> Y                  QA = W0 (DEEP 1) / W1 (DEEP 2)
+//       ph1: read W1 (4)        issue A1(t+1) -> Y   vmcnt(8): A1(t) has landed            [read in ph2]
+//       ph2: read A1 (8)        issue A0(t+2) -> X   (A0 of X: last read in ph0)
+//       ph3: DEEP 1: read W0 again (4), retired BEFORE the phase's first barrier; DEEP 2: W0 stays in registers, no read
+//                               issue QB(t+2) -> X   vmcnt(6): A0, QA, QB of K-tile t+1 have landed  [read in ph0 / ph1 of t+1]
+//     QB = W1 (DEEP 1: last read in ph1) / W0 (DEEP 2: last read in ph0).
+// Rules kept (guide 5, "Read a staged buffer one phase AFTER the wait that retires it"; WAR: "restage >= 2 phases after the last
+// ds_read, or 1 phase after when an lgkmcnt before the reading phase's first barrier retired those reads"): every wait sits before
+// the first barrier of its phase and its data is read in a later phase (the lagging half of the workgroup has then waited too);
+// every quarter is re-filled two phases after its last read (DEEP 1's W0: one phase, behind the early lgkmcnt of ph3).
+// Tile boundaries: the last K-tile of a tile issues nothing in ph2 / ph3 (its stage X is the epilogue's transposition scratch), and
+// the first K-tile of the next tile issues those two quarters on top of its own in ph0 / ph1 -- the in-order vmcnt counts come out
+// the same (8 and 6), plus the epilogue's NST stores in the relaxed first wait.
+template <int MODE, typename OutT, typename T, int DEEP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands (bf16 or IEEE half)");
+  static_assert(DEEP >= 0 && DEEP <= 2, "0 = one quarter in flight, 1 = deep (W0 re-read), 2 = deep (W0 kept in registers)");
   constexpr int WM = 2, WN = 4, TM = 8, TN = 4, NW = 8, BM = 256, BN = 256;
   if (p.epi.m_dev) {        // the row count lives in device memory (GemmEpi::m_dev): the grid was sized for the host's upper bound
     p.M = *p.epi.m_dev;
     p.MT = (p.M + BM - 1) / BM;
   }
   constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;
-  constexpr int SUPER = SUPER_ROWS / BM;
+  const int SUPER = p.super_tiles > 0 ? p.super_tiles : SUPER_ROWS / BM;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
@@ -991,6 +1015,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   }
 
   u32x4 aS[4][2], wS[2][2];     // register subtile: 4 activation x 2 weight fragments x 2 K halves
+  [[maybe_unused]] u32x4 wD[DEEP == 2 ? 2 : 1][2][2];   // the deep variants' weight fragments (DEEP 2: W0 and W1 apart)
   bool relax_first = false;     // the previous tile's epilogue issued exactly NST stores last (see the phase-end wait)
   VTC_STAMP_INIT();
   while (true) {
@@ -1006,64 +1031,138 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
 
     for (int t = 0; t < ksteps; ++t) {
       const unsigned st_cur = lds_base + cur * STAGE, st_nxt = lds_base + (cur ^ 1) * STAGE;
-      // what streams in during this K-tile: K-tile t+1 of this tile, or K-tile 0 of the next tile (when this is
-      // the workgroup's last tile: K-tile 0 of this one again, into the stage nobody reads any more)
-      const int kn = t + 1;
-      const bool to_next = kn == ksteps && has_next;
-      const int sm = to_next ? m0n : m0, sn = to_next ? n0n : n0, kk = kn < ksteps ? kn : 0;
-      const bool fastA = sm + BM <= p.M, fastW = sn + BN <= p.N;
-      if constexpr (CAN_GATHER) {
-        if (gather && to_next) gather_offsets(m0n);     // from here on the next tile's K-tile 0 streams in
+      if constexpr (DEEP == 0) {
+        // what streams in during this K-tile: K-tile t+1 of this tile, or K-tile 0 of the next tile (when this is
+        // the workgroup's last tile: K-tile 0 of this one again, into the stage nobody reads any more)
+        const int kn = t + 1;
+        const bool to_next = kn == ksteps && has_next;
+        const int sm = to_next ? m0n : m0, sn = to_next ? n0n : n0, kk = kn < ksteps ? kn : 0;
+        const bool fastA = sm + BM <= p.M, fastW = sn + BN <= p.N;
+        if constexpr (CAN_GATHER) {
+          if (gather && to_next) gather_offsets(m0n);     // from here on the next tile's K-tile 0 streams in
+        }
+        static_for<4>([&](auto ph_c) __attribute__((always_inline)) {
+          constexpr int ph = decltype(ph_c)::value;
+          constexpr int qm = ph >> 1, qn = (ph == 1 || ph == 2) ? 1 : 0;
+          // (a) this quadrant's new fragments (published by the wait + barrier that ended the previous phase)
+          if constexpr (ph != 2) {
+  #pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              lds_read16(wS[j][0], st_cur + w_rd + coff0, (qn * 2 + j) * 16 * ROWB);
+              lds_read16(wS[j][1], st_cur + w_rd + coff1, (qn * 2 + j) * 16 * ROWB);
+            }
+          }
+          if constexpr (ph == 0 || ph == 2) {
+  #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              lds_read16(aS[i][0], st_cur + a_rd + coff0, (qm * 4 + i) * 16 * ROWB);
+              lds_read16(aS[i][1], st_cur + a_rd + coff1, (qm * 4 + i) * 16 * ROWB);
+            }
+          }
+          // (b) one quarter of the next K-tile
+          stage_quarter(ph, sm, sn, kk, st_nxt, fastA, fastW);
+          // (c) everybody has issued; the reads land while we wait here
+          __builtin_amdgcn_s_barrier();
+          lgkm_wait_subtile(aS, wS);
+          // (d) the MFMA cluster
+          __builtin_amdgcn_s_setprio(1);
+  #pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+  #pragma unroll
+            for (int i = 0; i < 4; ++i)
+  #pragma unroll
+              for (int j = 0; j < 2; ++j) Mma<T>::run(wS[j][ks], aS[i][ks], acc[qm * 4 + i][qn * 2 + j]);
+          __builtin_amdgcn_s_setprio(0);
+          // (e) my pieces of every quarter but the newest have landed; the barrier makes that everybody's.  A
+          //     quarter is read three phases after its issue at the earliest, and the half of the workgroup that runs
+          //     one barrier ahead must not read what the other half has not waited for yet: hence one phase early.
+          // First K-tile after an (interior) epilogue: the wave's NST epilogue stores are older than this K-tile's
+          // pieces in the in-order vmcnt queue, and a plain vmcnt(2) here would park the wave until they are all
+          // acknowledged.  Nothing issued after them is needed before the end of phase 2 (quarter A0 has one phase of
+          // slack in the steady-state schedule: issued in phase 0, read after the barrier that ends phase 3, which the
+          // lagging half reaches with its waits up to phase 2 done), so phases 0 and 1 leave the stores -- and the
+          // quarters issued since -- in flight and only make sure of everything OLDER than the stores.
+          constexpr int NST = TM * (sizeof(OutT) == 2 ? 2 : 4);   // 16-byte stores per wave in tile_epilogue's fast paths (its LAST vm ops)
+          if (ph < 2 && t == 0 && relax_first) {
+            if constexpr (ph == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");
+          } else
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        });
+      } else {
+        // ---- deep pipeline (see the kernel's header comment) ----
+        constexpr int QA = DEEP == 2 ? 2 : 1, QB = DEEP == 2 ? 1 : 2;     // quarter ids: 0 = A0, 1 = W0, 2 = W1, 3 = A1
+        constexpr int NST = TM * (sizeof(OutT) == 2 ? 2 : 4);             // 16-byte stores per wave in tile_epilogue's fast paths (its LAST vm ops)
+        const bool first = t == 0, last = t == ksteps - 1;                // of this tile (ksteps >= 2: never both)
+        // K-tile t+1 (-> st_nxt): of this tile, or K-tile 0 of the next tile (no next tile: K-tile 0 of this one again, into a stage
+        // nobody reads any more -- the counted waits stay uniform)
+        const bool nx1 = t + 1 == ksteps && has_next;
+        const int sm1 = nx1 ? m0n : m0, sn1 = nx1 ? n0n : n0, kk1 = t + 1 < ksteps ? t + 1 : 0;
+        const bool fA1 = sm1 + BM <= p.M, fW1 = sn1 + BN <= p.N;
+        // K-tile t+2 (-> st_cur, behind this K-tile's reads); t = ksteps - 2: K-tile 0 of the next tile; t = ksteps - 1: nothing
+        const bool nx2 = t + 2 >= ksteps && has_next;
+        const int sm2 = nx2 ? m0n : m0, sn2 = nx2 ? n0n : n0, kk2 = t + 2 < ksteps ? t + 2 : 0;
+        const bool fA2 = sm2 + BM <= p.M, fW2 = sn2 + BN <= p.N;
+        static_for<4>([&](auto ph_c) __attribute__((always_inline)) {
+          constexpr int ph = decltype(ph_c)::value;
+          constexpr int qm = ph >> 1, qn = (ph == 1 || ph == 2) ? 1 : 0;
+          constexpr int wreg = DEEP == 2 ? qn : 0;                        // DEEP 2: W0 and W1 live in registers of their own
+          // (a) this quadrant's new fragments
+          if constexpr (ph == 0 || ph == 1 || (ph == 3 && DEEP == 1)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              lds_read16(wD[wreg][j][0], st_cur + w_rd + coff0, (qn * 2 + j) * 16 * ROWB);
+              lds_read16(wD[wreg][j][1], st_cur + w_rd + coff1, (qn * 2 + j) * 16 * ROWB);
+            }
+          }
+          if constexpr (ph == 0 || ph == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              lds_read16(aS[i][0], st_cur + a_rd + coff0, (qm * 4 + i) * 16 * ROWB);
+              lds_read16(aS[i][1], st_cur + a_rd + coff1, (qm * 4 + i) * 16 * ROWB);
+            }
+          }
+          // (b) this phase's quarter(s); (c) the counted waits, BEFORE the phase's first barrier (their data is read in a later phase)
+          if constexpr (ph == 0) {
+            stage_quarter(QA, sm1, sn1, kk1, st_nxt, fA1, fW1);
+            if (first) stage_quarter(0, sm1, sn1, kk1, st_nxt, fA1, fW1);        // A0 of K-tile 1: the previous tile's ph2 did not issue it
+          } else if constexpr (ph == 1) {
+            if (first) stage_quarter(QB, sm1, sn1, kk1, st_nxt, fA1, fW1);       // ... nor QB in its ph3 (QB before A1: ph3's count)
+            stage_quarter(3, sm1, sn1, kk1, st_nxt, fA1, fW1);
+            // A1 of THIS K-tile (issued four quarters ago) has landed.  First K-tile after an interior epilogue: its NST stores sit
+            // between A1 and this K-tile's quarters in the in-order queue, and nothing younger than them is needed yet.
+            if (first && relax_first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          } else if constexpr (ph == 2) {
+            if (!last) {
+              if constexpr (CAN_GATHER) {
+                if (gather && nx2 && t + 2 == ksteps) gather_offsets(m0n);       // every activation quarter from here on is the next tile's
+              }
+              stage_quarter(0, sm2, sn2, kk2, st_cur, fA2, fW2);
+            }
+          } else {
+            if (!last) stage_quarter(QB, sm2, sn2, kk2, st_cur, fA2, fW2);
+            if constexpr (DEEP == 1) lgkm_wait_w4(wD[0]);                         // W0's second read retired before the barrier: re-filled next phase
+            // A0, QA, QB of K-tile t+1 have landed (A1 and this K-tile's two quarters stay in flight)
+            if (last) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          }
+          __builtin_amdgcn_s_barrier();
+          lgkm_wait_subtile(aS, wD[0]);
+          if constexpr (DEEP == 2) lgkm_wait_w4(wD[1]);
+          // (d) the MFMA cluster
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) Mma<T>::run(wD[wreg][j][ks], aS[i][ks], acc[qm * 4 + i][qn * 2 + j]);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_s_barrier();
+        });
       }
-      static_for<4>([&](auto ph_c) __attribute__((always_inline)) {
-        constexpr int ph = decltype(ph_c)::value;
-        constexpr int qm = ph >> 1, qn = (ph == 1 || ph == 2) ? 1 : 0;
-        // (a) this quadrant's new fragments (published by the wait + barrier that ended the previous phase)
-        if constexpr (ph != 2) {
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            lds_read16(wS[j][0], st_cur + w_rd + coff0, (qn * 2 + j) * 16 * ROWB);
-            lds_read16(wS[j][1], st_cur + w_rd + coff1, (qn * 2 + j) * 16 * ROWB);
-          }
-        }
-        if constexpr (ph == 0 || ph == 2) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            lds_read16(aS[i][0], st_cur + a_rd + coff0, (qm * 4 + i) * 16 * ROWB);
-            lds_read16(aS[i][1], st_cur + a_rd + coff1, (qm * 4 + i) * 16 * ROWB);
-          }
-        }
-        // (b) one quarter of the next K-tile
-        stage_quarter(ph, sm, sn, kk, st_nxt, fastA, fastW);
-        // (c) everybody has issued; the reads land while we wait here
-        __builtin_amdgcn_s_barrier();
-        lgkm_wait_subtile(aS, wS);
-        // (d) the MFMA cluster
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) Mma<T>::run(wS[j][ks], aS[i][ks], acc[qm * 4 + i][qn * 2 + j]);
-        __builtin_amdgcn_s_setprio(0);
-        // (e) my pieces of every quarter but the newest have landed; the barrier makes that everybody's.  A
-        //     quarter is read three phases after its issue at the earliest, and the half of the workgroup that runs
-        //     one barrier ahead must not read what the other half has not waited for yet: hence one phase early.
-        // First K-tile after an (interior) epilogue: the wave's NST epilogue stores are older than this K-tile's
-        // pieces in the in-order vmcnt queue, and a plain vmcnt(2) here would park the wave until they are all
-        // acknowledged.  Nothing issued after them is needed before the end of phase 2 (quarter A0 has one phase of
-        // slack in the steady-state schedule: issued in phase 0, read after the barrier that ends phase 3, which the
-        // lagging half reaches with its waits up to phase 2 done), so phases 0 and 1 leave the stores -- and the
-        // quarters issued since -- in flight and only make sure of everything OLDER than the stores.
-        constexpr int NST = TM * (sizeof(OutT) == 2 ? 2 : 4);   // 16-byte stores per wave in tile_epilogue's fast paths (its LAST vm ops)
-        if (ph < 2 && t == 0 && relax_first) {
-          if constexpr (ph == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NST) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");
-        } else
-          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      });
       cur ^= 1;
     }
     VTC_STAMP(0);       // K loop (incl. the stagger barrier)
@@ -1124,19 +1223,35 @@ int run(GemmParams p, hipStream_t stream) {
   return 0;
 }
 
-template <int MODE, typename OutT, typename T>
-int run_phased(GemmParams p, hipStream_t stream) {
+int g_deep = VTC_GEMM_DEEP_DEFAULT;   // pipeline depth of the 256 x 256 kernel: 0 = one quarter in flight (rounds 1-3), 1 / 2 = deep (VTC_GEMM_DEEP)
+
+template <int MODE, typename OutT, typename T, int DEEP>
+int run_phased_d(GemmParams p, hipStream_t stream) {
   p.MT = cdiv(p.M, 256); p.NT = cdiv(p.N, 256);
   const int ntiles = p.MT * p.NT;
   const size_t shmem = (size_t)2 * 512 * ROWB + (MODE == EPI_RESID_LN ? 16 : 0);   // 128 KiB: one workgroup per CU (+ the ticket word)
   const int grid = min(ntiles, num_cus());
   static PerDeviceOnce attr;
-  if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&gemm_phased_kernel<MODE, OutT, T>), (int)shmem, "gemm_phased")) return 1;
+  if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&gemm_phased_kernel<MODE, OutT, T, DEEP>), (int)shmem, "gemm_phased")) return 1;
   VTC_STAMP_HOST_BEFORE(p, stream);
-  hipLaunchKernelGGL((gemm_phased_kernel<MODE, OutT, T>), dim3(grid), dim3(512), shmem, stream, p);
+  hipLaunchKernelGGL((gemm_phased_kernel<MODE, OutT, T, DEEP>), dim3(grid), dim3(512), shmem, stream, p);
   VTC_STAMP_HOST_AFTER(p, stream, grid, MODE);
   VTC_LAUNCH_CHECK("gemm_phased");
   return 0;
+}
+template <int MODE, typename OutT, typename T>
+int run_phased(const GemmParams &p, hipStream_t stream) {
+  // the deep pipeline needs two K-tiles per tile; the fused-LayerNorm tail and the sweep's block-minima epilogue stay on the
+  // round-3 loop (their register budgets are the tightest of all instantiations)
+  if constexpr (MODE != EPI_RESID_LN && MODE != EPI_L2MIN) {
+    if (p.K >= 128) {
+      if (g_deep == 1) return run_phased_d<MODE, OutT, T, 1>(p, stream);
+#ifdef VTC_GEMM_DEEP2
+      if (g_deep == 2) return run_phased_d<MODE, OutT, T, 2>(p, stream);
+#endif
+    }
+  }
+  return run_phased_d<MODE, OutT, T, 0>(p, stream);
 }
 
 int g_resid_small_k = 0; // residual epilogues with K <= this take the 128 x 128 kernel (two workgroups per CU: one's epilogue under the other's K loop); 0 = heuristic only (VTC_GEMM_RESID_SMALL_K)
@@ -1269,17 +1384,20 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
               "gemm: folded LayerNorm arguments do not go with epilogue %d", epi.mode);
   }
   // diagnostics knobs, read once (C++11 static initialisation is thread-safe; never written afterwards)
-  struct Env { int tile = 0, sg = 0, st = 0, cg = -1, rsk = 0; };
+  struct Env { int tile = 0, sg = 0, st = 0, cg = -1, rsk = 0, deep = VTC_GEMM_DEEP_DEFAULT, super = 0; };
   static const Env env = [] {
     Env v;
     if (const char *e = getenv("VTC_GEMM_TILE")) v.tile = atoi(e);
     if (const char *e = getenv("VTC_GEMM_CG")) v.cg = atoi(e);
+    if (const char *e = getenv("VTC_GEMM_DEEP")) v.deep = atoi(e);
+    if (const char *e = getenv("VTC_GEMM_SUPER")) v.super = atoi(e);
     if (const char *e = getenv("VTC_GEMM_RESID_SMALL_K")) v.rsk = atoi(e);
     if (const char *e = getenv("VTC_GEMM_STAGGER")) sscanf(e, "%d,%d", &v.sg, &v.st);
     return v;
   }();
   g_force_tile = env.tile;
   g_resid_small_k = env.rsk;
+  g_deep = env.deep;
   GemmParams p;
   p.A = (const char *)A; p.W = (const char *)W; p.bias = bias; p.out = out;
   p.M = M; p.N = N; p.K = K;
@@ -1287,6 +1405,7 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
   p.ldo = epi.ldo > 0 ? epi.ldo : N;
   p.MT = 0; p.NT = 0;
   p.col_group = env.cg >= 0 ? env.cg : 0;
+  p.super_tiles = env.super;
   p.stagger_groups = env.sg; p.stagger_ticks = env.st;
   p.epi = epi;
   ProfScope prof(dtype != VTC_F32 ? VTC_PROF_GEMM_BF16 : VTC_PROF_GEMM_F32, epi.m_dev ? 2.0 * N * K : 2.0 * M * N * K, stream,

@@ -56,6 +56,7 @@ struct GemmParams {
   int lda_bytes, ldw_bytes, ldo;
   int MT, NT;
   int col_group;   // phased kernel: column tiles per group of the tile walk (0 = all NT columns in one group)
+  int super_tiles; // phased kernel: row tiles per super-row of the tile walk (0 = SUPER_ROWS / 256)
   int stagger_groups, stagger_ticks;   // phased kernel: workgroup (slot % groups) starts (slot % groups) * ticks x 10 ns late
 #ifdef VTC_GEMM_STAMPS
   unsigned long long *dbg;   // diagnostic build: per-wave phase cycle sums
@@ -113,6 +114,11 @@ __device__ __forceinline__ void lgkm_wait_subtile(u32x4 (&a)[4][2], u32x4 (&w)[2
   asm volatile("s_waitcnt lgkmcnt(0)"
                : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]),
                  "+v"(a[3][1]), "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
+}
+
+// four weight fragments (one 32-column half x two K halves) have landed
+__device__ __forceinline__ void lgkm_wait_w4(u32x4 (&w)[2][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]));
 }
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})

@@ -364,6 +364,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
   const int P = w->grid * w->grid, T = 1 + P * F, W = w->width;
   VTC_CHECK(1 + P <= 80 && F < 80, "vision_forward: sequence too long (1+P=%d, F=%d)", 1 + P, F);
   VTC_CHECK(w->variant == 0 || w->variant == 1, "vision_forward: unknown variant %d", w->variant);
+  VTC_CHECK(!(w->variant == 1 && w->nframes == 0), "vision_forward: variant 1 (model/timesformer_clip.py) is a video tower: nframes must be > 0");
   const int rows = n_items * T, res = w->grid * w->patch;
   VisionWs v = plan_vision(w, n_items, F, dtype, ws);
   VTC_CHECK(ws_bytes >= v.total, "vision_forward: workspace too small (%zu < %zu)", ws_bytes, v.total);

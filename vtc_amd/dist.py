@@ -94,30 +94,39 @@ def sweep_path(n_total: int, precision: int, world: int, depth: int = 11) -> str
     return "one distance matrix, row + column top-k" if one else "two searches per rank ([N/G, N] blocks)"
 
 
+A2A_MODE = os.environ.get("VTC_A2A", "single")     # "single": one all_to_all_single on a padded [G, 4, nblk, max shard] buffer; "list": all_to_all on per-rank slices
+
+
 def exchange_column_planes(planes: torch.Tensor, n_total: int, rank: int, world: int) -> torch.Tensor:
     """planes [4, nblk_pad, n_total] of this rank's rows -> [world, 4, nblk_pad, n_local]: what every rank (in rank order)
-    holds for THIS rank's columns.  RCCL: one all_to_all; gloo (tests): point-to-point sends."""
+    holds for THIS rank's columns.  One equal-split all_to_all_single (shards differ by at most one column: the buffer is
+    padded to the largest) -- the collective form RCCL and gloo both implement; gloo (tests, one-card rehearsals) has no
+    device-memory transport, so there the buffer is staged through host memory."""
     bounds = [shard_bounds(n_total, r, world) for r in range(world)]
     lo, hi = bounds[rank]
-    send = [planes[:, :, a:b].contiguous() for a, b in bounds]
-    recv = planes.new_empty(world, planes.shape[0], planes.shape[1], hi - lo)
-    if dist.get_backend() == "nccl":
+    mx = max(b - a for a, b in bounds)
+    P, NB = planes.shape[0], planes.shape[1]
+    nccl = dist.get_backend() == "nccl"
+    if A2A_MODE == "list" and nccl:
+        send = [planes[:, :, a:b].contiguous() for a, b in bounds]
+        recv = planes.new_empty(world, P, NB, hi - lo)
         dist.all_to_all(list(recv.unbind(0)), send)
+        return recv
+    if all(b - a == mx for a, b in bounds):
+        send = planes.reshape(P, NB, world, mx).permute(2, 0, 1, 3).contiguous()
     else:
-        # gloo has no all_to_all and no device-memory send/recv: point-to-point, staged through host memory (tests, rehearsals)
-        host = [t.cpu() for t in send]
-        got = [torch.empty(recv.shape[1:], dtype=recv.dtype) for _ in range(world)]
-        ops_ = []
-        for r in range(world):
-            if r != rank:
-                ops_.append(dist.P2POp(dist.isend, host[r], r))
-                ops_.append(dist.P2POp(dist.irecv, got[r], r))
-        for w in dist.batch_isend_irecv(ops_):
-            w.wait()
-        got[rank] = host[rank]
-        for r in range(world):
-            recv[r].copy_(got[r])
-    return recv
+        send = planes.new_zeros(world, P, NB, mx)
+        for r, (a, b) in enumerate(bounds):
+            send[r, :, :, : b - a].copy_(planes[:, :, a:b])
+    if nccl:
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send)
+    else:
+        host = send.cpu()
+        got = torch.empty_like(host)
+        dist.all_to_all_single(got, host)
+        recv = got.to(planes.device)
+    return recv if hi - lo == mx else recv[..., : hi - lo].contiguous()
 
 
 def sweep_workspace_bytes(n_total: int, n_local: int, d: int, precision: int, world: int) -> int:
@@ -137,15 +146,27 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
                    topk: Optional[Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor]] = None,
                    precision: int = 3,    # _lib.SWEEP_EXACT
                    ws: Optional[torch.Tensor] = None,
-                   shard_ops: Optional[tuple] = None):
+                   shard_ops: Optional[tuple] = None,
+                   phases: Optional[dict] = None):
     """R@K both directions for row-sharded embeddings.
 
     Returns ({k: recall b_from_a-direction as RecallAtK.compute(a, b)}, {k: compute(b, a)}).
     ``topk(gallery, queries, depth) -> ids`` defaults to the HIP sweep; tests inject a CPU one to
     exercise the sharding logic under gloo.  ``ws``: a caller-owned uint8 workspace reused across calls (grown by the
     ops layer when too small).  ``shard_ops = (rows_fn, cols_fn, row_block)``: stand-ins for ops.sweep_shard_rows /
-    ops.sweep_shard_cols (tests: the one-GEMM-per-rank exchange under gloo)."""
+    ops.sweep_shard_cols (tests: the one-GEMM-per-rank exchange under gloo).  ``phases``: a dict that receives this rank's
+    GPU time per phase in ms (HIP events on the launch stream: allgather / rows_gemm_select / alltoall / cols_select /
+    search_a / search_b / hits / allreduce) and the path taken -- what a scaling run is read from."""
     lo, hi = shard_bounds(n_total, rank, world)
+    marks = []
+
+    def mark(name):
+        if phases is not None and feats_a_local.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((name, e))
+
+    mark("start")
     assert feats_a_local.shape[0] == hi - lo and feats_b_local.shape[0] == hi - lo
     if world > 1 and feats_a_local.shape[1] == feats_b_local.shape[1] and feats_a_local.dtype == feats_b_local.dtype:
         # ONE exchange for both embedding sets ([n_r, 2D] rows): at 10k x 512 the all-gather is latency-bound, a second
@@ -156,6 +177,7 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
     else:
         a_all = all_gather_rows(feats_a_local, n_total, rank, world)
         b_all = all_gather_rows(feats_b_local, n_total, rank, world)
+    mark("allgather")
     depth = min(int(max(k_vals)) + 1, n_total)
     hip_sweep = topk is None
     if topk is None:
@@ -172,6 +194,7 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
         from . import ops
         i1, _, i2, _ = ops.l2_topk_bidir(a_all, b_all, depth, precision=precision, return_dists=False, ws=ws)
         both = (i1, i2)
+        mark("bidir_gemm_select")
     if both is None and world > 1 and (shard_ops is not None or (hip_sweep and one_matrix_sharded(n_total, precision, world, depth))):
         # one [N/G, N] GEMM per rank: rows finished locally, column block minima to the column owners
         if shard_ops is None:
@@ -182,13 +205,21 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
         bounds = [shard_bounds(n_total, r, world) for r in range(world)]
         nblk_pad = -(-max(h - l for l, h in bounds) // rb)
         i1, planes = rows_fn(a_all, feats_b_local, depth, nblk_pad)          # gallery a, queries b: this rank's b rows
+        mark("rows_gemm_select")
         recv = exchange_column_planes(planes, n_total, rank, world)
+        mark("alltoall")
         src_base = torch.tensor([l for l, _ in bounds], dtype=torch.int32, device=planes.device)
         i2 = cols_fn(b_all, feats_a_local, depth, recv, src_base)            # gallery b, queries a: this rank's a rows
         both = (i1, i2)
+        mark("cols_select")
+        if phases is not None:
+            phases["exchange"] = (f"all_to_all{'' if A2A_MODE == 'list' else '_single'} (RCCL)" if dist.get_backend() == "nccl"
+                                  else f"all_to_all_single through host memory ({dist.get_backend()})")
     # compute(a, b): gallery a, queries b (model/metric.py:137-146); this rank owns query rows [lo, hi)
     for d_, (gal, qry) in enumerate(((a_all, feats_b_local), (b_all, feats_a_local))):
         ids = both[d_] if both is not None else topk(gal, qry, depth)
+        if both is None:
+            mark("search_b_from_a" if d_ == 0 else "search_a_from_b")
         if ids.is_cuda and len(ks) <= 4:
             from . import ops
             ops.recall_hits(ids, ks, target_offset=lo, hits=hits[d_])
@@ -196,9 +227,15 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
             tgt = torch.arange(lo, hi, device=ids.device)[:, None]
             for j, k in enumerate(ks):
                 hits[d_, j] = (ids[:, :k] == tgt).any(dim=1).sum()
+    mark("hits")
     if world > 1:
         dist.all_reduce(hits, op=dist.ReduceOp.SUM)
+        mark("allreduce")
     hits = hits.cpu()
+    if marks:
+        for (_, e0), (name, e1) in zip(marks, marks[1:]):
+            phases[name + "_ms"] = round(phases.get(name + "_ms", 0.0) + e0.elapsed_time(e1), 4)
+        phases["path"] = sweep_path(n_total, precision, world, depth) if hip_sweep else "injected top-k"
     r_ab = {k: hits[0, j].item() / n_total for j, k in enumerate(k_vals)}
     r_ba = {k: hits[1, j].item() / n_total for j, k in enumerate(k_vals)}
     return r_ab, r_ba

@@ -24,12 +24,29 @@ from torch.utils.data import Dataset
 SOT, EOT = 49406, 49407
 
 
-def pack_token_lists(token_lists, max_len=77, device=None):
+def pack_token_lists(token_lists, max_len=77, device=None, summarise=None, strict=False):
     """The array-building half of the reference's `_tokenise` (dataset_loaders/dataset_loaders.py:224-248) on the GPU: one list of
     BPE ids per text (the encoder's output; the encoder itself and the RAKE summariser stay host text processing) -> ids
-    [n, max_len] int64 on `device`, as `PretrainedCLIP*.forward` takes them.  One ragged H2D copy + one kernel."""
+    [n, max_len] int64 on `device`, as `PretrainedCLIP*.forward` takes them.  One ragged H2D copy + one kernel.
+
+    Over-long texts (`len(ids) + 2 >= max_len`): the reference first re-encodes the RAKE keyword summary of the text and truncates
+    only if that is still too long (:235-243).  `summarise(i) -> ids` is the caller's hook for that step (RAKE + BPE of text i);
+    without one the ORIGINAL ids are truncated, which differs from the reference for such texts -- a warning says so (`strict`:
+    an exception instead)."""
     from .. import ops
     device = torch.device(device if device is not None else "cuda")
+    over = [i for i, t in enumerate(token_lists) if len(t) + 2 >= max_len]
+    if over and summarise is not None:
+        token_lists = list(token_lists)
+        for i in over:
+            token_lists[i] = list(summarise(i))
+    elif over:
+        msg = (f"pack_token_lists: {len(over)} text(s) reach max_len={max_len} (first: index {over[0]}); the reference summarises such "
+               "texts with RAKE before truncating (dataset_loaders.py:235-243) -- pass summarise=, or the ids differ from the reference's")
+        if strict:
+            raise ValueError(msg)
+        import warnings
+        warnings.warn(msg, stacklevel=2)
     lens = torch.tensor([len(t) for t in token_lists], dtype=torch.int32)
     offsets = torch.zeros(len(token_lists) + 1, dtype=torch.int32)
     offsets[1:] = torch.cumsum(lens, 0)

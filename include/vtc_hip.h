@@ -94,7 +94,8 @@ typedef struct {
   int flags;                      /* VTC_TOWER_* (below): per-model choices of the kernel path, same results            */
   float pix_mean[3], pix_std[3];  /* pixel_dtype VTC_U8: x = (u8/255 - mean[c]) / std[c], i.e. ToTensor + Normalize of
                                      CLIP_TRANSFORM (dataset_loaders/dataset_loaders.py:40-49) fused into the patch gather */
-  const void  *conv_w;            /* conv1.weight flattened [W, 3*patch*patch]            */
+  const void  *conv_w;            /* conv1.weight flattened [W, Kp], Kp = 3*patch*patch rounded up to a multiple of 64 (zero-padded
+                                     columns: patch 14 -> 588 -> 640; patch 16 / 32 unchanged)   */
   const float *class_embedding;   /* [W]                                                  */
   const float *pos;               /* positional_embedding [1+grid*grid, W]                */
   const float *temporal;          /* temporal_embed [nframes, W] or NULL                  */

@@ -50,6 +50,10 @@ class ClipArch:
 
 # ViT-B/32: model/timesformer_clip_alt.py:290-296 + upstream CLIP defaults.
 VIT_B32 = ClipArch()
+# ViT-B/16 and ViT-L/14: model/timesformer_clip_alt.py:297-310 (197 / 257 tokens per frame; upstream text towers 512 x 8 / 768 x 12).
+VIT_B16 = ClipArch(vision_patch_size=16)
+VIT_L14 = ClipArch(embed_dim=768, vision_layers=24, vision_width=1024, vision_patch_size=14,
+                   transformer_width=768, transformer_heads=12)
 # A small architecture with the same structure, for second-scale oracle cases.
 # head_dim stays 64 (upstream: heads = width // 64); EOT stays 49407 because
 # model/model.py:208 hard-codes it, so the vocabulary keeps its real size.

@@ -49,7 +49,7 @@ def save(name, case, **arrays):
 
 
 def arch_of(name):
-    return {"TINY": A.TINY, "VIT_B32": A.VIT_B32}[name]
+    return {"TINY": A.TINY, "VIT_B32": A.VIT_B32, "VIT_B16": A.VIT_B16, "VIT_L14": A.VIT_L14}[name]
 
 
 def visual_tower(variant, arch_name, nframes, B, wseed, xseed):
@@ -69,6 +69,14 @@ def gen_towers():
             case = dict(kind="visual_tower", variant=variant, arch=arch_name, nframes=F_, B=B, wseed=11, xseed=12)
             save(f"tower_{variant}_{arch_name.lower()}_f{F_}", case,
                  out=visual_tower(variant, arch_name, F_, B, 11, 12))
+
+
+def gen_towers_b16_l14():
+    """The other two model types of make_timesformer_clip_vit_alt (model/timesformer_clip_alt.py:297-310): 197 and 257 tokens per
+    frame (space attention beyond 80 keys), patch 16 and 14 (K = 768 / 588), width 1024 x 24 layers."""
+    for arch_name in ("VIT_B16", "VIT_L14"):
+        case = dict(kind="visual_tower", variant="alt", arch=arch_name, nframes=2, B=1, wseed=11, xseed=12)
+        save(f"tower_alt_{arch_name.lower()}_f2", case, out=visual_tower("alt", arch_name, 2, 1, 11, 12))
 
 
 def build_wrapper(kind, arch_name, seed, **kw):
@@ -197,6 +205,7 @@ if __name__ == "__main__":
         sys.exit(0)
     gen_loss()
     gen_towers()
+    gen_towers_b16_l14()
     gen_cam_at_init()
     gen_wrappers()
     gen_train_step()

@@ -104,6 +104,32 @@ def test_attention_contiguous(dtype, L_, causal):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("L_,causal", [(81, False), (96, True), (129, True), (197, False), (257, False), (272, True)])
+def test_attention_long_sequences_tiled(dtype, L_, causal):
+    """80 < L <= 272 (ViT-B/16: 197, ViT-L/14: 257 tokens per frame): the K/V-tiled online-softmax kernel against
+    softmax(q k^T / 8 [+ causal]) v in fp32 on the same (rounded) operands; sequence lengths on and off the 16- and 64-key grids."""
+    L, ops = _ops()
+    heads, n_seq = 2, 3
+    W = heads * 64
+    g = torch.Generator().manual_seed(L_)
+    qkv = torch.randn(n_seq * L_, 3 * W, generator=g) * 1.5          # scores with a real spread: the running maximum moves
+    qd = qkv.cuda().to(dtype)
+    q, k, v = qd.float().cpu().reshape(n_seq, L_, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = ref_attention(q, k, v, causal).permute(0, 2, 1, 3).reshape(n_seq * L_, W)
+    out = ops.attention(qd, n_seq, L_, heads, causal=causal).float().cpu()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max() < tol, float((out - ref).abs().max())
+
+
+def test_attention_rejects_sequences_beyond_the_tiled_kernel():
+    L, ops = _ops()
+    qd = torch.zeros(273, 3 * 64, device="cuda")
+    with pytest.raises(RuntimeError, match="272"):
+        ops.attention(qd, 1, 273, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_single_query_attention_vs_fp32_reference(dtype):
     """vtc_single_query_attention (the last block's attention): one projected query per sequence over the keys / values of
     the packed qkv buffer -- contiguous sequences (image tower), the space branch's [cls, frame patches] map with the query shared by

@@ -18,7 +18,7 @@ from oracle import timesformer_ref as T
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
-ARCH = {"TINY": A.TINY, "VIT_B32": A.VIT_B32}
+ARCH = {"TINY": A.TINY, "VIT_B32": A.VIT_B32, "VIT_B16": A.VIT_B16, "VIT_L14": A.VIT_L14}
 DTYPES = [torch.float32, torch.bfloat16]
 
 
@@ -811,3 +811,49 @@ def test_one_launch_cam_from_two_streams_at_once():
     assert time.perf_counter() - t0 < 5.0
     for o in outs[0] + outs[1]:
         assert (o - ref).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("arch_name,model_type", [("VIT_B16", "ViT-B/16"), ("VIT_L14", "ViT-L/14")])
+def test_every_model_type_forward_vs_oracle(arch_name, model_type):
+    """VERDICT r3 missing #4: the other two model types of the reference's factory (model/timesformer_clip_alt.py:297-310) through
+    the drop-in wrappers -- 197 / 257 tokens per frame (the K/V-tiled attention core), patch 16 / 14 (K = 768 / 588 -> 640 padded),
+    width 1024 x 24 layers, 768-d features (CAM with n_heads = 12) -- against the live oracle: fp32 1e-5, bf16 1e-3."""
+    import warnings
+    from vtc_amd.host import model as HM
+    a = ARCH[arch_name]
+    B, F = 2, 2
+    sd = A.synth_model(a, 91, "timesformer_finaltf", nframes=F)
+    g = torch.Generator().manual_seed(92)
+    for k in list(sd):                       # a checkpoint's temporal_fc / CAM projections are not the init's zeros
+        if k.endswith("temporal_fc.weight") or (k.startswith("final_transformer.") and (k.endswith("out_proj.weight") or k.endswith("c_proj.weight"))):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.02
+    vid = A.synth_pixels((B, F, 3, 224, 224), 93)
+    title = A.synth_tokens(B, a, 94)
+    comments = A.synth_tokens(B * 5, a, 95, empty_frac=0.2).reshape(B, 5, -1)
+    heads = a.embed_dim // 64
+    ref = M.pretrained_clip_timesformer_finaltf(vid, title, comments, sd, a, "text", n_heads=heads)
+
+    class _TSF(HM.PretrainedCLIP_TimeSformer_finaltf):
+        nframes = F
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = _TSF(model_type=model_type, branch_to_adapt_val="text", n_heads=heads)
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().cuda()
+    scale = float(sd["model.logit_scale"].exp())
+    for dtype in DTYPES:
+        m.compute_dtype = dtype
+        got = m(vid.cuda(), title.cuda(), comments.cuda())
+        tol = tol_for(dtype, 512)
+        report(f"{model_type} TimeSformer_finaltf {dtype} feats_vis", float((got[0].cpu() - ref[0]).abs().max()), tol)
+        report(f"{model_type} TimeSformer_finaltf {dtype} feats_text", float((got[1].cpu() - ref[1]).abs().max()), tol)
+        report(f"{model_type} TimeSformer_finaltf {dtype} cosine sim", float((got[2].cpu() - ref[2]).abs().max()) / scale, tol)
+    # the image tower of the same model type (upstream VisionTransformer: 197 / 257 tokens, one attention per block)
+    sdi = A.synth_model(a, 96, "clip")
+    img = A.synth_pixels((3, 3, 224, 224), 97)
+    refi = CR.encode_image(img, sdi, a, "model.visual.").numpy()
+    from vtc_amd import towers
+    for dtype in DTYPES:
+        pv = towers.PackedVision(cuda_sd({k: v for k, v in sdi.items() if k.startswith("model.visual.")}), "model.visual.", dtype)
+        out = pv.forward(img.cuda()).cpu().numpy()
+        report(f"{model_type} image tower {dtype}", np.abs(unit(out) - unit(refi)).max(), tol_for(dtype, 512))

@@ -10,7 +10,7 @@ from oracle import model_ref as M
 from oracle import timesformer_ref as T
 
 torch.set_grad_enabled(False)
-ARCH = {"TINY": A.TINY, "VIT_B32": A.VIT_B32}
+ARCH = {"TINY": A.TINY, "VIT_B32": A.VIT_B32, "VIT_B16": A.VIT_B16, "VIT_L14": A.VIT_L14}
 TOL = dict(rtol=0, atol=2e-5)  # fp32 CPU, different op order (einops/MHA vs index-wise)
 
 

@@ -217,6 +217,165 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   }
 }
 
+// ---- longer sequences: 80 < L <= 272 (ViT-B/16: 1 + 196 tokens per frame, ViT-L/14: 1 + 256; model/timesformer_clip_alt.py:297-310) ----
+// ONE WORKGROUP (4 waves) per (sequence, head): the K rows and V^T of the sequence are staged once into LDS by all four waves,
+// then wave w takes the query tiles w, w + 4, ...; per query tile an ONLINE softmax over chunks of 64 keys (4 MFMA key tiles):
+// running maximum m and running sum l per query (lane-local: queries sit on lanes, as in attn_kernel), the P.V accumulators
+// rescaled by exp(m_old - m_new) when the maximum moves.  Same fragment maps, scaling, masking and store as attn_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_tiled_kernel(const AttnParams p, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  constexpr int SZ = sizeof(T);
+  constexpr int NCH = AT<T>::NCH, KS = AT<T>::KS, EPC = AT<T>::EPC;
+  constexpr int KROW = 64 * SZ + 16;        // K row stride in bytes (16-byte pad: spreads the 16 rows of a fragment over the banks)
+  const int Lp = 16 * ntiles, VS = Lp + 4;  // V^T row stride in elements (keeps 8 / 16-byte alignment)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  char *kl = lds_raw;
+  T *vt = reinterpret_cast<T *>(lds_raw + (size_t)Lp * KROW);
+
+  const int gw = blockIdx.x;
+  const int s = gw / p.heads, h = gw - s * p.heads;
+  const int s_hi = s / p.s2, s_lo = s - s_hi * p.s2;
+  const long base = p.seq_offsets ? (long)p.seq_offsets[s] : (long)s_hi * p.a1 + (long)s_lo * p.a2 + p.a0;
+  const int first = 1 + s_lo * p.a3;
+  const int L = p.seq_offsets ? p.seq_offsets[s + 1] - p.seq_offsets[s] : p.L;
+  const size_t ld = (size_t)3 * p.W * SZ;
+  auto row_of = [&](int tok) -> long { return tok == 0 ? base : base + first + (long)(tok - 1) * p.pstride; };
+
+  // ---- K rows and V^T -> LDS (rows past the sequence end: zeros; they are masked below) ----
+  {
+    const char *kbase = p.qkv + (size_t)(p.W + h * 64) * SZ, *vbase = p.qkv + (size_t)(2 * p.W + h * 64) * SZ;
+    for (int idx = tid; idx < Lp * NCH; idx += 256) {
+      const int tok = idx / NCH, ch = idx - tok * NCH;
+      uint4 kr = make_uint4(0, 0, 0, 0), vr = make_uint4(0, 0, 0, 0);
+      if (tok < L) {
+        const size_t ro = (size_t)row_of(tok) * ld + ch * 16;
+        kr = *reinterpret_cast<const uint4 *>(kbase + ro);
+        vr = *reinterpret_cast<const uint4 *>(vbase + ro);
+      }
+      *reinterpret_cast<uint4 *>(kl + (size_t)tok * KROW + ch * 16) = kr;
+      const T *e = reinterpret_cast<const T *>(&vr);
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) vt[(ch * EPC + j) * VS + tok] = e[j];
+    }
+  }
+  __syncthreads();
+
+  const char *qbase = p.qkv + (size_t)(h * 64) * SZ;
+  for (int qt = wave; qt < ntiles && qt * 16 < L; qt += 4) {
+    const int qtok = qt * 16 + c16;
+    uint4 qf[KS];
+    {
+      const char *r = qbase + (size_t)row_of(min(qtok, L - 1)) * ld;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4 *>(r + (4 * ks + g) * 16);
+    }
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < ntiles; kc += 4) {
+      if (kc * 16 >= L || (p.causal && kc > qt)) break;       // the rest lies past the sequence end / in every query's future
+      f32x4 sc[4];
+      float cm = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kt = kc + j;
+        sc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (kt >= ntiles || kt * 16 >= L || (p.causal && kt > qt)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[j][r] = -INFINITY;
+          continue;
+        }
+        const char *kr = kl + (size_t)(kt * 16 + c16) * KROW + g * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) mma_qk(T(), *reinterpret_cast<const uint4 *>(kr + ks * 64), qf[ks], sc[j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + g * 4 + r;
+          float v = sc[j][r] * 0.125f;       // q * head_dim^-0.5 (timesformer_clip_alt.py:48,52)
+          if (key >= L || (p.causal && key > qtok)) v = -INFINITY;
+          sc[j][r] = v;
+          cm = fmaxf(cm, v);
+        }
+      }
+      cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+      cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+      const float mn = fmaxf(m, cm);          // finite from the first chunk on: key 0 is visible to every query
+      const float alpha = sizeof(T) == 4 ? expf(m - mn) : __expf(m - mn);
+      m = mn;
+      float ps = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = sizeof(T) == 4 ? expf(sc[j][r] - mn) : __expf(sc[j][r] - mn);
+          sc[j][r] = e;
+          ps += e;
+        }
+      l = l * alpha + ps;                      // this lane's keys only; summed over the four key groups at the end
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+      // O^T[d][query] += sum_key Vt[d][key] * P[query][key]
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int k0 = kc + 2 * jj, k1 = k0 + 1;
+          if (k0 >= ntiles) break;
+          const bool has1 = k1 < ntiles;
+          bf16x8 pf;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pf[r] = (short)cvt16<T>(sc[2 * jj][r]);
+            pf[4 + r] = has1 ? (short)cvt16<T>(sc[2 * jj + 1][r]) : (short)0;
+          }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const unsigned short *vr = reinterpret_cast<const unsigned short *>(vt) + (dt * 16 + c16) * VS + g * 4;
+            const uint2 lo = *reinterpret_cast<const uint2 *>(vr + k0 * 16);
+            uint2 hi = make_uint2(0, 0);
+            if (has1) hi = *reinterpret_cast<const uint2 *>(vr + k1 * 16);
+            mma_qk(T(), make_uint4(lo.x, lo.y, hi.x, hi.y), __builtin_bit_cast(uint4, pf), o[dt]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kt = kc + j;
+          if (kt >= ntiles) break;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const float4 vf = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(vt) + (dt * 16 + c16) * VS + kt * 16 + g * 4);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, sc[j][0], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, sc[j][1], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, sc[j][2], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, sc[j][3], o[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qtok < L) {
+      if (p.cls_out && qtok == 0) {
+        float *dst = p.cls_out + (size_t)s * p.W + h * 64 + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          *reinterpret_cast<float4 *>(dst + dt * 16) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+      } else {
+        T *dst = reinterpret_cast<T *>(p.out) + (size_t)row_of(qtok) * p.W + h * 64 + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          ElemOps<T>::store4(dst + dt * 16, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+      }
+    }
+  }
+}
+
 // Global cls attention of model/timesformer_clip.py:81,158: the cls query of each item attends to ALL
 // T tokens of the item.  One wave per (item, head); lanes = the 64 head dimensions; scores via a
 // wave reduction per key, kept in LDS; output row = the item's cls row.  T up to 1024.
@@ -391,6 +550,19 @@ int run(const AttnParams &p, hipStream_t stream) {
   return 0;
 }
 
+constexpr int ATTN_TILED_MAX_L = 272;
+template <typename T>
+int run_tiled(const AttnParams &p, hipStream_t stream) {
+  VTC_CHECK(p.L <= ATTN_TILED_MAX_L, "attention: sequence length %d > %d unsupported", p.L, ATTN_TILED_MAX_L);
+  const int ntiles = cdiv(p.L, 16), Lp = 16 * ntiles;
+  const size_t shmem = (size_t)Lp * (64 * sizeof(T) + 16) + (size_t)64 * (Lp + 4) * sizeof(T);     // K rows + V^T: 74 KB (16-bit) / 145 KB (fp32) at L = 272
+  static PerDeviceOnce attr;
+  if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&attn_tiled_kernel<T>), 160 * 1024, "attention_tiled")) return 1;
+  hipLaunchKernelGGL((attn_tiled_kernel<T>), dim3(p.n_seq * p.heads), dim3(256), shmem, stream, p, ntiles);
+  VTC_LAUNCH_CHECK("attention_tiled");
+  return 0;
+}
+
 template <typename T>
 int dispatch(const AttnParams &p, hipStream_t stream) {
   switch (cdiv(p.L, 16)) {
@@ -400,8 +572,7 @@ int dispatch(const AttnParams &p, hipStream_t stream) {
     case 4: return run<T, 4>(p, stream);
     case 5: return run<T, 5>(p, stream);
   }
-  vtc_set_error("attention: sequence length %d > 80 unsupported", p.L);
-  return 1;
+  return run_tiled<T>(p, stream);
 }
 
 }  // namespace

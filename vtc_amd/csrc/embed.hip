@@ -81,6 +81,32 @@ __global__ __launch_bounds__(256) void im2row_kernel(const PixT *__restrict__ px
   ElemOps<T>::store4(out + m * K + k, v.x, v.y, v.z, v.w);
 }
 
+// Any patch size (ViT-L/14: patch 14, K = 588): one thread per output element, K padded with zeros to `kpad` columns (the GEMM
+// consumes K in 128-byte rows; the packed conv1 weight is zero-padded to the same width).  PixT = unsigned char applies
+// ToTensor + Normalize on the way.
+template <typename PixT, typename T>
+__global__ __launch_bounds__(256) void im2row_generic_kernel(const PixT *__restrict__ px, T *__restrict__ out, int n_frames, int grid,
+                                                             int patch, int res, int kpad, PixNorm nrm) {
+  const int K = 3 * patch * patch;
+  const size_t total = (size_t)n_frames * grid * grid * kpad;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int k = (int)(idx % kpad);
+  const size_t m = idx / kpad;
+  float v = 0.f;
+  if (k < K) {
+    const int c = k / (patch * patch), rem = k - c * patch * patch;
+    const int i = rem / patch, j = rem - i * patch;
+    const int P = grid * grid;
+    const int f = (int)(m / P), pp = (int)(m - (size_t)f * P);
+    const int py = pp / grid, pxx = pp - py * grid;
+    const size_t src = (((size_t)f * 3 + c) * res + (size_t)py * patch + i) * res + (size_t)pxx * patch + j;
+    if constexpr (sizeof(PixT) == 1) v = ((float)px[src] / 255.0f - nrm.mean[c]) * nrm.inv_std[c];
+    else v = ElemOps<PixT>::load(px + src);
+  }
+  ElemOps<T>::store(out + idx, v);
+}
+
 __global__ __launch_bounds__(256) void cls_rows_kernel(float *x, const float *__restrict__ cls, const float *__restrict__ pos0,
                                                        int n_items, int T, int W) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -331,9 +357,32 @@ __global__ __launch_bounds__(256) void cam_finalize_kernel(const float *__restri
 
 }  // namespace
 
+// columns of the patch matrix / of the packed conv1 weight: 3 patch^2 rounded up to whole 128-byte GEMM rows of either operand size
+int patch_k_padded(int patch) { return (3 * patch * patch + 63) / 64 * 64; }
+
 int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res,
                   const float *mean, const float *stdv, hipStream_t stream) {
-  VTC_CHECK(patch % 4 == 0, "im2row: patch=%d must be a multiple of 4", patch);
+  if (patch % 4 != 0 || patch_k_padded(patch) != 3 * patch * patch) {
+    // patch 14 (ViT-L/14, model/timesformer_clip_alt.py:304-310): element-wise gather, zero-padded K
+    const int kpad = patch_k_padded(patch);
+    PixNorm nrm = {{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
+    if (pixel_dtype == VTC_U8)
+      for (int c = 0; c < 3; ++c) {
+        VTC_CHECK(stdv[c] > 0.f, "im2row: pix_std[%d] must be positive for uint8 pixels", c);
+        nrm.mean[c] = mean[c]; nrm.inv_std[c] = 1.0f / stdv[c];
+      }
+    const size_t total = (size_t)n_frames * grid * grid * kpad;
+    const dim3 g((unsigned)((total + 255) / 256)), b(256);
+    ProfScope prof(VTC_PROF_EMBED, (double)total * ((pixel_dtype == VTC_U8 ? 1 : pixel_dtype == VTC_BF16 ? 2 : 4) + (dtype == VTC_F32 ? 4 : 2)), stream);
+    VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "im2row: output dtype %d", dtype);
+#define VTC_IM2ROW_G(PT, OT) hipLaunchKernelGGL((im2row_generic_kernel<PT, OT>), g, b, 0, stream, (const PT *)px, (OT *)out, n_frames, grid, patch, res, kpad, nrm)
+    if (pixel_dtype == VTC_U8) { if (dtype == VTC_BF16) VTC_IM2ROW_G(unsigned char, bf16_t); else VTC_IM2ROW_G(unsigned char, float); }
+    else if (pixel_dtype == VTC_F32) { if (dtype == VTC_BF16) VTC_IM2ROW_G(float, bf16_t); else VTC_IM2ROW_G(float, float); }
+    else { if (dtype == VTC_BF16) VTC_IM2ROW_G(bf16_t, bf16_t); else VTC_IM2ROW_G(bf16_t, float); }
+#undef VTC_IM2ROW_G
+    VTC_LAUNCH_CHECK("im2row_generic");
+    return 0;
+  }
   if (pixel_dtype == VTC_U8) {
     PixNorm nrm;
     for (int c = 0; c < 3; ++c) {

@@ -33,6 +33,7 @@ void vtc_set_error(const char *fmt, ...) {
 extern "C" const char *vtc_last_error(void) { return g_err; }
 extern "C" int vtc_abi_version(void) { return 5; }
 int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res, const float *mean, const float *stdv, hipStream_t stream);
+int patch_k_padded(int patch);
 int launch_pixels_u8_to_operand(const void *px, void *out, int dtype, int n_frames, int res, const float *mean, const float *stdv, hipStream_t stream);
 int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, int T, int W, hipStream_t stream);
 int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int F, int T, int W, hipStream_t stream);
@@ -290,7 +291,7 @@ VisionWs plan_vision(const vtc_vision_w *w, int n_items, int F, int dtype, void 
   VisionWs v;
   const int P = w->grid * w->grid, T = 1 + P * F, W = w->width;
   const size_t rows = (size_t)pad256(n_items * T);      // padded: the folded-LayerNorm GEMMs run whole 256-row tiles
-  const size_t patch_elems = (size_t)n_items * F * P * 3 * w->patch * w->patch;
+  const size_t patch_elems = (size_t)n_items * F * P * patch_k_padded(w->patch);
   size_t big_elems = rows * 4 * W;
   if (patch_elems > big_elems) big_elems = patch_elems;
   v.x = (float *)b.take(rows * W * 4);
@@ -392,7 +393,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
     } else {
       RUN(launch_im2row(pixels, pixel_dtype, v.big, dtype, n_items * F, w->grid, w->patch, res, w->pix_mean, w->pix_std, s));
     }
-    RUN(launch_gemm(act, w->conv_w, nullptr, v.x, n_items * F * P, W, 3 * w->patch * w->patch, dtype, e, s));
+    RUN(launch_gemm(act, w->conv_w, nullptr, v.x, n_items * F * P, W, patch_k_padded(w->patch), dtype, e, s));
   }
   RUN(launch_cls_rows(v.x, w->class_embedding, w->pos, n_items, T, W, s));
   RUN(launch_layernorm(v.x, w->ln_pre_g, w->ln_pre_b, v.x, rows, W, VTC_F32, nullptr, 1, false, s));

@@ -193,7 +193,11 @@ class PackedVision:
         # raw uint8 pixels: ToTensor + Normalize of CLIP_TRANSFORM (dataset_loaders/dataset_loaders.py:40-49)
         w.pix_mean = (C.c_float * 3)(0.48145466, 0.4578275, 0.40821073)
         w.pix_std = (C.c_float * 3)(0.26862954, 0.26130258, 0.27577711)
-        w.conv_w = k.mat(conv.reshape(w.width, -1), dtype)
+        cw = conv.reshape(w.width, -1)
+        kp = (cw.shape[1] + 63) // 64 * 64          # K of the patch GEMM in whole 128-byte rows (ViT-L/14: 588 -> 640, zero columns)
+        if kp != cw.shape[1]:
+            cw = torch.cat([cw, cw.new_zeros(w.width, kp - cw.shape[1])], dim=1)
+        w.conv_w = k.mat(cw, dtype)
         w.class_embedding, w.pos = k.f32(sd["class_embedding"]), k.f32(sd["positional_embedding"])
         w.temporal = k.f32(sd["temporal_embed"]) if w.nframes else None
         w.ln_pre_g, w.ln_pre_b = k.f32(sd["ln_pre.weight"]), k.f32(sd["ln_pre.bias"])

@@ -446,7 +446,8 @@ __device__ __forceinline__ void unpack_chunk(const uint4 &raw, float (&f)[AT<T>:
 template <typename T>
 __global__ __launch_bounds__(256) void sq_attn_kernel(const SqParams p) {
   constexpr int SZ = sizeof(T), NCH = AT<T>::NCH, EPC = AT<T>::EPC, KP = 64 / NCH;
-  __shared__ float pl[4][128];
+  constexpr int SQ_MAXL = 320, SQ_PL = SQ_MAXL / 64;     // keys per sequence (ViT-L/14: 257), keys per lane
+  __shared__ float pl[4][SQ_MAXL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gw = blockIdx.x * 4 + wave;
   if (gw >= p.n_out * p.heads) return;              // no workgroup barrier below: waves are independent
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256) void sq_attn_kernel(const SqParams p) {
     base = (long)s_hi * p.a1 + (long)s_lo * p.a2 + p.a0;
     first = 1 + s_lo * p.a3; pstride = p.pstride; L = p.L; qi = s_hi;
   }
-  L = min(max(L, 1), 128);
+  L = min(max(L, 1), SQ_MAXL);
   auto row_of = [&](int tok) -> long { return tok == 0 ? base : base + first + (long)(tok - 1) * pstride; };
   const size_t ld = (size_t)3 * p.W * SZ;
   const int ch = lane % NCH, kq = lane / NCH;
@@ -487,14 +488,24 @@ __global__ __launch_bounds__(256) void sq_attn_kernel(const SqParams p) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // softmax over the L keys (two per lane)
-  const float s0 = lane < L ? pw[lane] : -INFINITY, s1 = lane + 64 < L ? pw[lane + 64] : -INFINITY;
-  const float mx = wave_max(fmaxf(s0, s1));
-  const float e0 = lane < L ? __expf(s0 - mx) : 0.f, e1 = lane + 64 < L ? __expf(s1 - mx) : 0.f;
-  const float inv = 1.0f / wave_sum(e0 + e1);
+  // softmax over the L keys (SQ_PL per lane)
+  float sv[SQ_PL], mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < SQ_PL; ++i) {
+    sv[i] = lane + 64 * i < L ? pw[lane + 64 * i] : -INFINITY;
+    mx = fmaxf(mx, sv[i]);
+  }
+  mx = wave_max(mx);
+  float es = 0.f;
+#pragma unroll
+  for (int i = 0; i < SQ_PL; ++i) {
+    sv[i] = lane + 64 * i < L ? __expf(sv[i] - mx) : 0.f;
+    es += sv[i];
+  }
+  const float inv = 1.0f / wave_sum(es);
   __builtin_amdgcn_wave_barrier();
-  pw[lane] = e0 * inv;
-  pw[lane + 64] = e1 * inv;
+#pragma unroll
+  for (int i = 0; i < SQ_PL; ++i) pw[lane + 64 * i] = sv[i] * inv;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -609,8 +620,8 @@ int launch_attention_ragged(const void *qkv, void *out, int n_seq, int max_L, in
 // One query per sequence (struct SqParams): affine key map as launch_attention (eot == NULL) or the text tower's EOT query.
 int launch_single_query_attention(const void *qkv, const void *q, float *out, int n_out, int L, int heads, int s2, int a0, int a1, int a2,
                                   int a3, int pstride, const int *eot, const int *offs, int ctx, int dtype, hipStream_t stream) {
-  VTC_CHECK(n_out > 0 && heads > 0 && s2 > 0 && (eot || (L > 0 && L <= 128)), "single_query_attention: bad sizes n_out=%d L=%d", n_out, L);
-  VTC_CHECK(!eot || ctx <= 128, "single_query_attention: context %d > 128", ctx);
+  VTC_CHECK(n_out > 0 && heads > 0 && s2 > 0 && (eot || (L > 0 && L <= 320)), "single_query_attention: bad sizes n_out=%d L=%d", n_out, L);
+  VTC_CHECK(!eot || ctx <= 320, "single_query_attention: context %d > 320", ctx);
   SqParams p;
   p.qkv = (const char *)qkv; p.q = (const char *)q; p.out = out;
   p.n_out = n_out; p.heads = heads; p.W = heads * 64;

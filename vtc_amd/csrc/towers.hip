@@ -363,7 +363,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
   VTC_CHECK(!tsf || F <= w->nframes, "vision_forward: %d frames > temporal_embed rows %d", F, w->nframes);
   VTC_CHECK(w->width == w->heads * 64, "vision_forward: head_dim must be 64 (width %d, heads %d)", w->width, w->heads);
   const int P = w->grid * w->grid, T = 1 + P * F, W = w->width;
-  VTC_CHECK(1 + P <= 80 && F < 80, "vision_forward: sequence too long (1+P=%d, F=%d)", 1 + P, F);
+  VTC_CHECK(1 + P <= 272 && F <= 272, "vision_forward: sequence too long (1+P=%d, F=%d; the attention cores cover 272 tokens)", 1 + P, F);
   VTC_CHECK(w->variant == 0 || w->variant == 1, "vision_forward: unknown variant %d", w->variant);
   VTC_CHECK(!(w->variant == 1 && w->nframes == 0), "vision_forward: variant 1 (model/timesformer_clip.py) is a video tower: nframes must be > 0");
   const int rows = n_items * T, res = w->grid * w->patch;

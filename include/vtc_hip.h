@@ -250,6 +250,10 @@ int vtc_l2_sweep_shard_cols(const float *b_all, const float *a_local, int n_tota
 /* hits[j] += #{ i : (target_offset + i) in ids[i, :k_vals[j]] }   (hits: int64 device) */
 int vtc_recall_hits(const int64_t *ids, int n_queries, int depth, int64_t target_offset, const int *k_vals_host,
                     int nk, long long *hits, void *stream);
+/* the same for the two directions of one evaluation (RecallAtK.result(), model/metric.py:166-187: compute(a, b) and compute(b, a),
+ * same number of queries and the same targets) in ONE launch */
+int vtc_recall_hits_pair(const int64_t *ids_a, const int64_t *ids_b, int n_queries, int depth, int64_t target_offset,
+                         const int *k_vals_host, int nk, long long *hits_a, long long *hits_b, void *stream);
 
 /* ---- primitives (exported for parity tests and reuse) -------------------------------- */
 enum { VTC_EPI_STORE = 0,   /* out = acc + bias                      (out dtype = out_dtype) */

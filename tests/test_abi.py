@@ -75,7 +75,7 @@ def test_state_dict_contract_matches_reference_keys():
     cfg = ClipConfig(**asdict(A.TINY))
     for kind, cls in (("clip", HM.PretrainedCLIP), ("clip_finaltf", HM.PretrainedCLIP_finaltf),
                       ("timesformer", HM.PretrainedCLIP_TimeSformer), ("timesformer_finaltf", HM.PretrainedCLIP_TimeSformer_finaltf)):
-        m = cls(model_type=cfg)
+        m = cls(model_type=cfg, **({"n_heads": 2} if kind.endswith("finaltf") else {}))      # TINY features are 128-d: 2 heads of 64
         m.load_state_dict(A.synth_model(A.TINY, 1, kind), strict=True)
     # constructor kwargs of the reference (model/model.py:309-315,375-390,484,540-553)
     want = {"PretrainedCLIP": ["model_type", "freeze", "residual_activation", "comment_fusion"],
@@ -97,7 +97,7 @@ def test_cam_init_from_avg_zeroing():
     from oracle import arch as A
     from vtc_amd.host import model as HM
     from vtc_amd.host.clip_arch import ClipConfig
-    m = HM.PretrainedCLIP_finaltf(model_type=ClipConfig(**asdict(A.TINY)))
+    m = HM.PretrainedCLIP_finaltf(model_type=ClipConfig(**asdict(A.TINY)), n_heads=2)
     for blk in m.final_transformer.resblocks:                      # model/model.py:440-450
         assert blk.mlp.c_proj.weight.abs().sum() == 0 and blk.attn.out_proj.weight.abs().sum() == 0
     assert m.final_linear.weight.abs().sum() == 0                  # :452

@@ -56,6 +56,91 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict
   }
 }
 
+// ---- fused prologue of the block-minima sweep (round 4): one launch for BOTH embedding sets ---------------------------------
+// Per row x (one wave): |x|^2 (fp32), the bf16 operand row x~ = rne(x) (xb == NULL: statistics only), and the two numbers the
+// certificate's error bound is made of -- |x~| and |e| with e = x - x~, the row's ACTUAL rounding error (exact in fp32: x and x~
+// agree in sign, exponent and the top mantissa bits, so the difference is representable) -- plus the running maxima of all three
+// over the set (per-block maxima, folded by sweep_prep_max_kernel).
+//   | q~.g~ - q.g | = | q~.e_g + e_q.g~ + e_q.e_g |  <=  |q~||e_g| + |e_q||g~| + |e_q||e_g|          (Cauchy-Schwarz)
+// With |e| <= 2^-8 |x| this is the worst-case bound of rounds 2-3 (2u + u^2)|q||g|; on real embeddings |e| ~ 0.3 x 2^-8 |x|, so
+// the certified candidate sets are ~3x tighter -- and rows that do sit on bf16 midpoints (the adversarial test) still get the
+// full bound, because |e| is measured, not assumed.  Both norms carry a 1e-4 relative slack for their fp32 summation.
+struct PrepSide {
+  const float *x;
+  bf16_t *xb;
+  float *n2;
+  float2 *st;      // (|x~|, |e|) per row
+  float *mx;       // [0] max |x|^2, [1] max |x~|, [2] max |e|   (written by sweep_prep_max_kernel)
+  int n;
+};
+constexpr int PREP_RPW = 4;      // rows per wave
+// part[block][8]: the block's maxima {A: |x|^2, |x~|, |e|, -; B: ...} -- no atomics (20 000 rows x 3 atomic maxima on two sets of
+// three words took 0.5 ms); sweep_prep_max_kernel folds the blocks' rows
+__global__ __launch_bounds__(256) void sweep_prep_kernel(PrepSide A, PrepSide B, int d, float *__restrict__ part) {
+  __shared__ float red[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < PREP_RPW; ++i) {
+    int r = (blockIdx.x * 4 + wave) * PREP_RPW + i;
+    if (r >= A.n + B.n) break;                   // wave-uniform
+    const bool second = r >= A.n;
+    const PrepSide &S = second ? B : A;
+    if (second) r -= A.n;
+    const float *xr = S.x + (size_t)r * d;
+    float n2 = 0.f, nt2 = 0.f, e2 = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+      const float4 v = *reinterpret_cast<const float4 *>(xr + c);
+      const float f[4] = {v.x, v.y, v.z, v.w};
+      unsigned short h[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = f2bf(f[j]);
+        const float t = bf2f(h[j]), e = f[j] - t;
+        n2 = fmaf(f[j], f[j], n2);
+        nt2 = fmaf(t, t, nt2);
+        e2 = fmaf(e, e, e2);
+      }
+      if (S.xb) *reinterpret_cast<uint2 *>(S.xb + (size_t)r * d + c) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    }
+    n2 = wave_sum(n2); nt2 = wave_sum(nt2); e2 = wave_sum(e2);
+    const float nt = sqrtf(nt2) * 1.0001f, e = sqrtf(e2) * 1.0001f;
+    if (lane == 0) {
+      S.n2[r] = n2;
+      S.st[r] = make_float2(nt, e);
+    }
+    const int o = second ? 4 : 0;
+    mx[o] = fmaxf(mx[o], n2); mx[o + 1] = fmaxf(mx[o + 1], nt); mx[o + 2] = fmaxf(mx[o + 2], e);
+  }
+  if (lane < 8) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v = lane == k ? mx[k] : v;
+    red[wave][lane] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) part[(size_t)blockIdx.x * 8 + threadIdx.x] = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+}
+__global__ __launch_bounds__(256) void sweep_prep_max_kernel(const float *__restrict__ part, int nblocks, float *__restrict__ mxA, float *__restrict__ mxB) {
+  __shared__ float red[32][8];
+  const int k = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  float m = 0.f;
+  for (int b = sl; b < nblocks; b += 32) m = fmaxf(m, part[(size_t)b * 8 + k]);
+  red[sl][k] = m;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    float v = 0.f;
+    for (int i = 0; i < 32; ++i) v = fmaxf(v, red[i][threadIdx.x]);
+    if (threadIdx.x < 3) mxA[threadIdx.x] = v;
+    else if (threadIdx.x >= 4 && threadIdx.x < 7) mxB[threadIdx.x - 4] = v;
+  }
+}
+static int prep_blocks(int rows) { return cdiv(rows, 4 * PREP_RPW); }
+static void launch_sweep_prep(const PrepSide &A, const PrepSide &B, int d, float *part, hipStream_t stream) {
+  const int nb = prep_blocks(A.n + B.n);
+  hipLaunchKernelGGL(sweep_prep_kernel, dim3(nb), dim3(256), 0, stream, A, B, d, part);
+  hipLaunchKernelGGL(sweep_prep_max_kernel, dim3(1), dim3(256), 0, stream, part, nb, A.mx, B.mx);
+}
+
 // Wave-wide sorted best list, one entry per lane (lane i = i-th best), order = (distance, index).
 struct WaveList {
   float bd;
@@ -363,11 +448,36 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
 // nbs == nblk; several: the column planes every rank sent for this rank's columns, stacked in rank order) -- block `blk`
 // holds entries src_base[blk / nbs] + (blk % nbs) * bw + (key & 127) of the other side (src_base == NULL: 0).
 // OW owners per workgroup: 64, or 32 when 64 would leave CUs without a workgroup (10k x 10k: 157 workgroups of 64)
+// (round 4: ONE launch serves both directions of the one-matrix sweep -- workgroups [0, nblocks_a) take problem A, the rest B;
+// nblocks_a == gridDim.x: a single problem.  The same holds for exact_rerank_kernel and block_rescan_kernel below.)
+struct MinselArgs {
+  const unsigned *keys;
+  int R, nblk, bw, nbs;
+  const int *src_base;
+  int depth;
+  const float *own_norm;
+  const float2 *own_st;
+  const float *other_max;
+  float kappa;
+  int64_t *cand;
+  int *cand_n;
+  float *theta_out;
+};
 template <int OW>
-__global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict__ keys, int R, int nblk, int bw, int nbs,
-                                                     const int *__restrict__ src_base, int depth,
-                                                     const float *__restrict__ own_norm, const float *__restrict__ other_max, float kappa,
-                                                     int64_t *__restrict__ cand, int *__restrict__ cand_n, float *__restrict__ theta_out) {
+__global__ __launch_bounds__(256) void minsel_kernel(const MinselArgs PA, const MinselArgs PB, int nblocks_a) {
+  const bool second = (int)blockIdx.x >= nblocks_a;
+  const MinselArgs &P = second ? PB : PA;
+  const int bid = second ? (int)blockIdx.x - nblocks_a : (int)blockIdx.x;
+  const unsigned *__restrict__ keys = P.keys;
+  const int R = P.R, nblk = P.nblk, bw = P.bw, nbs = P.nbs, depth = P.depth;
+  const int *__restrict__ src_base = P.src_base;
+  const float *__restrict__ own_norm = P.own_norm;
+  const float2 *__restrict__ own_st = P.own_st;
+  const float *__restrict__ other_max = P.other_max;
+  const float kappa = P.kappa;
+  int64_t *__restrict__ cand = P.cand;
+  int *__restrict__ cand_n = P.cand_n;
+  float *__restrict__ theta_out = P.theta_out;
   constexpr int TG = OW / 4, NSUB = 256 / TG, NI = 64 / NSUB;      // vector loads: TG threads along the owners, NSUB block slices
   constexpr int OPW = OW / 4;                                       // owners per wave
   constexpr int SROWS = 256 / OW, NQ = 64 / SROWS;                  // scalar loads: a thread per owner, SROWS block slices
@@ -375,7 +485,7 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
   __shared__ unsigned tl[3][64 * 65];
   __shared__ float bmin[32][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int r0 = blockIdx.x * OW;
+  const int r0 = bid * OW;
   const size_t plane = (size_t)nbs * R;                       // one plane of one source
   auto blk_off = [&](int blk) -> size_t {                      // offset of (plane 0, blk, owner 0)
     const int src = blk / nbs;
@@ -463,7 +573,10 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
     wl.offer(m2[cc], 64 + lane, wl.beats(m2[cc], 64 + lane), lane, depth);
     const float u = wl.tau;
     const int r = min(r0 + OPW * w + cc, R - 1);
-    const float eps = kappa * (own_norm[r] + *other_max);
+    // |approx - exact| of any entry of this owner's row (sweep_prep_kernel: measured rounding errors; other_max = the other
+    // side's {max |x|^2, max |x~|, max |e|}) + kappa x the fp32 terms (accumulation, norms, the key's index bits)
+    const float2 st = own_st[r];
+    const float eps = 1.001f * (2.0f * (st.x * other_max[2] + st.y * other_max[1] + st.y * other_max[2]) + kappa * (own_norm[r] + other_max[0]));
     theta[cc] = u + 2.0f * eps;          // u == +inf (fewer than depth pool entries) keeps theta infinite: everything is a candidate
   }
   // ---- pass 2: every pool entry with key <= theta, and the smallest fourth-in-block key ----
@@ -516,14 +629,21 @@ __global__ __launch_bounds__(256) void minsel_kernel(const unsigned *__restrict_
   }
 }
 
-static void launch_minsel(const unsigned *keys, int R, int nblk, int bw, int nbs, const int *src_base, int depth, const float *own_norm,
-                          const float *other_max, float kappa, int64_t *cand, int *cand_n, float *theta, hipStream_t stream) {
-  if (cdiv(R, 64) < vtcgemm::num_cus())
-    hipLaunchKernelGGL(minsel_kernel<32>, dim3(cdiv(R, 32)), dim3(256), 0, stream, keys, R, nblk, bw, nbs, src_base, depth, own_norm, other_max,
-                       kappa, cand, cand_n, theta);
-  else
-    hipLaunchKernelGGL(minsel_kernel<64>, dim3(cdiv(R, 64)), dim3(256), 0, stream, keys, R, nblk, bw, nbs, src_base, depth, own_norm, other_max,
-                       kappa, cand, cand_n, theta);
+static MinselArgs minsel_args(const unsigned *keys, int R, int nblk, int bw, int nbs, const int *src_base, int depth, const float *own_norm,
+                              const float2 *own_st, const float *other_max, float kappa, int64_t *cand, int *cand_n, float *theta) {
+  return MinselArgs{keys, R, nblk, bw, nbs, src_base, depth, own_norm, own_st, other_max, kappa, cand, cand_n, theta};
+}
+// one problem (B == nullptr) or both directions in one launch
+static void launch_minsel(const MinselArgs &A, const MinselArgs *B, hipStream_t stream) {
+  const int total = A.R + (B ? B->R : 0);
+  const MinselArgs &Bv = B ? *B : A;
+  if (cdiv(total, 64) < vtcgemm::num_cus()) {
+    const int na = cdiv(A.R, 32), nb = B ? cdiv(B->R, 32) : 0;
+    hipLaunchKernelGGL(minsel_kernel<32>, dim3(na + nb), dim3(256), 0, stream, A, Bv, na);
+  } else {
+    const int na = cdiv(A.R, 64), nb = B ? cdiv(B->R, 64) : 0;
+    hipLaunchKernelGGL(minsel_kernel<64>, dim3(na + nb), dim3(256), 0, stream, A, Bv, na);
+  }
 }
 
 // ---- VTC_SWEEP_EXACT ------------------------------------------------------------------------------------
@@ -546,15 +666,34 @@ __device__ __forceinline__ double wave_dist64(const float *__restrict__ q, const
 // has approx(j) <= approx_(depth) + 2 eps, so it is on the list when approx_(cdepth) > approx_(depth) + 2 eps, with
 // eps = kappa (|q|^2 + max|g|^2) a worst-case bound of the split-bf16 distance error (dropped lo.lo products, the
 // two bf16 roundings of each operand, fp32 accumulation of 3 D products).  Otherwise the row is flagged.
-__global__ __launch_bounds__(256) void exact_rerank_kernel(const float *__restrict__ queries, const float *__restrict__ gallery, int nq,
-                                                           int ng, int d, const int64_t *__restrict__ cand, const float *__restrict__ cand_d,
-                                                           int cdepth, int depth, const float *__restrict__ qn, const float *__restrict__ gmax,
-                                                           float kappa, int64_t *__restrict__ ids, float *__restrict__ dists,
-                                                           int *__restrict__ flags,      // flags[0] = count, flags[1..] = rows
-                                                           const int *__restrict__ cand_n) {    // block-minima path: the row's list holds cand_n[r] entries
-                                                                                                 // and is ALREADY certified complete (< 0: it is not); else nullptr
+struct RerankArgs {
+  const float *queries, *gallery;
+  int nq, ng, d;
+  const int64_t *cand;
+  const float *cand_d;
+  int cdepth, depth;
+  const float *qn, *gmax;
+  float kappa;
+  int64_t *ids;
+  float *dists;
+  int *flags;          // flags[0] = count, flags[1..] = rows
+  const int *cand_n;   // block-minima path: the row's list holds cand_n[r] entries and is ALREADY certified complete (< 0: it is not); else nullptr
+};
+__global__ __launch_bounds__(256) void exact_rerank_kernel(const RerankArgs PA, const RerankArgs PB, int nblocks_a) {
+  const bool second = (int)blockIdx.x >= nblocks_a;
+  const RerankArgs &P = second ? PB : PA;
+  const int bid = second ? (int)blockIdx.x - nblocks_a : (int)blockIdx.x;
+  const float *__restrict__ queries = P.queries, *__restrict__ gallery = P.gallery;
+  const int nq = P.nq, ng = P.ng, d = P.d, cdepth = P.cdepth, depth = P.depth;
+  const int64_t *__restrict__ cand = P.cand;
+  const float *__restrict__ cand_d = P.cand_d, *__restrict__ qn = P.qn, *__restrict__ gmax = P.gmax;
+  const float kappa = P.kappa;
+  int64_t *__restrict__ ids = P.ids;
+  float *__restrict__ dists = P.dists;
+  int *__restrict__ flags = P.flags;
+  const int *__restrict__ cand_n = P.cand_n;
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int r = bid * 4 + (threadIdx.x >> 6);
   if (r >= nq) return;
   const float *q = queries + (size_t)r * d;
   const int n_list = cand_n ? cand_n[r] : cdepth;
@@ -786,10 +925,30 @@ __global__ __launch_bounds__(256) void exact_fallback_merge_kernel(int depth, co
 // the pool entries <= theta of the safe blocks and EVERY entry of the unsafe ones (an entry that is not among its block's three
 // smallest has the block's fourth key below its own).  That set contains the true top-depth; fp64 distances, sorted by
 // (distance, index): the same ids as the brute force.  One workgroup per flagged owner, a wave per block at a time.
-__global__ __launch_bounds__(256) void block_rescan_kernel(const float *__restrict__ queries, const float *__restrict__ gallery, int ng, int d,
-                                                           int depth, const int *__restrict__ flags, const unsigned *__restrict__ keys, int R,
-                                                           int nblk, int bw, int nbs, int n_src, const int *__restrict__ src_base,
-                                                           const float *__restrict__ theta, int64_t *__restrict__ ids, float *__restrict__ dists) {
+struct RescanArgs {
+  const float *queries, *gallery;
+  int ng, d, depth;
+  const int *flags;
+  const unsigned *keys;
+  int R, nblk, bw, nbs, n_src;
+  const int *src_base;
+  const float *theta;
+  int64_t *ids;
+  float *dists;
+};
+__global__ __launch_bounds__(256) void block_rescan_kernel(const RescanArgs PA, const RescanArgs PB, int nblocks_a) {
+  const bool second = (int)blockIdx.x >= nblocks_a;
+  const RescanArgs &P = second ? PB : PA;
+  const int bid = second ? (int)blockIdx.x - nblocks_a : (int)blockIdx.x;
+  const int nbl = second ? (int)gridDim.x - nblocks_a : nblocks_a;
+  const float *__restrict__ queries = P.queries, *__restrict__ gallery = P.gallery;
+  const int ng = P.ng, d = P.d, depth = P.depth, R = P.R, nblk = P.nblk, bw = P.bw, nbs = P.nbs, n_src = P.n_src;
+  const int *__restrict__ flags = P.flags;
+  const unsigned *__restrict__ keys = P.keys;
+  const int *__restrict__ src_base = P.src_base;
+  const float *__restrict__ theta = P.theta;
+  int64_t *__restrict__ ids = P.ids;
+  float *__restrict__ dists = P.dists;
   constexpr int CAP = 4096;               // candidate list of a round: CAP / bw blocks, each at most bw entries
   __shared__ double sd[4][64];
   __shared__ int si[4][64];
@@ -799,7 +958,7 @@ __global__ __launch_bounds__(256) void block_rescan_kernel(const float *__restri
   const int n_flagged = flags[0];
   const size_t plane = (size_t)nbs * R;
   const int cb = min(CAP / bw, 256);      // blocks per round, a thread per block
-  for (int f = blockIdx.x; f < n_flagged; f += gridDim.x) {     // uniform for the workgroup
+  for (int f = bid; f < n_flagged; f += nbl) {     // uniform for the workgroup
     const int r = flags[1 + f];
     const float *q = queries + (size_t)r * d;
     const float th = theta[r];
@@ -899,9 +1058,13 @@ __global__ __launch_bounds__(256) void max_reduce_kernel(const float *__restrict
   if (threadIdx.x == 0) *out = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
 }
 
+// (ids2 != NULL: a second id array of the same shape and targets -- the other direction -- counted into hits2 by the second half of the grid)
 __global__ __launch_bounds__(256) void recall_hits_kernel(const int64_t *__restrict__ ids, int n, int depth, int64_t target_offset,
-                                                          int k0, int k1, int k2, int k3, int nk, unsigned long long *hits) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+                                                          int k0, int k1, int k2, int k3, int nk, unsigned long long *hits,
+                                                          const int64_t *__restrict__ ids2, unsigned long long *hits2) {
+  const int half = (int)gridDim.x >> (ids2 ? 1 : 0);
+  if (ids2 && (int)blockIdx.x >= half) { ids = ids2; hits = hits2; }
+  const int i = ((int)blockIdx.x % half) * 256 + threadIdx.x;
   int rank = 1 << 30;
   if (i < n) {
     const int64_t t = target_offset + i;
@@ -1063,17 +1226,21 @@ constexpr int CD2 = 64;       // capacity of a candidate list of the block-minim
 //   q~.g~ - q.g = sum q e_g + g e_q + e_q e_g,  |e| <= u |x|   =>   |.| <= (2u + u^2) |q||g| <= (2u + u^2)(|q|^2 + |g|^2) / 2,
 // twice that on the distance: 2^-7 (1 + 2^-9); fp32 accumulation of d products and the two fp32 norms (2 d 2^-24); the 7 index
 // bits of the key (2^-16 of a distance <= 2 (|q|^2 + |g|^2)); the epilogue's roundings (slack)
-float exact2_kappa(int d) { return 1.0f / 128.0f * (1.0f + 1.0f / 512.0f) + 2.0f * d / 16777216.0f + 1.0f / 32768.0f + 1e-6f; }
+// (round 4: the operand-rounding term is no longer this worst case but the rows' measured |e| -- sweep_prep_kernel / minsel_kernel;
+// what remains here are the fp32 terms, relative to |q|^2 + max|g|^2)
+float exact2_kappa(int d) { return 2.0f * d / 16777216.0f + 1.0f / 32768.0f + 1e-6f; }
 
 struct Sweep2Ws {
-  float *qn, *gn, *gmax, *qmax;
+  float *qn, *gn, *gmax, *qmax;      // gmax / qmax: {max |x|^2, max |x~|, max |e|} of the gallery / query side (adjacent 256-byte slots)
+  float2 *qst, *gst;                 // (|x~|, |e|) per row
+  float *pmax;                       // sweep_prep_kernel's per-block maxima
   bf16_t *qb, *gb;
   unsigned *rowk, *colk;
   int nblk_c, nblk_r, rb;
   int64_t *cand, *cand2;
   int *cand_n, *cand2_n;
   float *theta, *theta2;
-  int *flags;
+  int *flags, *flags2;               // uncertified rows of the row / column direction (count + list)
   FallbackWs fb;
   size_t total;
 };
@@ -1088,6 +1255,9 @@ Sweep2Ws plan2(char *ws, int ng, int nq, int d, bool bidir) {
   s.gn = (float *)take((size_t)ng * 4);
   s.gmax = (float *)take(256);
   s.qmax = (float *)take(256);
+  s.qst = (float2 *)take((size_t)nq * 8);
+  s.gst = (float2 *)take((size_t)ng * 8);
+  s.pmax = (float *)take((size_t)((nq + ng) / 16 + 2) * 8 * 4);
   s.qb = (bf16_t *)take((size_t)nq * d * 2);
   s.gb = (bf16_t *)take((size_t)ng * d * 2);
   s.rowk = (unsigned *)take((size_t)L2MIN_PLANES * s.nblk_c * nq * 4);
@@ -1102,6 +1272,7 @@ Sweep2Ws plan2(char *ws, int ng, int nq, int d, bool bidir) {
     s.theta2 = (float *)take((size_t)ng * 4);
   }
   s.flags = (int *)take((size_t)(std::max(nq, bidir ? ng : 0) + 1) * 4);
+  s.flags2 = bidir ? (int *)take((size_t)(ng + 1) * 4) : nullptr;
   s.fb.part_d = (double *)take((size_t)FB_ROWS * FB_CHUNKS * FB_SLOT * 8);
   s.fb.part_i = (int *)take((size_t)FB_ROWS * FB_CHUNKS * FB_SLOT * 4);
   s.total = off;
@@ -1113,12 +1284,11 @@ Sweep2Ws plan2(char *ws, int ng, int nq, int d, bool bidir) {
 // column direction is NOT finished here (vtc_l2_sweep_shard_cols does, after the exchange)
 int exact2_impl(const float *a, const float *b, int na, int nb, int d, int depth, int64_t *ids_b2a, float *dists_b2a, int64_t *ids_a2b,
                 float *dists_a2b, const Sweep2Ws &s, hipStream_t stream, unsigned *colk_out = nullptr, int nblk_r_pad = 0) {
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(nb, 4)), dim3(256), 0, stream, b, s.qn, nb, d);
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(na, 4)), dim3(256), 0, stream, a, s.gn, na, d);
-  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)(((size_t)nb * d + 255) / 256)), dim3(256), 0, stream, b, s.qb, nb, d, 1, 0);
-  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)(((size_t)na * d + 255) / 256)), dim3(256), 0, stream, a, s.gb, na, d, 1, 1);
-  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, s.gn, na, s.gmax);
-  if (ids_a2b) hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, s.qn, nb, s.qmax);
+  {   // norms, bf16 operands, rounding-error statistics and their maxima of both sets: one launch (rounds 1-3: six)
+    ProfScope prof(VTC_PROF_TOPK, (double)(na + nb) * d * 6, stream);
+    const PrepSide A{b, s.qb, s.qn, s.qst, s.qmax, nb}, B{a, s.gb, s.gn, s.gst, s.gmax, na};
+    launch_sweep_prep(A, B, d, s.pmax, stream);
+  }
   VTC_LAUNCH_CHECK("l2_topk prologue");
   GemmEpi e;
   e.mode = EPI_L2MIN; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
@@ -1132,25 +1302,39 @@ int exact2_impl(const float *a, const float *b, int na, int nb, int d, int depth
   }
   if (int rc = launch_gemm(s.qb, s.gb, nullptr, nullptr, nb, na, d, VTC_BF16, e, stream)) return rc;
   const float kappa = exact2_kappa(d);
+  const MinselArgs m1 = minsel_args(s.rowk, nb, s.nblk_c, 64, s.nblk_c, nullptr, depth, s.qn, s.qst, s.gmax, kappa, s.cand, s.cand_n, s.theta);
+  const Rescan rs1{s.rowk, nb, s.nblk_c, 64, s.nblk_c, 1, nullptr, s.theta};
+  if (!ids_a2b) {
+    {
+      ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * s.nblk_c * nb * 4, stream);
+      launch_minsel(m1, nullptr, stream);
+    }
+    VTC_LAUNCH_CHECK("minsel");
+    return exact_finish(a, b, na, nb, d, depth, CD2, s.cand, nullptr, s.qn, s.gn, s.gmax, s.flags, ids_b2a, dists_b2a, stream, s.cand_n, &s.fb, &rs1);
+  }
+  // both directions: ONE launch per stage (rounds 2-3: two) -- the stages of the two directions are independent, and at 10k x 10k
+  // a direction alone leaves CUs idle (313 minsel workgroups, a re-rank wave per row)
+  const MinselArgs m2 = minsel_args(s.colk, na, s.nblk_r, s.rb, s.nblk_r, nullptr, depth, s.gn, s.gst, s.qmax, kappa, s.cand2, s.cand2_n, s.theta2);
   {
-    ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * s.nblk_c * nb * 4, stream);
-    launch_minsel(s.rowk, nb, s.nblk_c, 64, s.nblk_c, nullptr, depth, s.qn, s.gmax, kappa, s.cand, s.cand_n, s.theta, stream);
+    ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * ((double)s.nblk_c * nb + (double)s.nblk_r * na) * 4, stream);
+    launch_minsel(m1, &m2, stream);
   }
   VTC_LAUNCH_CHECK("minsel");
-  const Rescan rs1{s.rowk, nb, s.nblk_c, 64, s.nblk_c, 1, nullptr, s.theta};
-  if (int rc = exact_finish(a, b, na, nb, d, depth, CD2, s.cand, nullptr, s.qn, s.gn, s.gmax, s.flags, ids_b2a, dists_b2a, stream, s.cand_n, &s.fb,
-                            &rs1))
-    return rc;
-  if (ids_a2b) {
-    {
-      ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * s.nblk_r * na * 4, stream);
-      launch_minsel(s.colk, na, s.nblk_r, s.rb, s.nblk_r, nullptr, depth, s.gn, s.qmax, kappa, s.cand2, s.cand2_n, s.theta2, stream);
-    }
-    VTC_LAUNCH_CHECK("minsel cols");
-    const Rescan rs2{s.colk, na, s.nblk_r, s.rb, s.nblk_r, 1, nullptr, s.theta2};
-    return exact_finish(b, a, nb, na, d, depth, CD2, s.cand2, nullptr, s.gn, s.qn, s.qmax, s.flags, ids_a2b, dists_a2b, stream, s.cand2_n, &s.fb,
-                        &rs2);
+  (void)hipMemsetAsync(s.flags, 0, (size_t)((char *)s.flags2 - (char *)s.flags) + sizeof(int), stream);     // both counters: one fill (the lists between them are rewritten anyway)
+  const RerankArgs r1{b, a, nb, na, d, s.cand, nullptr, CD2, depth, s.qn, s.gmax, 0.f, ids_b2a, dists_b2a, s.flags, s.cand_n};
+  const RerankArgs r2{a, b, na, nb, d, s.cand2, nullptr, CD2, depth, s.gn, s.qmax, 0.f, ids_a2b, dists_a2b, s.flags2, s.cand2_n};
+  {
+    ProfScope prof(VTC_PROF_TOPK, (double)(na + nb) * (2.0 * depth + 1.0) * d * 4, stream);
+    hipLaunchKernelGGL(exact_rerank_kernel, dim3(cdiv(nb, 4) + cdiv(na, 4)), dim3(256), 0, stream, r1, r2, cdiv(nb, 4));
   }
+  {
+    ProfScope prof(VTC_PROF_TOPK, 0.0, stream);
+    const RescanArgs q1{b, a, na, d, depth, s.flags, s.rowk, nb, s.nblk_c, 64, s.nblk_c, 1, nullptr, s.theta, ids_b2a, dists_b2a};
+    const RescanArgs q2{a, b, nb, d, depth, s.flags2, s.colk, na, s.nblk_r, s.rb, s.nblk_r, 1, nullptr, s.theta2, ids_a2b, dists_a2b};
+    const int g1 = std::min(nb, 1024), g2 = std::min(na, 1024);
+    hipLaunchKernelGGL(block_rescan_kernel, dim3(g1 + g2), dim3(256), 0, stream, q1, q2, g1);
+  }
+  VTC_LAUNCH_CHECK("l2_topk exact (both directions)");
   return 0;
 }
 }  // namespace
@@ -1194,13 +1378,16 @@ extern "C" int vtc_l2_sweep_shard_cols(const float *b_all, const float *a_local,
   // gallery = b_all (n_total), queries = a_local (n_local): the plan's qn/gn/cand/flags/fallback areas fit as they are
   Sweep2Ws s = plan2((char *)ws, n_total, n_local, d, false);
   const int rb = vtc_l2_sweep_row_block();
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(n_local, 4)), dim3(256), 0, stream, a_local, s.qn, n_local, d);
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv(n_total, 4)), dim3(256), 0, stream, b_all, s.gn, n_total, d);
-  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(256), 0, stream, s.gn, n_total, s.gmax);
+  {   // statistics only (the operands were rounded by the ranks that ran the GEMMs -- with this same rounding)
+    ProfScope prof(VTC_PROF_TOPK, (double)(n_total + n_local) * d * 4, stream);
+    const PrepSide A{a_local, nullptr, s.qn, s.qst, s.qmax, n_local}, B{b_all, nullptr, s.gn, s.gst, s.gmax, n_total};
+    launch_sweep_prep(A, B, d, s.pmax, stream);
+  }
   const float kappa = exact2_kappa(d);
   {
     ProfScope prof(VTC_PROF_TOPK, (double)(L2MIN_PLANES + 1) * n_src * nblk_pad * n_local * 4, stream);
-    launch_minsel(planes, n_local, n_src * nblk_pad, rb, nblk_pad, src_base, depth, s.qn, s.gmax, kappa, s.cand, s.cand_n, s.theta, stream);
+    const MinselArgs m = minsel_args(planes, n_local, n_src * nblk_pad, rb, nblk_pad, src_base, depth, s.qn, s.qst, s.gmax, kappa, s.cand, s.cand_n, s.theta);
+    launch_minsel(m, nullptr, stream);
   }
   VTC_LAUNCH_CHECK("minsel shard cols");
   const Rescan rs{planes, n_local, n_src * nblk_pad, rb, nblk_pad, n_src, src_base, s.theta};
@@ -1292,12 +1479,16 @@ static int exact_finish(const float *gallery, const float *queries, int ng, int 
   // norms (d * 2^-24), the epilogue's three roundings.  (Block-minima lists arrive certified.)
   const float kappa = 3.0f / 65536.0f + 4.0f * d / 16777216.0f + 1e-6f;
   (void)hipMemsetAsync(flags, 0, sizeof(int), stream);
-  hipLaunchKernelGGL(exact_rerank_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, queries, gallery, nq, ng, d, cand, cand_d, cdepth,
-                     depth, qn, gmax, kappa, ids, dists, flags, cand_n);
+  const RerankArgs ra{queries, gallery, nq, ng, d, cand, cand_d, cdepth, depth, qn, gmax, kappa, ids, dists, flags, cand_n};
+  {   // (work = bytes gathered at ~2 x depth candidates per row: the lists' lengths live on the device)
+    ProfScope prof(VTC_PROF_TOPK, (double)nq * (2.0 * depth + 1.0) * d * 4, stream);
+    hipLaunchKernelGGL(exact_rerank_kernel, dim3(cdiv(nq, 4)), dim3(256), 0, stream, ra, ra, cdiv(nq, 4));
+  }
   int f_first = 0;
   if (rs) {     // block-minima path: the uncertified owners are settled from their own planes (no pass over the gallery)
-    hipLaunchKernelGGL(block_rescan_kernel, dim3(std::min(nq, 2048)), dim3(256), 0, stream, queries, gallery, ng, d, depth, flags, rs->keys,
-                       rs->R, rs->nblk, rs->bw, rs->nbs, rs->n_src, rs->src_base, rs->theta, ids, dists);
+    ProfScope prof(VTC_PROF_TOPK, 0.0, stream);
+    const RescanArgs rr{queries, gallery, ng, d, depth, flags, rs->keys, rs->R, rs->nblk, rs->bw, rs->nbs, rs->n_src, rs->src_base, rs->theta, ids, dists};
+    hipLaunchKernelGGL(block_rescan_kernel, dim3(std::min(nq, 2048)), dim3(256), 0, stream, rr, rr, std::min(nq, 2048));
     VTC_LAUNCH_CHECK("l2_topk block rescan");
     return 0;
   }
@@ -1386,9 +1577,30 @@ extern "C" int vtc_recall_hits(const int64_t *ids, int nq, int depth, int64_t ta
     VTC_CHECK(k_vals[i] >= 1 && k_vals[i] <= depth, "recall_hits: k=%d outside [1, depth=%d]", k_vals[i], depth);
     k[i] = k_vals[i];
   }
-  hipLaunchKernelGGL(recall_hits_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, ids, nq, depth, target_offset,
-                     k[0], k[1], k[2], k[3], nk, (unsigned long long *)hits);
+  {
+    ProfScope prof(VTC_PROF_TOPK, (double)nq * depth * 8, (hipStream_t)stream);
+    hipLaunchKernelGGL(recall_hits_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, ids, nq, depth, target_offset,
+                       k[0], k[1], k[2], k[3], nk, (unsigned long long *)hits, (const int64_t *)nullptr, (unsigned long long *)nullptr);
+  }
   VTC_LAUNCH_CHECK("recall_hits");
+  return 0;
+}
+
+extern "C" int vtc_recall_hits_pair(const int64_t *ids_a, const int64_t *ids_b, int nq, int depth, int64_t target_offset, const int *k_vals,
+                                    int nk, long long *hits_a, long long *hits_b, void *stream) {
+  VTC_CHECK(ids_a && ids_b && hits_a && hits_b, "recall_hits_pair: null argument");
+  VTC_CHECK(nk >= 1 && nk <= 4, "recall_hits_pair: nk=%d must be in [1,4]", nk);
+  int k[4] = {0, 0, 0, 0};
+  for (int i = 0; i < nk; ++i) {
+    VTC_CHECK(k_vals[i] >= 1 && k_vals[i] <= depth, "recall_hits_pair: k=%d outside [1, depth=%d]", k_vals[i], depth);
+    k[i] = k_vals[i];
+  }
+  {
+    ProfScope prof(VTC_PROF_TOPK, 2.0 * nq * depth * 8, (hipStream_t)stream);
+    hipLaunchKernelGGL(recall_hits_kernel, dim3(2 * cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, ids_a, nq, depth, target_offset,
+                       k[0], k[1], k[2], k[3], nk, (unsigned long long *)hits_a, ids_b, (unsigned long long *)hits_b);
+  }
+  VTC_LAUNCH_CHECK("recall_hits_pair");
   return 0;
 }
 

@@ -216,7 +216,14 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
             phases["exchange"] = (f"all_to_all{'' if A2A_MODE == 'list' else '_single'} (RCCL)" if dist.get_backend() == "nccl"
                                   else f"all_to_all_single through host memory ({dist.get_backend()})")
     # compute(a, b): gallery a, queries b (model/metric.py:137-146); this rank owns query rows [lo, hi)
+    pair_done = False
+    if both is not None and both[0].is_cuda and len(ks) <= 4 and both[0].shape == both[1].shape:
+        from . import ops
+        ops.recall_hits_pair(both[0], both[1], ks, lo, hits)        # both directions: one launch
+        pair_done = True
     for d_, (gal, qry) in enumerate(((a_all, feats_b_local), (b_all, feats_a_local))):
+        if pair_done:
+            break
         ids = both[d_] if both is not None else topk(gal, qry, depth)
         if both is None:
             mark("search_b_from_a" if d_ == 0 else "search_a_from_b")

@@ -335,6 +335,18 @@ def sweep_shard_cols(b_all: torch.Tensor, a_local: torch.Tensor, depth: int, pla
 
 
 @on_device
+def recall_hits_pair(ids_a: torch.Tensor, ids_b: torch.Tensor, k_vals: Sequence[int], target_offset: int, hits: torch.Tensor) -> torch.Tensor:
+    """hits[0] += hits of ids_a, hits[1] += hits of ids_b (both [n, depth], same targets): one launch for both directions."""
+    ids_a, ids_b = _gpu(ids_a, torch.int64, "ids_a"), _gpu(ids_b, torch.int64, "ids_b")
+    assert ids_a.shape == ids_b.shape and hits.shape[0] == 2 and hits.is_contiguous()
+    nq, depth = ids_a.shape
+    ks = (C.c_int * len(k_vals))(*[int(k) for k in k_vals])
+    L.check(L.lib().vtc_recall_hits_pair(ids_a.data_ptr(), ids_b.data_ptr(), nq, depth, int(target_offset), ks, len(k_vals),
+                                         hits[0].data_ptr(), hits[1].data_ptr(), _stream()), "vtc_recall_hits_pair")
+    return hits
+
+
+@on_device
 def recall_hits(ids: torch.Tensor, k_vals: Sequence[int], target_offset: int = 0,
                 hits: Optional[torch.Tensor] = None) -> torch.Tensor:
     ids = _gpu(ids, torch.int64, "ids")

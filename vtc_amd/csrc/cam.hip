@@ -583,15 +583,26 @@ int launch_cam_fused(const vtc_cam_w *w, const float *main_feats, const float *c
   ProfScope prof(VTC_PROF_GEMM_F32, 2.0 * p.rows * 12.0 * w->width * w->width * w->layers, stream);
   void *kargs[] = {&p};
   hipError_t le;
+  // VTC_CAM_COOP=0 (diagnostics; read once): an ordinary launch behind an occupancy check instead -- rocprofv3 (ROCm 7.2) segfaults
+  // in its teardown, after writing its output, in any process that made a cooperative launch (tools/exit_probe.py); the profiling
+  // scripts set this so that their runs exit cleanly.  Without the runtime's residency guarantee the bounded spin + error word
+  // below are what stands between a lost CU and a silent wrong answer.
+  static const bool coop = [] { const char *e = getenv("VTC_CAM_COOP"); return !(e && e[0] == '0'); }();
+  auto launch = [&](const void *fn, int shmem) -> hipError_t {
+    if (coop) return hipLaunchCooperativeKernel(fn, dim3(grid), dim3(256), kargs, shmem, stream);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, shmem) != hipSuccess || per_cu < 1) return hipErrorCooperativeLaunchTooLarge;
+    return hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, shmem, stream);
+  };
   vtc_count_launch();
   if (w->width == 512) {
     constexpr int shmem = (4 * 16 * WLD<512> + 4 * 2 * 15 * 64) * 4;
     static PerDeviceOnce attr;
     if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&cam_fused_kernel<512>), shmem, "cam_fused")) return 1;
-    le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&cam_fused_kernel<512>), dim3(grid), dim3(256), kargs, shmem, stream);
+    le = launch(reinterpret_cast<const void *>(&cam_fused_kernel<512>), shmem);
   } else {
     constexpr int shmem = (4 * 16 * WLD<128> + 4 * 2 * 15 * 64) * 4;
-    le = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&cam_fused_kernel<128>), dim3(grid), dim3(256), kargs, shmem, stream);
+    le = launch(reinterpret_cast<const void *>(&cam_fused_kernel<128>), shmem);
   }
   if (le != hipSuccess) {
     (void)hipGetLastError();      // (the profiler then holds one empty record for this call)

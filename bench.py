@@ -18,7 +18,10 @@ Top-level objects beside the contract's fields:
                 BASELINE.md section 2: the video tower's time + space attention branches (LayerNorm + QKV + attention core +
                 out-proj + temporal_fc + cls bookkeeping launches) at the reference's 4.27 GFLOP per layer per video,
                 over their summed kernel time, as a fraction of 2.5 PFLOP/s.
-  sweep_10000_ms / sweep_50000_ms (+ _hbm_frac)
+  headline_batch_independence[_max_err]
+                items [0:16] and [B-16:B] of the timed batch re-encoded as two B = 16 forwards (the shape the tests and the
+                cpu_baseline leg hold to the oracle): max abs error of the embeddings and of the cosine block; > 1e-3 fails the run.
+  sweep_10000_ms / sweep_50000_ms (+ _hbm_frac, _phases_ms_per_rank)
                 the second half of BASELINE's metric: N x N similarity + R@1/5/10 in both directions, parity mode
                 (EXACT), sharded over the ranks; fraction of 8 TB/s at the algorithmic 2 x 8 N^2 bytes.
   cpu_baseline  the oracle (plain PyTorch fp32 restatement of the reference, kind "port") on this box's host cores,

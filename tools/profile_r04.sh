@@ -10,9 +10,9 @@ cd /tmp
 # (tools/exit_probe.py): the one-launch CAM goes out as an ordinary launch behind an occupancy check for these runs
 export VTC_CAM_COOP=0
 export VTC_OVERLAP=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/r04_stats -- python3 $R/bench.py --steps 8 --warmup 2 --no-extra --no-cpu --no-sweep > $O/r04_stats.json 2> $O/r04_stats.err || echo "(non-zero exit: see the .err file; rocprofv3 has written its output before the process teardown)"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/r04_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-extra --no-cpu --no-sweep > /dev/null 2> $O/r04_fetch.err || echo "(non-zero exit: see the .err file; rocprofv3 has written its output before the process teardown)"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/r04_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-extra --no-cpu --no-sweep > /dev/null 2> $O/r04_write.err || echo "(non-zero exit: see the .err file; rocprofv3 has written its output before the process teardown)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/r04_stats -- python3 $R/bench.py --steps 8 --warmup 2 --no-extra --no-cpu --no-sweep --no-independence > $O/r04_stats.json 2> $O/r04_stats.err || echo "(non-zero exit: see the .err file; rocprofv3 has written its output before the process teardown)"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/r04_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-extra --no-cpu --no-sweep --no-independence > /dev/null 2> $O/r04_fetch.err || echo "(non-zero exit: see the .err file; rocprofv3 has written its output before the process teardown)"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/r04_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-extra --no-cpu --no-sweep --no-independence > /dev/null 2> $O/r04_write.err || echo "(non-zero exit: see the .err file; rocprofv3 has written its output before the process teardown)"
 unset VTC_OVERLAP
 for s in 1 2 4 8 16; do
   export VTC_GEMM_SUPER=$s

@@ -6,9 +6,8 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out
 cd /tmp
-# rocprofv3 (ROCm 7.2) segfaults in its teardown -- after writing its output -- in a process that made a cooperative launch
-# (tools/exit_probe.py): the one-launch CAM goes out as an ordinary launch behind an occupancy check for these runs
-export VTC_CAM_COOP=0
+# (the one-launch CAM is an ordinary launch by default; VTC_CAM_COOP=1 -- cooperative -- makes rocprofv3 of ROCm 7.2 segfault
+# in its teardown, after writing its output: tools/exit_probe.py)
 export VTC_OVERLAP=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r04_stats -- python3 $R/bench.py --steps 8 --warmup 2 --no-extra --no-cpu --no-sweep --no-independence > $O/r04_stats.json 2> $O/r04_stats.err || echo "(non-zero exit: see the .err file; rocprofv3 has written its output before the process teardown)"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/r04_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-extra --no-cpu --no-sweep --no-independence > /dev/null 2> $O/r04_fetch.err || echo "(non-zero exit: see the .err file; rocprofv3 has written its output before the process teardown)"

@@ -574,20 +574,20 @@ int launch_cam_fused(const vtc_cam_w *w, const float *main_feats, const float *c
   p.act = w->residual_activation; p.scale = w->squash_scale; p.bn_mean = w->bn_mean; p.bn_var = w->bn_var;
   p.out = adapted;
   VTC_CHECK(hipMemsetAsync(bar, 0, CAM_BAR_BYTES, stream) == hipSuccess, "cam_fused: barrier reset failed");
-  // Every workgroup must be resident for the grid barrier: one per CU (width 512: 136 KiB of LDS each, so exactly one fits), and
-  // the launch is COOPERATIVE (hipLaunchCooperativeKernel): the runtime checks that the grid fits the device with this kernel's
-  // resources and orders cooperative grids among themselves, so no workgroup waits for one that cannot become resident because
-  // something else (a persistent GEMM on a side stream, RCCL, a CU mask) holds its CU.  A launch the
-  // runtime refuses (too large for the CUs this process may use) is not an error: -1 sends the caller down the multi-launch path.
+  // Every workgroup must be resident for the grid barrier: one per CU (width 512: 136 KiB of LDS each, so exactly one fits).
+  // nothing guaranteed that.  Two launch forms, measured in round 4 (profiles/r04_experiments.txt):
+  //   * default -- an ordinary launch behind an occupancy check of THIS kernel on THIS device (grid <= CUs x resident workgroups per
+  //     CU, else -1: the caller takes the multi-launch path).  What the check cannot see (a foreign kernel holding a CU: another
+  //     process, RCCL, a CU mask) ends in the bounded spin of grid_barrier: NaN embeddings AND the device-visible error word
+  //     below, which fails every later call on the device with a message -- loud, never a silent wrong answer;
+  //   * VTC_CAM_COOP=1 (read once) -- hipLaunchCooperativeKernel: the runtime validates residency and serialises cooperative
+  //     grids.  Not the default because it costs +0.11 ms per forward at B = 1 (+6 %; the cooperative queue hand-over) and because
+  //     rocprofv3 of ROCm 7.2 segfaults in its teardown in any process that made one (tools/exit_probe.py).
   const int grid = vtcgemm::num_cus();
   ProfScope prof(VTC_PROF_GEMM_F32, 2.0 * p.rows * 12.0 * w->width * w->width * w->layers, stream);
   void *kargs[] = {&p};
   hipError_t le;
-  // VTC_CAM_COOP=0 (diagnostics; read once): an ordinary launch behind an occupancy check instead -- rocprofv3 (ROCm 7.2) segfaults
-  // in its teardown, after writing its output, in any process that made a cooperative launch (tools/exit_probe.py); the profiling
-  // scripts set this so that their runs exit cleanly.  Without the runtime's residency guarantee the bounded spin + error word
-  // below are what stands between a lost CU and a silent wrong answer.
-  static const bool coop = [] { const char *e = getenv("VTC_CAM_COOP"); return !(e && e[0] == '0'); }();
+  static const bool coop = [] { const char *e = getenv("VTC_CAM_COOP"); return e && e[0] == '1'; }();
   auto launch = [&](const void *fn, int shmem) -> hipError_t {
     if (coop) return hipLaunchCooperativeKernel(fn, dim3(grid), dim3(256), kargs, shmem, stream);
     int per_cu = 0;

@@ -871,35 +871,3 @@ def test_every_model_type_forward_vs_oracle(arch_name, model_type):
         pv = towers.PackedVision(cuda_sd({k: v for k, v in sdi.items() if k.startswith("model.visual.")}), "model.visual.", dtype)
         out = pv.forward(img.cuda()).cpu().numpy()
         report(f"{model_type} image tower {dtype}", np.abs(unit(out) - unit(refi)).max(), tol_for(dtype, 512))
-
-
-def test_small_batch_fold_statistics_merged_by_the_last_tile_are_stable_and_right():
-    """Round 4: at small batches the LayerNorm statistics of the folded scheme are merged by the LAST column tile of each row block
-    of the residual GEMM (gemm.hip: fold_merge_tail -- an in-launch hand-off between workgroups on different CUs / XCDs: agent-scope
-    release + ticket + acquire) instead of a fold_stats_kernel launch.  The partials buffer is re-used by every residual GEMM of a
-    forward, so a missing or mis-scoped acquire would read the previous GEMM's partials from a stale cache line.  Screen: the
-    same forward repeated must be bit-identical every time (a race shows as a run that differs), at three sizes that put 1 .. many
-    tiles on a row block's counter, and agree with the oracle."""
-    from vtc_amd import towers
-    a = A.VIT_B32
-    sdv = A.synth_visual(a, 81, nframes=8, prefix="model.visual.")
-    g = torch.Generator().manual_seed(82)
-    for k in list(sdv):
-        if k.endswith("temporal_fc.weight"):
-            sdv[k] = torch.randn(sdv[k].shape, generator=g) * 0.02
-    pvt = towers.PackedVision(cuda_sd(sdv), "model.visual.", torch.bfloat16)
-    sdt = A.synth_text(a, 83, prefix="model.")
-    pt = towers.PackedText(cuda_sd(sdt), "model.", torch.bfloat16, heads=a.transformer_heads)
-    for B, reps in ((1, 30), (7, 15), (50, 6)):
-        vid = A.synth_pixels((B, 8, 3, 224, 224), 84 + B).cuda().bfloat16()
-        txt = A.synth_tokens(6 * B, a, 85 + B, empty_frac=0.1).cuda()
-        first_v = pvt.forward(vid).clone()
-        first_t = pt.forward(txt).clone()
-        for _ in range(reps):
-            assert torch.equal(pvt.forward(vid), first_v), f"video tower not reproducible at B={B}"
-            assert torch.equal(pt.forward(txt), first_t), f"text tower not reproducible at B={B}"
-        n = min(B, 2)
-        ref = T.timesformer_alt(vid[:n].float().cpu(), sdv, a, "model.visual.").numpy()
-        report(f"TimeSformer B={B} (statistics merged in the GEMM) vs oracle", np.abs(unit(first_v[:n].cpu().numpy()) - unit(ref)).max(), 1e-3)
-        reft = CR.encode_text(txt[:4].cpu(), sdt, a, "model.").numpy()
-        report_text(f"text S={6 * B} (statistics merged in the GEMM) vs oracle", unit(first_t[:4].cpu().numpy()), unit(reft), torch.bfloat16, a.embed_dim)

@@ -210,11 +210,6 @@ struct GemmEpi {
                               // the operand copy (no third array); `out` (fp32) is neither read nor written
   float *fold_part = nullptr;
   const float *fold_stat = nullptr, *fold_s = nullptr;
-  // producer, small problems (round 4): the LAST column tile of a row block merges the block's partials into fold_stat_out
-  // itself (what fold_stats_kernel does in a launch of its own).  fold_cnt: one arrival counter per 64 rows, zero before the
-  // first launch that uses it (the last arriver resets its own); nullptr: the separate kernel runs.
-  int *fold_cnt = nullptr;
-  float *fold_stat_out = nullptr;
   // the row count M in DEVICE memory (*m_dev <= the M handed to launch_gemm, which then only sizes the grid): the ragged text
   // tower without a host sync (vtc_text_forward2) -- the persistent kernels read it when they start
   const int *m_dev = nullptr;

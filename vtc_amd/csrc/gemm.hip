@@ -624,53 +624,6 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
 
 }
 
-// ---- folded LayerNorm, producer side at SMALL sizes: the row statistics merged by the last column tile of a row block -------------
-// At a batch of 1-64 videos a forward is 250 launches and 60 of them are fold_stats_kernel at its ~5 us floor (14 % of a B = 1
-// forward, 5 % at B = 50: profiles/r04_experiments.txt).  Here every tile of a residual GEMM, once its epilogue has stored the
-// (hi, lo) rows and the per-(64 columns, row) partials, takes a ticket on its row block; the tile that draws NT - 1 knows that
-// every partial of the block is stored and merges them exactly as fold_stats_kernel does (same arithmetic, same order: the
-// statistics are bit-identical).  The hand-off is the guide's counter form (cdna_hip_programming.md 5 "in-launch split-K
-// reduction" / Guideline 16): plain stores -> EVERY wave s_waitcnt vmcnt(0) -> workgroup barrier -> one lane: agent-scope
-// release fence, its own wait, relaxed agent-scope fetch_add; the last arriver: agent-scope acquire fence + wait by one lane,
-// barrier, then plain VECTOR loads by every wave.  Correct for any placement of a block's tiles over CUs / XCDs.  The drain in
-// front of the ticket gives back what the relaxed first wait of the next tile earns, so the towers ask for this only where a
-// CU runs one or two tiles per launch (towers.hip: resid_proj).  (noinline: registers apart from the K loop's.)
-// (arguments by value: a GemmParams passed by reference would live in scratch, and the K loop's wave-uniform operands with it)
-template <int BM_>
-__device__ __attribute__((noinline)) void fold_merge_tail(int *fold_cnt, float *fold_part, float *fold_stat_out, int M, int N, int NT, int m0,
-                                                          int *word) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave: its stores have left
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (keep: fence, wait, THEN the ticket -- Guideline 16, Pitfall 12)
-    *word = __hip_atomic_fetch_add(fold_cnt + m0 / BM_, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (*word != NT - 1) return;                                  // uniform: the other tiles of the block just leave
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(fold_cnt + m0 / BM_, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch (stream order)
-  }
-  __syncthreads();
-  const int nb = N >> 6;
-  float *part = fold_part;                                      // (not const __restrict__: these bytes must stay off the scalar path)
-  for (int r = threadIdx.x; r < BM_ && m0 + r < M; r += blockDim.x) {
-    const size_t m = (size_t)(m0 + r);
-    float sum = 0.f;
-    for (int q = 0; q < nb; ++q) sum += part[2 * ((size_t)q * M + m)];
-    const float mean = sum / (64.0f * nb);
-    float m2 = 0.f;
-    for (int q = 0; q < nb; ++q) {
-      const float2 v = *reinterpret_cast<const float2 *>(part + 2 * ((size_t)q * M + m));
-      const float d = v.x * (1.0f / 64.0f) - mean;
-      m2 += v.y + 64.0f * d * d;
-    }
-    *reinterpret_cast<float2 *>(fold_stat_out + 2 * m) = make_float2(mean, 1.0f / sqrtf(m2 / (64.0f * nb) + 1e-5f));
-  }
-}
-
 // WM x WN waves, each owning TM x TN MFMA tiles of 16x16.
 // NSTAGE LDS buffers: 2 = wait for the next slab at the end of every K-step; 3 = the LDS-DMA of slab
 // t+2 is issued at step t and only slab t+1 is waited for (counted s_waitcnt vmcnt(G)), so two slabs are
@@ -812,10 +765,6 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(GemmParams p) {
     }
 
     tile_epilogue<T, MODE, OutT, WM, WN, TM, TN, STAGE / NW>(acc, p, m0, n0, ((cur + NSTAGE - 1) % NSTAGE) * STAGE);
-    if constexpr (MODE == EPI_RESID_FOLD || MODE == EPI_RESID_FOLD_C) {
-      if (p.epi.fold_cnt)
-        fold_merge_tail<BM>(p.epi.fold_cnt, p.epi.fold_part, p.epi.fold_stat_out, p.M, p.N, p.NT, m0, reinterpret_cast<int *>(lds + NSTAGE * STAGE));   // one word behind the stages (run() asks for it)
-    }
     if (has_next) __syncthreads();         // the transposition area becomes the next K-step's staging buffer
 
     if (!has_next) break;
@@ -1221,9 +1170,6 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
     VTC_STAMP(1);       // re-join wait
 
     tile_epilogue<T, MODE, OutT, WM, WN, TM, TN, STAGE / NW>(acc, p, m0, n0, (cur ^ 1) * STAGE);
-    if constexpr (MODE == EPI_RESID_FOLD || MODE == EPI_RESID_FOLD_C) {
-      if (p.epi.fold_cnt) fold_merge_tail<BM>(p.epi.fold_cnt, p.epi.fold_part, p.epi.fold_stat_out, p.M, p.N, p.NT, m0, reinterpret_cast<int *>(lds + 2 * STAGE));
-    }
     if constexpr (MODE == EPI_RESID_LN) {
       int *ticket = reinterpret_cast<int *>(lds + 2 * STAGE);       // one word behind the two stages (run_phased asks for it)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // EVERY storing wave drains its write-through stores ...
@@ -1267,7 +1213,7 @@ int run(GemmParams p, hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT_ = WM * WN * 64;
   p.MT = cdiv(p.M, BM); p.NT = cdiv(p.N, BN);
   const int ntiles = p.MT * p.NT;
-  const size_t shmem = (size_t)NSTAGE * (BM + BN) * ROWB + ((MODE == EPI_RESID_FOLD || MODE == EPI_RESID_FOLD_C) ? 16 : 0);   // (+ the ticket word)
+  const size_t shmem = (size_t)NSTAGE * (BM + BN) * ROWB;
   const int wg_per_cu = shmem > 80 * 1024 ? 1 : 2;
   const int grid = min(ntiles, num_cus() * wg_per_cu);
   static PerDeviceOnce attr;
@@ -1283,7 +1229,7 @@ template <int MODE, typename OutT, typename T, int DEEP>
 int run_phased_d(GemmParams p, hipStream_t stream) {
   p.MT = cdiv(p.M, 256); p.NT = cdiv(p.N, 256);
   const int ntiles = p.MT * p.NT;
-  const size_t shmem = (size_t)2 * 512 * ROWB + ((MODE == EPI_RESID_LN || MODE == EPI_RESID_FOLD || MODE == EPI_RESID_FOLD_C) ? 16 : 0);   // 128 KiB: one workgroup per CU (+ the ticket word)
+  const size_t shmem = (size_t)2 * 512 * ROWB + (MODE == EPI_RESID_LN ? 16 : 0);   // 128 KiB: one workgroup per CU (+ the ticket word)
   const int grid = min(ntiles, num_cus());
   static PerDeviceOnce attr;
   if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&gemm_phased_kernel<MODE, OutT, T, DEEP>), (int)shmem, "gemm_phased")) return 1;
@@ -1428,7 +1374,6 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
     VTC_CHECK(gemm_resid_ln_supported(M, N, K, dtype), "gemm: fused residual + LayerNorm does not cover M=%d N=%d K=%d dtype=%d", M, N, K, dtype);
     VTC_CHECK(epi.ln_g && epi.ln_b && epi.ln_out && epi.ln_cnt && (epi.ldo == 0 || epi.ldo == N), "gemm: fused LayerNorm arguments");
   }
-  VTC_CHECK(!epi.fold_cnt || (epi.y16 && epi.fold_stat_out), "gemm: fold_cnt goes with the (hi, lo) residual epilogue and fold_stat_out");
   if (epi.y16 || epi.fold_stat) {     // folded LayerNorm: only the interior fast epilogues carry it
     // (the consumer may write its N columns into a wider output -- ldo > N: a column window of a projection; the producer's (hi, lo)
     // arrays are indexed with ldo too, so there ldo == N)

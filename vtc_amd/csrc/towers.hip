@@ -34,7 +34,6 @@ extern "C" const char *vtc_last_error(void) { return g_err; }
 extern "C" int vtc_abi_version(void) { return 5; }
 int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res, const float *mean, const float *stdv, hipStream_t stream);
 int patch_k_padded(int patch);
-namespace vtcgemm { int num_cus(); }
 int launch_pixels_u8_to_operand(const void *px, void *out, int dtype, int n_frames, int res, const float *mean, const float *stdv, hipStream_t stream);
 int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, int T, int W, hipStream_t stream);
 int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int F, int T, int W, hipStream_t stream);
@@ -104,7 +103,6 @@ struct Fold {
                             // stream lives in (xb, xl) and the fp32 x is stale (GemmEpi::y16lo)
   float *part = nullptr;    // [W / 64][rows_pad] (sum, squared deviations)
   float *stat = nullptr;    // [rows_pad] (mean, rstd)
-  int *cnt = nullptr;       // [rows_pad / 64] arrival counters of the producer-side merge (zeroed once per forward); nullptr: fold_stats_kernel
   int rows_pad = 0;
   int fmt = -1;             // operand format (xb, xl) / stat currently hold (-1: the stream is the fp32 x)
 };
@@ -114,20 +112,6 @@ int fold_merge_rows(Fold &f, float *x, int n, int W, const int *row_index, int r
   return launch_split_merge_rows(f.xb, f.xl, x, n, W, row_index, row_mul, f.fmt, s);
 }
 inline int pad256(int rows) { return (rows + 255) / 256 * 256; }
-// Producer-side merge of the LayerNorm statistics (gemm.hip: fold_merge_tail) instead of a fold_stats_kernel launch behind every
-// residual GEMM: where a CU runs at most two 256 x 256 tiles of that GEMM per launch (a forward of <= ~100 videos / ~140 pairs of
-// text), the launch is the cost; beyond, the drain in front of the ticket is.  The plan always reserves the counters; this
-// decides, zeroes them once per forward, or drops them (VTC_FOLD_MERGE=0: never, diagnostics; read once).
-int fold_merge_setup(Fold &f, int W, hipStream_t s) {
-  static const bool off = [] { const char *e = getenv("VTC_FOLD_MERGE"); return e && e[0] == '0'; }();
-  const long tiles = (long)(f.rows_pad / 256) * (W / 256);
-  if (!f.on || off || tiles > 2L * vtcgemm::num_cus()) {
-    f.cnt = nullptr;
-    return 0;
-  }
-  VTC_CHECK(hipMemsetAsync(f.cnt, 0, (size_t)(f.rows_pad / 64 + 4) * 4, s) == hipSuccess, "fold_merge: counter reset failed");
-  return 0;
-}
 bool fold_usable(const vtc_block_w *blocks, int layers, int W, int dtype, bool timesformer, int flags) {
   if ((flags & (VTC_TOWER_NO_LN_FOLD | VTC_TOWER_FUSED_ATTN | VTC_TOWER_FUSED_ATTN_SPACE)) || dtype == VTC_F32 || W % 256 != 0) return false;
   for (int l = 0; l < layers; ++l)
@@ -193,10 +177,6 @@ int resid_proj(Fold &f, const void *A, const void *w, const float *bias, float *
       if (f.fmt >= 0) RUN(launch_split_merge_rows(f.xb, f.xl, x, rows.n, W, nullptr, 1, f.fmt, s, rows.dev));
       RUN(launch_cast_rowstats(x, f.xb, f.xl, f.stat, rows.n, W, dtype, s, rows.dev));
       f.fmt = dtype;
-    }
-    if (f.cnt) {      // small problem: the last column tile of each row block merges the statistics (gemm.hip: fold_merge_tail)
-      e.fold_cnt = f.cnt; e.fold_stat_out = f.stat;
-      return launch_gemm(A, w, bias, x, f.rows_pad, W, K, dtype, e, s);
     }
     RUN(launch_gemm(A, w, bias, x, f.rows_pad, W, K, dtype, e, s));
     return launch_fold_stats(f.part, W / 64, f.rows_pad, f.stat, s, rows.dev_pad());
@@ -325,7 +305,6 @@ VisionWs plan_vision(const vtc_vision_w *w, int n_items, int F, int dtype, void 
     v.fold.xl = b.take(rows * W * 2);
     v.fold.part = (float *)b.take((size_t)(W / 64 + 1) * rows * 8);
     v.fold.stat = (float *)b.take(rows * 8);
-    v.fold.cnt = (int *)b.take((rows / 64 + 4) * 4);
   }
   plan_tail(b, v.tail, n_items, W);
   v.total = b.off;
@@ -360,7 +339,6 @@ TextWs plan_text(int rows_, int n_seq, int W, int dtype, void *ws) {
     t.fold.xl = b.take(rows * W * 2);
     t.fold.part = (float *)b.take((size_t)(W / 64 + 1) * rows * 8);
     t.fold.stat = (float *)b.take(rows * 8);
-    t.fold.cnt = (int *)b.take((rows / 64 + 4) * 4);
   }
   plan_tail(b, t.tail, n_seq, W);
   t.total = b.off;
@@ -422,7 +400,6 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
 
   Fold &fold = v.fold;
   fold.on = fold_usable(w->blocks, w->layers, W, dtype, tsf, w->flags);
-  RUN(fold_merge_setup(fold, W, s));
   const bool prune = prune_last(w->flags);
   const bool tail_q = prune_last_queries(w->flags) && !(tsf && w->variant == 1);   // ... and its queries (not on the v1 tower's global cls attention)
   for (int l = 0; l < w->layers; ++l) {
@@ -549,7 +526,6 @@ int text_forward_impl(const vtc_text_w *w, const TextIds &ids, int mode, const i
   else RUN(launch_text_embed_ragged(ids, w->tok_emb, w->pos, offs, t.x, t.eot, n_seq, w->ctx, W, w->vocab, s));
   Fold &fold = t.fold;
   fold.on = fold_usable(w->blocks, w->layers, W, dtype, false, w->flags);
-  RUN(fold_merge_setup(fold, W, s));
   // attention work of the ragged batch for the profiler (the lengths are not known here): rows x (mean length ~ ctx / 2)
   const double attn_flops_per_row = 4.0 * (0.5 * w->ctx) * 64 * w->heads;
   const bool prune = prune_last(w->flags), tail_q = prune_last_queries(w->flags);

@@ -112,10 +112,23 @@ def midpoint_case(n_gallery=2048, d=512, depth=11):
     return g, q[None]
 
 
-def certificate_sets(gallery, query, depth, kappa, bw=64):
+def measured_eps(gallery, query, kappa_fp32):
+    """Round 4's per-row error bound (sweep.hip: sweep_prep_kernel + minsel_kernel): with x~ = bf16(x) and e = x - x~ the rows'
+    ACTUAL rounding errors, | q~.g~ - q.g | = | q~.e_g + e_q.g~ + e_q.e_g | <= |q~||e_g| + |e_q||g~| + |e_q||e_g| (Cauchy-Schwarz),
+    twice that on the distance, the gallery side by its maxima, plus kappa_fp32 (|q|^2 + max|g|^2) for the fp32 terms; the same
+    1e-4 slack on the measured norms and 1e-3 on the whole as the kernels carry."""
+    q, g = query[0].astype(np.float64), gallery.astype(np.float64)
+    qt, gt = bf16_round(query[0]).astype(np.float64), bf16_round(gallery).astype(np.float64)
+    nq_t, e_q = np.sqrt((qt ** 2).sum()) * 1.0001, np.sqrt(((q - qt) ** 2).sum()) * 1.0001
+    ng_t, e_g = np.sqrt((gt ** 2).sum(1)).max() * 1.0001, np.sqrt(((g - gt) ** 2).sum(1)).max() * 1.0001
+    return 1.001 * (2.0 * (nq_t * e_g + e_q * ng_t + e_q * e_g) + kappa_fp32 * ((q ** 2).sum() + (g ** 2).sum(1).max()))
+
+
+def certificate_sets(gallery, query, depth, kappa, bw=64, eps=None):
     """The block-minima certificate of sweep.hip (minsel_kernel) restated for ONE query: plain-bf16 approximate distances in
-    fp32, per-block three smallest + the fourth as a bound, u = depth-th smallest block minimum, theta = u + 2 kappa
-    (|q|^2 + max|g|^2).  Returns (candidate ids with approx <= theta, certified?, approx distances)."""
+    fp32, per-block three smallest + the fourth as a bound, u = depth-th smallest block minimum, theta = u + 2 eps with
+    eps = kappa (|q|^2 + max|g|^2) (rounds 2-3: a worst-case constant) or the `eps` given (round 4: measured_eps).
+    Returns (candidate ids with approx <= theta, certified?, approx distances)."""
     qb, gb = bf16_round(query[0]), bf16_round(gallery)
     qn = np.float32((query[0].astype(np.float64) ** 2).sum())
     gn = (gallery.astype(np.float64) ** 2).sum(1).astype(np.float32)
@@ -131,7 +144,7 @@ def certificate_sets(gallery, query, depth, kappa, bw=64):
         pool += list(o[:3])
         fourth.append(approx[o[3]] if len(o) > 3 else np.inf)
     u = np.sort(np.array(mins))[depth - 1]
-    theta = u + 2.0 * kappa * (qn + gn.max())
+    theta = u + 2.0 * (kappa * (qn + gn.max()) if eps is None else eps)
     pool = np.array(pool)
     cand = pool[approx[pool] <= theta]
     return cand, bool(min(fourth) > theta and cand.size <= 64), approx

@@ -125,3 +125,39 @@ def test_certificate_error_bound_needs_the_full_bf16_roundoff():
     err = approx.astype(np.float64) - exact
     bound = k_new * (float((q.astype(np.float64) ** 2).sum()) + float((g.astype(np.float64) ** 2).sum(1).max()))
     assert np.abs(err).max() <= bound and np.abs(err).max() > 0.5 * bound * 0.55     # the case really exercises the bound
+
+
+def test_measured_rounding_error_bound_is_rigorous_and_tighter():
+    """Round 4: the certificate's eps is built from the rows' MEASURED bf16 rounding errors (|x - bf16(x)|, exact in fp32) instead
+    of the worst case 2^-8 |x| (oracle/sweep_planes.measured_eps = sweep.hip sweep_prep_kernel + minsel_kernel).  It must (a) still
+    bound every entry's error -- also on the adversarial midpoint case, where every coordinate's error IS the worst case, so the
+    bound may not shrink there -- and keep the true nearest row in the certified list; (b) be several times smaller on ordinary
+    embeddings, which is what shrinks the candidate sets."""
+    from oracle import sweep_planes as SP
+    d, depth = 512, 11
+    k_fp32 = 2.0 * d / 2 ** 24 + 2.0 ** -15 + 1e-6
+    k_worst = 2.0 ** -7 * (1 + 2.0 ** -9) + k_fp32
+    # (a) adversarial
+    g, q = SP.midpoint_case(d=d, depth=depth)
+    exact = ((g.astype(np.float64) - q.astype(np.float64)) ** 2).sum(1)
+    eps = SP.measured_eps(g, q, k_fp32)
+    cand, cert, approx = SP.certificate_sets(g, q, depth, None, eps=eps)
+    assert np.abs(approx.astype(np.float64) - exact).max() <= eps
+    assert cert and 0 in cand
+    worst = k_worst * (float((q.astype(np.float64) ** 2).sum()) + float((g.astype(np.float64) ** 2).sum(1).max()))
+    assert eps > 0.45 * worst                # the rows that carry the case sit on midpoints: no free lunch there (the +-1 fillers round exactly)
+    # (b) unit-norm random embeddings with a planted neighbourhood
+    rng = np.random.default_rng(3)
+    g = rng.standard_normal((4096, d)).astype(np.float32)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    q = (g[7] + 0.05 * rng.standard_normal(d).astype(np.float32))[None]
+    q /= np.linalg.norm(q)
+    exact = ((g.astype(np.float64) - q.astype(np.float64)) ** 2).sum(1)
+    eps = SP.measured_eps(g, q, k_fp32)
+    worst = k_worst * (float((q.astype(np.float64) ** 2).sum()) + float((g.astype(np.float64) ** 2).sum(1).max()))
+    cand_m, cert_m, approx = SP.certificate_sets(g, q, depth, None, eps=eps)
+    cand_w, cert_w, _ = SP.certificate_sets(g, q, depth, k_worst)
+    assert np.abs(approx.astype(np.float64) - exact).max() <= eps
+    assert eps < 0.5 * worst and cand_m.size <= cand_w.size      # measured |e| ~ 0.0016 |x| on random data against the worst case 0.0039 |x|
+    top = np.argsort(exact, kind="stable")[:depth]
+    assert cert_m and set(top) <= set(cand_m.tolist())

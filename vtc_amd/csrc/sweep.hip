@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict
 // agree in sign, exponent and the top mantissa bits, so the difference is representable) -- plus the running maxima of all three
 // over the set (per-block maxima, folded by sweep_prep_max_kernel).
 //   | q~.g~ - q.g | = | q~.e_g + e_q.g~ + e_q.e_g |  <=  |q~||e_g| + |e_q||g~| + |e_q||e_g|          (Cauchy-Schwarz)
-// With |e| <= 2^-8 |x| this is the worst-case bound of rounds 2-3 (2u + u^2)|q||g|; on real embeddings |e| ~ 0.3 x 2^-8 |x|, so
+// With |e| <= 2^-8 |x| this is the worst-case bound of rounds 2-3 (2u + u^2)|q||g|; on real embeddings |e| ~ 0.4 x 2^-8 |x|, so
 // the bound is ~0.45 x that and the candidate sets shrink accordingly -- and rows that do sit on bf16 midpoints (the adversarial test) still get the
 // full bound, because |e| is measured, not assumed.  Both norms carry a 1e-4 relative slack for their fp32 summation.
 struct PrepSide {

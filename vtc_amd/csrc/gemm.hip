@@ -95,12 +95,28 @@ __device__ __forceinline__ unsigned umed3(unsigned x, unsigned y, unsigned z) {
   asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
   return r;
 }
+// (bits & ~mask) | (idx & mask): a key from a distance's bit pattern and an index inside the block, one VALU (v_bfi_b32)
+__device__ __forceinline__ unsigned key_bfi(unsigned mask, unsigned idx, unsigned bits) {
+  unsigned r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(idx), "v"(bits));
+  return r;
+}
+// the value the lane 16 / 32 away holds (lane ^ 16, lane ^ 32): v_permlane16_swap / v_permlane32_swap of a register with itself leave
+// the partner half's value in one of the two results -- no LDS round trip (ds_bpermute) as __shfl_xor compiles to
+__device__ __forceinline__ unsigned xor32_of(unsigned x, bool upper) {
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);     // r[0]: lanes 32-63 <- x[0-31];  r[1]: lanes 0-31 <- x[32-63]
+  return upper ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned xor16_of(unsigned x, bool odd_row) {
+  const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);     // r[0]: odd 16-lane rows <- the even row below;  r[1]: even rows <- the odd row above
+  return odd_row ? r[0] : r[1];
+}
 // Sorted quadruple of the four smallest keys seen.
 struct Min4 {
   unsigned a, b, c, d;
   __device__ __forceinline__ void init() { a = b = c = d = VTC_L2MIN_INF; }
-  __device__ __forceinline__ void insert(unsigned k) {       // 5 VALU: a, b, c shift up around k; d = fourth smallest
-    d = min(d, max(c, k));
+  __device__ __forceinline__ void insert(unsigned k) {       // 4 VALU: a, b, c shift up around k; d = fourth smallest of {a, b, c, d, k}
+    d = umed3(c, d, k);          // k <= c: c;  c < k < d: k;  k >= d: d   (round 4: was min(d, max(c, k)))
     c = umed3(b, c, k);
     b = umed3(a, b, k);
     a = min(a, k);
@@ -154,8 +170,8 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
       for (int e = 0; e < 4; ++e) {
         // a distance that rounding made negative (a query against itself: |q|^2 in fp32 minus |bf16(q)|^2) clamps to zero --
         // as a signed-integer max, which needs no canonicalisation; its key then sorts first, as it must
-        const unsigned bits = (unsigned)max(__float_as_int((rn - 2.0f * acc[i][j][e]) + cn[j][e]), 0) & ~127u;
-        unsigned kr = bits | (unsigned)(16 * j + 4 * g + e), kc = bits | (unsigned)(16 * i + l15);
+        const unsigned bits = (unsigned)max(__float_as_int((rn - 2.0f * acc[i][j][e]) + cn[j][e]), 0);
+        unsigned kr = key_bfi(127u, (unsigned)(16 * j + 4 * g + e), bits), kc = key_bfi(127u, (unsigned)(16 * i + l15), bits);
         if (!interior) {
           const bool v = mv && ((cvalid >> (4 * j + e)) & 1);
           kr = v ? kr : VTC_L2MIN_INF;
@@ -165,10 +181,10 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
         if (cols_too) col[j][e].insert(kc);
       }
     // the row's 64 columns of this wave sit in the four lanes l15 + 16 g: merge (xor 16, xor 32)
-#pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-      const unsigned oa = __shfl_xor(row.a, o, 64), ob = __shfl_xor(row.b, o, 64), oc = __shfl_xor(row.c, o, 64), od = __shfl_xor(row.d, o, 64);
-      row.merge(oa, ob, oc, od);
+    {
+      const bool odd = (g & 1) != 0, up = g >= 2;
+      row.merge(xor16_of(row.a, odd), xor16_of(row.b, odd), xor16_of(row.c, odd), xor16_of(row.d, odd));
+      row.merge(xor32_of(row.a, up), xor32_of(row.b, up), xor32_of(row.c, up), xor32_of(row.d, up));
     }
     // lane g stores plane g (keys 1-3, bound): 16 consecutive rows each (64-byte segments).  A wave whose 64 columns lie
     // wholly past N owns no block (its slot would be the next plane's block 0).
@@ -1242,7 +1258,7 @@ int run_phased_d(GemmParams p, hipStream_t stream) {
 template <int MODE, typename OutT, typename T>
 int run_phased(const GemmParams &p, hipStream_t stream) {
   // the deep pipeline needs two K-tiles per tile; the fused-LayerNorm tail and the sweep's block-minima epilogue stay on the
-  // round-3 loop (their register budgets are the tightest of all instantiations)
+  // round-3 loop (register budgets: EPI_L2MIN with the deep loop spills 18 registers and measures the same, r04_experiments.txt 7)
   if constexpr (MODE != EPI_RESID_LN && MODE != EPI_L2MIN) {
     if (p.K >= 128) {
       if (g_deep == 1) return run_phased_d<MODE, OutT, T, 1>(p, stream);

@@ -271,8 +271,9 @@ def test_build_refuses_probe_macros():
 
 def test_every_advertised_model_type_constructs_or_refuses_at_construction():
     """VERDICT r3 missing #4: `CONFIGS` advertises what the reference's factory does (model/timesformer_clip_alt.py:290-310).  Every
-    key builds the wrappers with the reference's state-dict shapes; the one combination the HIP path does not cover (a CAM whose
-    head_dim is not 64: ViT-L/14's 768-d features with the default n_heads=8) says so in the constructor, not at the first forward.
+    key builds the wrappers with the reference's state-dict shapes and the reference's DEFAULT n_heads = 8 (ViT-L/14: head_dim 96, the
+    generic short-sequence attention core); what the HIP path does not cover (a CAM head_dim beyond 128 or not an integer) says so
+    in the constructor, not at the first forward.
     (Forwards of every key: tests/test_gpu_towers.py::test_every_model_type_forward_vs_oracle.)"""
     import warnings
     from dataclasses import replace
@@ -281,8 +282,7 @@ def test_every_advertised_model_type_constructs_or_refuses_at_construction():
     for name, cfg in clip_arch.CONFIGS.items():
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            heads = cfg.embed_dim // 64
-            c = HM.PretrainedCLIP_TimeSformer_finaltf(model_type=name, n_heads=heads)
+            c = HM.PretrainedCLIP_TimeSformer_finaltf(model_type=name)          # the reference's default n_heads = 8
             P = (cfg.image_resolution // cfg.vision_patch_size) ** 2
             v = c.model.visual
             assert v.positional_embedding.shape == (1 + P, cfg.vision_width) and v.temporal_embed.shape == (8, cfg.vision_width)
@@ -290,11 +290,13 @@ def test_every_advertised_model_type_constructs_or_refuses_at_construction():
             assert len(v.transformer.resblocks) == cfg.vision_layers and v.proj.shape == (cfg.vision_width, cfg.embed_dim)
             assert c.final_transformer.width == cfg.embed_dim and c.mask_embedding.shape == (1, cfg.embed_dim)
             del c
-    # the refusal, on a small architecture with ViT-L/14's feature width (768 = 12 x 64 != 8 x 64)
+    # the refusal, on a small architecture with ViT-L/14's feature width: 768 / 4 = 192 > 128, 768 / 7 not an integer
     small = replace(clip_arch.CONFIGS["ViT-L/14"], vision_layers=1, vision_width=128, transformer_layers=1,
                     vocab_size=49408)        # feature_dim = the text width 768 (model/model.py:394)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        with pytest.raises(NotImplementedError, match="head_dim"):
-            HM.PretrainedCLIP_finaltf(model_type=small)
+        for bad in (4, 7):
+            with pytest.raises(NotImplementedError, match="head_dim"):
+                HM.PretrainedCLIP_finaltf(model_type=small, n_heads=bad)
+        HM.PretrainedCLIP_finaltf(model_type=small)                  # default 8 heads of 96
         HM.PretrainedCLIP_finaltf(model_type=small, n_heads=12)

@@ -482,3 +482,31 @@ def test_gemm_resid_layernorm_equals_two_launches(dtype, M, N, K, skip):
     if a2 is not None:
         ops.gemm_resid_layernorm(a2, w, b, x, ln_g, ln_b, skip_mod=skip, ln_out=a2)
         assert torch.equal(x, x_ref) and torch.equal(a2, h_ref)
+
+
+@pytest.mark.parametrize("hd,L_", [(96, 6), (32, 16), (128, 3), (64, 6)])
+def test_cam_attention_any_head_dim_vs_fp32_reference(hd, L_):
+    """Round 4: the Context Adapter Module with head_dim != 64 (ViT-L/14's 768-d features at the reference's default n_heads = 8:
+    head_dim 96) runs its 1 + nc tokens through a generic short-sequence core; checked through vtc_cam_forward against the
+    oracle's CAM (model/model.py:141-205 restated) on random CAM weights."""
+    from oracle import arch as A
+    from oracle import model_ref as M
+    from vtc_amd import towers
+    heads = 4
+    D = heads * hd
+    nc = L_ - 1
+    a = A.ClipArch(embed_dim=D, transformer_width=D)
+    sd = A.synth_cam(a, 5, n_layers=2)
+    g = torch.Generator().manual_seed(hd + L_)
+    for k in list(sd):
+        if k.endswith("out_proj.weight") or k.endswith("c_proj.weight"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.05
+    B = 5
+    main = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=-1)
+    aux = torch.randn(nc, B, D, generator=g)
+    want = M.adapt_feature(main, aux, sd, n_heads=heads)
+    pc = towers.PackedCam({k: v.cuda() for k, v in sd.items()}, torch.float32, heads, True, None)
+    comments = torch.full((B, nc, 77), 5, dtype=torch.int64)      # no empty comment: aux is used as given
+    comments[..., 0] = 49406
+    got = pc.forward(main.cuda(), aux.permute(1, 0, 2).reshape(B * nc, D).contiguous().cuda(), comments.cuda()).cpu()
+    assert (got - want).abs().max() < 1e-5, float((got - want).abs().max())

@@ -831,7 +831,8 @@ def test_one_launch_cam_from_two_streams_at_once():
 def test_every_model_type_forward_vs_oracle(arch_name, model_type):
     """VERDICT r3 missing #4: the other two model types of the reference's factory (model/timesformer_clip_alt.py:297-310) through
     the drop-in wrappers -- 197 / 257 tokens per frame (the K/V-tiled attention core), patch 16 / 14 (K = 768 / 588 -> 640 padded),
-    width 1024 x 24 layers, 768-d features (CAM with n_heads = 12) -- against the live oracle: fp32 1e-5, bf16 1e-3."""
+    width 1024 x 24 layers, 768-d features with the reference's DEFAULT n_heads = 8 (ViT-L/14: CAM head_dim 96, the generic
+    short-sequence attention core) -- against the live oracle: fp32 1e-5, bf16 1e-3."""
     import warnings
     from vtc_amd.host import model as HM
     a = ARCH[arch_name]
@@ -844,7 +845,7 @@ def test_every_model_type_forward_vs_oracle(arch_name, model_type):
     vid = A.synth_pixels((B, F, 3, 224, 224), 93)
     title = A.synth_tokens(B, a, 94)
     comments = A.synth_tokens(B * 5, a, 95, empty_frac=0.2).reshape(B, 5, -1)
-    heads = a.embed_dim // 64
+    heads = 8                                # model/model.py:546 default
     ref = M.pretrained_clip_timesformer_finaltf(vid, title, comments, sd, a, "text", n_heads=heads)
 
     class _TSF(HM.PretrainedCLIP_TimeSformer_finaltf):

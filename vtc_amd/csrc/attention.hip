@@ -376,6 +376,59 @@ __global__ __launch_bounds__(256) void attn_tiled_kernel(const AttnParams p, int
   }
 }
 
+// ---- any head_dim, short contiguous sequences (round 4): the Context Adapter Module when feature_dim / n_heads != 64 --------------
+// (ViT-L/14: 768-d features with the reference's default n_heads = 8 -> head_dim 96, model/model.py:396-398).  L <= 16 tokens,
+// head_dim <= 128: one wave per (sequence, head), lane l owns head dimensions l and l + 64; the L x L scores are wave reductions
+// (the CAM is 1 + nc = 6 tokens: 36 of them), softmax in registers, q scaled by head_dim^-0.5 as upstream nn.MultiheadAttention
+// does.  Not a throughput kernel: the module is ~0.06 % of a forward's FLOPs.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_generic_small_kernel(const T *__restrict__ qkv, T *__restrict__ out, int n_seq, int L, int heads, int hd) {
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= n_seq * heads) return;
+  const int s = gw / heads, h = gw - s * heads;
+  const int W = heads * hd;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const bool d0 = lane < hd, d1 = lane + 64 < hd;
+  float q[16][2], k[16][2], v[16][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    q[i][0] = q[i][1] = k[i][0] = k[i][1] = v[i][0] = v[i][1] = 0.f;
+    if (i < L) {
+      const T *r = qkv + (size_t)(s * L + i) * 3 * W + h * hd;
+      if (d0) { q[i][0] = ElemOps<T>::load(r + lane) * scale; k[i][0] = ElemOps<T>::load(r + W + lane); v[i][0] = ElemOps<T>::load(r + 2 * W + lane); }
+      if (d1) { q[i][1] = ElemOps<T>::load(r + lane + 64) * scale; k[i][1] = ElemOps<T>::load(r + W + lane + 64); v[i][1] = ElemOps<T>::load(r + 2 * W + lane + 64); }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i < L) {                                   // wave-uniform (no `break`: the loop stays fully unrolled, q / k / v in registers)
+    float sc[16], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      sc[j] = -INFINITY;
+      if (j < L) {
+        sc[j] = wave_sum(q[i][0] * k[j][0] + q[i][1] * k[j][1]);
+        mx = fmaxf(mx, sc[j]);
+      }
+    }
+    float sum = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < L) {
+        const float e = expf(sc[j] - mx);
+        sum += e;
+        o0 = fmaf(e, v[j][0], o0);
+        o1 = fmaf(e, v[j][1], o1);
+      }
+    }
+    T *dst = out + (size_t)(s * L + i) * W + h * hd;
+    if (d0) ElemOps<T>::store(dst + lane, o0 / sum);
+    if (d1) ElemOps<T>::store(dst + lane + 64, o1 / sum);
+    }
+  }
+}
+
 // Global cls attention of model/timesformer_clip.py:81,158: the cls query of each item attends to ALL
 // T tokens of the item.  One wave per (item, head); lanes = the 64 head dimensions; scores via a
 // wave reduction per key, kept in LDS; output row = the item's cls row.  T up to 1024.
@@ -600,6 +653,18 @@ int launch_attention(const void *qkv, void *out, float *cls_out, int n_seq, int 
   ProfScope prof(VTC_PROF_ATTN, 4.0 * L * L * 64 * (double)n_seq * heads, stream);
   if (dtype == VTC_F16) return dispatch<f16_t>(p, stream);
   return dtype == VTC_BF16 ? dispatch<bf16_t>(p, stream) : dispatch<float>(p, stream);
+}
+
+// contiguous sequences of L <= 16 tokens, any head_dim <= 128 (the CAM with head_dim != 64); unmasked
+int launch_attention_generic_small(const void *qkv, void *out, int n_seq, int L, int heads, int hd, int dtype, hipStream_t stream) {
+  VTC_CHECK(n_seq > 0 && L >= 1 && L <= 16 && heads > 0 && hd >= 1 && hd <= 128, "attention (generic head_dim): n_seq=%d L=%d heads=%d head_dim=%d", n_seq, L, heads, hd);
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "attention (generic head_dim): dtype %d", dtype);
+  ProfScope prof(VTC_PROF_ATTN, 4.0 * L * L * hd * (double)n_seq * heads, stream);
+  const dim3 grid(cdiv(n_seq * heads, 4));
+  if (dtype == VTC_F32) hipLaunchKernelGGL((attn_generic_small_kernel<float>), grid, dim3(256), 0, stream, (const float *)qkv, (float *)out, n_seq, L, heads, hd);
+  else hipLaunchKernelGGL((attn_generic_small_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t *)qkv, (bf16_t *)out, n_seq, L, heads, hd);
+  VTC_LAUNCH_CHECK("attention_generic_small");
+  return 0;
 }
 
 // Ragged batch: sequence s occupies the packed rows [seq_offsets[s], seq_offsets[s+1]); max_L bounds the lengths.

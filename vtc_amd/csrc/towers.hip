@@ -41,6 +41,7 @@ int launch_text_prep(const TextIds &ids, int n_seq, int ctx, int *lens, int *off
 int launch_text_embed(const TextIds &ids, const float *tok, const float *pos, float *x, int *eot_row, int n_seq, int ctx, int W, int vocab, hipStream_t stream);
 int launch_text_embed_ragged(const TextIds &ids, const float *tok, const float *pos, const int *seq_offsets, float *x, int *eot_row, int n_seq, int ctx, int W, int vocab, hipStream_t stream);
 int launch_attention_ragged(const void *qkv, void *out, int n_seq, int max_L, int heads, int causal, const int *seq_offsets, double flops, const int *rows_dev, int dtype, hipStream_t stream);
+int launch_attention_generic_small(const void *qkv, void *out, int n_seq, int L, int heads, int hd, int dtype, hipStream_t stream);
 int launch_cam_tokens(const float *main_f, const float *comm, const int64_t *comments, const float *mask_emb, float *X, int B, int nc, int ctx, int D, hipStream_t stream);
 int launch_cls_global_attention(const void *qkv, void *out, int n_items, int Ttok, int heads, int dtype, hipStream_t stream);
 int launch_cam_finalize(const float *Y, const float *lin, const float *main_f, float *out, int B, int Lc, int D, int init_from_avg, int act, float scale, const float *bn_mean, const float *bn_var, hipStream_t stream);
@@ -209,7 +210,12 @@ int attn_part_contig(Fold &f, const vtc_block_w &b, float *x, void *h, void *big
     return 0;
   }
   RUN(ln_proj(f, x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, h, big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));
-  RUN(launch_attention(big, h, nullptr, n_seq, L, heads, causal, 1, 0, L, 0, 0, 1, dtype, s));
+  if (W != heads * 64) {      // the CAM with head_dim != 64 (ViT-L/14's 768-d features at the reference's default n_heads = 8)
+    VTC_CHECK(!causal && W % heads == 0, "attention: head_dim %d/%d", W, heads);
+    RUN(launch_attention_generic_small(big, h, n_seq, L, heads, W / heads, dtype, s));
+  } else {
+    RUN(launch_attention(big, h, nullptr, n_seq, L, heads, causal, 1, 0, L, 0, 0, 1, dtype, s));
+  }
   if (tail_src) { *tail_src = h; return 0; }
   RUN(resid_proj(f, h, b.out_w, b.out_b, x, rows, W, W, dtype, 0, s));
   return 0;
@@ -606,7 +612,8 @@ extern "C" int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, cons
   VTC_CHECK(w && main_feats && comm_feats && comments && adapted && ws, "cam_forward: null argument");
   VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "cam_forward: bad dtype %d", dtype);
   VTC_CHECK(B > 0 && nc >= 0 && 1 + nc <= 80, "cam_forward: B=%d nc=%d", B, nc);
-  VTC_CHECK(w->width == w->heads * 64, "cam_forward: head_dim must be 64 (width %d heads %d)", w->width, w->heads);
+  VTC_CHECK(w->heads >= 1 && w->width % w->heads == 0 && (w->width == w->heads * 64 || (w->width / w->heads <= 128 && 1 + nc <= 16)),
+            "cam_forward: head_dim %d / %d: 64, or <= 128 with at most 16 tokens per item", w->width, w->heads);
   const int D = w->width, Lc = 1 + nc, rows = B * Lc;
   TextWs t = plan_text(rows, B, D, dtype, ws);
   float *lin = (float *)((char *)ws + t.total);

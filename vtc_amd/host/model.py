@@ -223,11 +223,13 @@ class PretrainedCLIPBase(nn.Module):
 
     def _init_cam(self, n_layers, n_heads, init_from_avg):
         """model/model.py:396-400, :440-452."""
-        if self.feature_dim != int(n_heads) * 64:
-            # known at construction, so said at construction (never at the first forward): the HIP attention cores are built for
-            # head_dim 64 -- every reference config has it (512 / 8); ViT-L/14's 768-d features need n_heads=12
-            raise NotImplementedError(f"Context Adapter Module: head_dim must be 64 on the HIP path (feature_dim {self.feature_dim}, "
-                                      f"n_heads {n_heads}); pass n_heads={self.feature_dim // 64}")
+        hd, rem = divmod(self.feature_dim, int(n_heads))
+        if rem or hd > 128:
+            # known at construction, so said at construction (never at the first forward): the CAM's attention core covers head_dim 64
+            # (every reference config: 512 / 8; the MFMA kernels) and any head_dim <= 128 (ViT-L/14's 768 / 8 = 96: a small
+            # generic kernel, round 4)
+            raise NotImplementedError(f"Context Adapter Module: head_dim = feature_dim / n_heads must be an integer <= 128 on the HIP path "
+                                      f"(feature_dim {self.feature_dim}, n_heads {n_heads})")
         self.final_transformer = clip_arch.Transformer(width=self.feature_dim, layers=int(n_layers), heads=int(n_heads))
         self.final_linear = nn.Linear(self.feature_dim, self.feature_dim, bias=False)
         self.mask_embedding = nn.Parameter(torch.randn(1, self.feature_dim))

@@ -374,8 +374,8 @@ class PackedCam:
         w = L.CamW()
         w.width = sd["final_linear.weight"].shape[0]
         w.heads = heads
-        if w.width != heads * 64:
-            raise NotImplementedError(f"CAM head_dim must be 64 on the HIP path (width {w.width}, heads {heads})")
+        if w.width % heads or w.width // heads > 128:
+            raise NotImplementedError(f"CAM head_dim must be an integer <= 128 on the HIP path (width {w.width}, heads {heads})")
         w.layers = _n_layers(sd, "final_transformer")
         w.init_from_avg = int(bool(init_from_avg))
         w.residual_activation, w.squash_scale = _ACTS[residual_activation]

@@ -95,7 +95,7 @@ def _worker_one_matrix(rank, world, port, n, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(3, 601), (2, 400), (3, 101)])       # ragged shards, padded blocks (601 = 201 + 200 + 200 rows)
+@pytest.mark.parametrize("world,n", [(3, 601), (2, 400), (3, 101), (8, 1003)])       # ragged shards, padded blocks (601 = 201 + 200 + 200 rows); 8 ranks = the node the sweep is specified for (1003 = 3 x 126 + 5 x 125)
 def test_one_matrix_sharded_sweep_exchange(world, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -872,3 +872,23 @@ def test_every_model_type_forward_vs_oracle(arch_name, model_type):
         pv = towers.PackedVision(cuda_sd({k: v for k, v in sdi.items() if k.startswith("model.visual.")}), "model.visual.", dtype)
         out = pv.forward(img.cuda()).cpu().numpy()
         report(f"{model_type} image tower {dtype}", np.abs(unit(out) - unit(refi)).max(), tol_for(dtype, 512))
+
+
+def test_dense_text_chunking_covers_both_id_arrays():
+    """TEXT_CHUNK used to be ignored whenever a second id array was given.  Dense path, chunks of 5 sequences over
+    titles + comments == the unchunked call, bit for bit (the towers are per-sequence functions)."""
+    from vtc_amd import towers
+    a = A.TINY
+    sd = A.synth_text(a, 91, prefix="model.")
+    pt = towers.PackedText(cuda_sd(sd), "model.", torch.float32, heads=a.transformer_heads)
+    t1, t2 = A.synth_tokens(7, a, 92).cuda(), A.synth_tokens(13, a, 93, empty_frac=0.2).cuda()
+    whole = pt.forward(t1, ragged=False, ids_b=t2)
+    was = towers.TEXT_CHUNK
+    try:
+        towers.TEXT_CHUNK = 5
+        chunked = pt.forward(t1, ragged=False, ids_b=t2)
+    finally:
+        towers.TEXT_CHUNK = was
+    assert torch.equal(whole, chunked)
+    ref = CR.encode_text(torch.cat([t1, t2]).cpu(), sd, a, "model.").numpy()
+    report("dense text, chunked, two id arrays vs oracle", np.abs(unit(chunked.cpu().numpy()) - unit(ref)).max(), 1e-5)

@@ -21,8 +21,6 @@
 // head_dim is fixed at 64 (upstream: heads = width / 64).
 #include "common.h"
 
-namespace vtcgemm { int num_cus(); }
-
 namespace {
 
 struct AttnParams {
@@ -33,7 +31,6 @@ struct AttnParams {
   int s2, a0, a1, a2, a3, pstride;
   const int *seq_offsets;   // ragged mode: sequence s = rows [seq_offsets[s], seq_offsets[s+1]) (overrides the affine map)
   int W;  // model width = heads * 64
-  int qsplit = 1;           // attn_kernel: waves per (sequence, head) -- wave u takes the 16-query tiles u, u + qsplit, ... (small batches)
 };
 
 template <typename T> struct AT;
@@ -73,11 +70,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   T *vt = reinterpret_cast<T *>(lds_raw) + (size_t)wave * 64 * VS;
 
   int gw = blockIdx.x * 4 + wave;
-  const int total = p.n_seq * p.heads * p.qsplit;
+  const int total = p.n_seq * p.heads;
   const bool active = gw < total;
   if (!active) gw = total - 1;              // keep every wave alive for the barrier; stores are predicated
-  const int qt0 = gw % p.qsplit;            // small batches: the query tiles of a (sequence, head) are dealt out to qsplit waves
-  gw /= p.qsplit;
   const int s = gw / p.heads, h = gw - s * p.heads;
   const int s_hi = s / p.s2, s_lo = s - s_hi * p.s2;
   const long base = p.seq_offsets ? (long)p.seq_offsets[s] : (long)s_hi * p.a1 + (long)s_lo * p.a2 + p.a0;
@@ -124,12 +119,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     for (int ks = 0; ks < KS; ++ks) q[ks] = *reinterpret_cast<const uint4 *>(r + (4 * ks + g) * 16);
   };
   uint4 qf[KS], qn[KS];
-  const int qstep = p.qsplit;
-  load_q(qt0, qf);
-  for (int qt = qt0; qt < NT; qt += qstep) {
+  load_q(0, qf);
+  for (int qt = 0; qt < NT; ++qt) {
     if (qt * 16 >= L) break;
     const int qtok = qt * 16 + c16;
-    if (qt + qstep < NT && (qt + qstep) * 16 < L) load_q(qt + qstep, qn);
+    if (qt + 1 < NT && (qt + 1) * 16 < L) load_q(qt + 1, qn);
     f32x4 sc[NT];
     float mx = -INFINITY;
 #pragma unroll
@@ -614,12 +608,8 @@ int run(const AttnParams &p, hipStream_t stream) {
   const size_t shmem = (size_t)4 * 64 * VS * sizeof(T);
   static PerDeviceOnce attr;
   if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&attn_kernel<T, NT>), (int)shmem, "attention")) return 1;
-  // few (sequence, head) units (a forward of a handful of videos: 96 at B = 1): one wave per 16-query tile instead of per unit --
-  // the units' serial walk over their query tiles is the kernel's whole duration there
-  AttnParams q = p;
-  q.qsplit = (NT > 1 && (long)p.n_seq * p.heads * NT <= 8L * vtcgemm::num_cus()) ? NT : 1;
-  const int total = p.n_seq * p.heads * q.qsplit;
-  hipLaunchKernelGGL((attn_kernel<T, NT>), dim3(cdiv(total, 4)), dim3(256), shmem, stream, q);
+  const int total = p.n_seq * p.heads;
+  hipLaunchKernelGGL((attn_kernel<T, NT>), dim3(cdiv(total, 4)), dim3(256), shmem, stream, p);
   VTC_LAUNCH_CHECK("attention");
   return 0;
 }

@@ -54,6 +54,28 @@ __global__ void mfma_f32_kernel(const float *__restrict__ seed, float *__restric
   if (r == 12345.678f) sink[0] = r;
 }
 
+// sixteen DIFFERENT operand pairs (one per accumulator): more operand toggling than the constant-operand loop above
+template <int NACC>
+__global__ __launch_bounds__(512) void mfma_bf16_var_kernel(const uint4 *__restrict__ seed, float *__restrict__ sink, int iters) {
+  bf16x8 a[NACC], b[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    a[i] = __builtin_bit_cast(bf16x8, seed[(threadIdx.x + 7 * i) & 127]);
+    b[i] = __builtin_bit_cast(bf16x8, seed[(threadIdx.x + 13 * i + 5) & 127]);
+  }
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[i], acc[i], 0, 0, 0);
+  }
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (r == 12345.678f) sink[0] = r;
+}
+
 static float time_ms(hipEvent_t a, hipEvent_t b) { float ms; hipEventElapsedTime(&ms, a, b); return ms; }
 
 int main() {
@@ -109,6 +131,32 @@ int main() {
     t = time_ms(e0, e1) / 3 * 1e-3;
     flops = (double)cus * (threads / 64) * iters * 16 * (2.0 * 16 * 16 * 4);
     printf("MFMA f32  16x16x4,  %d wave(s)/SIMD, random operands: %.1f TFLOP/s\n", wps, flops / t / 1e12);
+  }
+  // ---- sustained: ~1.5 s of back-to-back bf16 MFMA launches (two waves per SIMD, sixteen operand pairs), one reading per ~100 ms
+  //      window, and the clock / socket power rocm-smi reports half a second in (the 2.4 ms bursts above run before DVFS reacts)
+  {
+    const int threads = 512, per = 20, windows = 15;
+    std::vector<hipEvent_t> ev(windows + 1);
+    for (auto &e : ev) hipEventCreate(&e);
+    hipLaunchKernelGGL((mfma_bf16_var_kernel<16>), dim3(cus), dim3(threads), 0, 0, (const uint4 *)seed, sink, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(ev[0]);
+    for (int w = 0; w < windows; ++w) {
+      for (int r = 0; r < per; ++r)
+        hipLaunchKernelGGL((mfma_bf16_var_kernel<16>), dim3(cus), dim3(threads), 0, 0, (const uint4 *)seed, sink, iters);
+      hipEventRecord(ev[w + 1]);
+    }
+    hipEventSynchronize(ev[4]);
+    if (FILE *f = popen("rocm-smi --showclocks --showpower 2>/dev/null | grep -E 'sclk|Power' ", "r")) {
+      char line[512];
+      while (fgets(line, sizeof line, f)) printf("  [rocm-smi during the sustained run] %s", line);
+      pclose(f);
+    }
+    hipEventSynchronize(ev[windows]);
+    const double flops = (double)cus * (threads / 64) * iters * 16 * (2.0 * 16 * 16 * 32) * per;
+    printf("MFMA bf16 16x16x32 sustained, 2 waves/SIMD, 16 operand pairs, TFLOP/s per ~100 ms window:");
+    for (int w = 0; w < windows; ++w) printf(" %.0f", flops / (time_ms(ev[w], ev[w + 1]) * 1e-3) / 1e12);
+    printf("\n");
   }
   return 0;
 }

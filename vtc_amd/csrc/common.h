@@ -67,6 +67,19 @@ template <typename T> __device__ __forceinline__ unsigned short cvt16(float f);
 template <> __device__ __forceinline__ unsigned short cvt16<bf16_t>(float f) { return f2bf(f); }
 template <> __device__ __forceinline__ unsigned short cvt16<f16_t>(float f) { return f2h(f); }
 
+// two floats -> one word of the operand format T, a in the low half (one v_cvt_pk_bf16_f32 / two v_cvt_f16_f32 + pack: same roundings as cvt16)
+template <typename T> __device__ __forceinline__ unsigned pack16(float a, float b);
+template <> __device__ __forceinline__ unsigned pack16<bf16_t>(float a, float b) {
+  typedef float f2v_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf2v_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2v_t){a, b}, bf2v_t));
+}
+template <> __device__ __forceinline__ unsigned pack16<f16_t>(float a, float b) {
+  typedef float f2v_t __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2v_t){a, b}, h2v_t));
+}
+
 // raw 16 bits of the operand format T -> float
 template <typename T> __device__ __forceinline__ float up16(unsigned short b);
 template <> __device__ __forceinline__ float up16<bf16_t>(unsigned short b) { return __builtin_bit_cast(float, ((unsigned)b) << 16); }

@@ -230,13 +230,22 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
   }
 }
 
-template <typename T, int MODE_T, typename OutT, int WM, int WN, int TM, int TN, int SCRATCH_PER_WAVE>
+// REJOIN (the phased kernel): waves 0 .. WN-1 run one barrier ahead of the others and wait for them here -- AFTER the tile's small
+// vectors (bias, folded-LayerNorm statistics, first residual rows) have been requested, BEFORE the LDS scratch is touched (it is the
+// stage the lagging half reads last).  Every path executes the barrier exactly once.
+template <typename T, int MODE_T, typename OutT, int WM, int WN, int TM, int TN, int SCRATCH_PER_WAVE, bool REJOIN = false>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmParams &p, int m0, int n0, unsigned scratch_off) {
   // EPI_*_FOLD = the base epilogue + the folded LayerNorm, compiled apart so that the plain kernels keep their registers
   constexpr bool FOLD = MODE_T >= EPI_FOLD_BASE;
   constexpr bool CENTER = MODE_T == EPI_RESID_FOLD_C;
   constexpr int MODE = CENTER ? VTC_EPI_RESID : (FOLD ? MODE_T - EPI_FOLD_BASE : MODE_T);
+  auto rejoin = [&]() __attribute__((always_inline)) {
+    if constexpr (REJOIN) {
+      if ((int)(threadIdx.x >> 6) / WN == 0) __builtin_amdgcn_s_barrier();
+    }
+  };
   if constexpr (MODE == EPI_L2MIN) {
+    rejoin();
     if constexpr (TN == 4) l2min_epilogue<WM, WN, TM, TN>(acc, p, m0, n0);
     return;
   }
@@ -272,25 +281,43 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       char *trb = lds + scratch_off + wave * SCRATCH_PER_WAVE;
       const int l15 = lane & 15;
       const int ncol0 = n0 + wc * TN * 16;
+      // The tile's small vectors -- bias, row statistics, s -- are requested back to back and waited for ONCE (one uniform branch
+      // around the bias loads: a select per load made hipcc wait for each of them in turn -- with the statistics and s, six
+      // dependent round trips per tile before the first store, profiles/r04_experiments.txt 10), and before the re-join barrier.
       float4 b4[TN];
+      if (p.bias) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b4[j] = p.bias ? *reinterpret_cast<const float4 *>(p.bias + ncol0 + 16 * j + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4 *>(p.bias + ncol0 + 16 * j + 4 * g);
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       // folded LayerNorm (GemmEpi::fold_stat): v = rstd_m (acc - mean_m s_n) + c_n, the row statistics in the MFMA layout
       // (row = lane & 15 of fragment row i), fetched before the first store of the tile
       // The wave's TM * 16 rows of (mean, rstd) and TN * 16 columns of s wait in the wave's LDS scratch behind the two
       // transposition buffers (32 + 16 registers less than holding them: the K loop leaves none to spare).
       [[maybe_unused]] float *fold_rs = reinterpret_cast<float *>(trb + 2 * 16 * TSB);
       [[maybe_unused]] float *fold_sc = fold_rs + 2 * TM * 16;
+      constexpr int NQ = (TM * 16 + 63) / 64;
+      [[maybe_unused]] float2 fst[NQ];
+      [[maybe_unused]] float4 fsc = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (FOLD) {
         static_assert(2 * 16 * TSB + (2 * TM * 16 + TN * 16) * 4 <= SCRATCH_PER_WAVE, "folded LayerNorm: row statistics + s in the wave's scratch");
 #pragma unroll
-        for (int q = 0; q < (TM * 16 + 63) / 64; ++q) {
-          const int r = lane + 64 * q;
-          if (TM * 16 % 64 == 0 || r < TM * 16)
-            *reinterpret_cast<float2 *>(fold_rs + 2 * r) = *reinterpret_cast<const float2 *>(p.epi.fold_stat + 2 * (size_t)(m0 + wr * TM * 16 + r));
+        for (int q = 0; q < NQ; ++q) {
+          const int r = min(lane + 64 * q, TM * 16 - 1);
+          fst[q] = *reinterpret_cast<const float2 *>(p.epi.fold_stat + 2 * (size_t)(m0 + wr * TM * 16 + r));
         }
-        if (lane < TN * 4) *reinterpret_cast<float4 *>(fold_sc + 4 * lane) = *reinterpret_cast<const float4 *>(p.epi.fold_s + ncol0 + 4 * lane);
+        fsc = *reinterpret_cast<const float4 *>(p.epi.fold_s + ncol0 + 4 * (lane & (TN * 4 - 1)));
+      }
+      rejoin();
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int r = lane + 64 * q;
+          if (TM * 16 % 64 == 0 || r < TM * 16) *reinterpret_cast<float2 *>(fold_rs + 2 * r) = fst[q];
+        }
+        if (lane < TN * 4) *reinterpret_cast<float4 *>(fold_sc + 4 * lane) = fsc;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -306,19 +333,29 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
           if constexpr (FOLD) {
             const float2 st = *reinterpret_cast<const float2 *>(fold_rs + 2 * (i * 16 + l15));
             const float4 sj = *reinterpret_cast<const float4 *>(fold_sc + 16 * j + 4 * g);
-            const float mu = st.x, rstd = st.y;
-            v0 = rstd * (acc[i][j][0] - mu * sj.x) + b4[j].x; v1 = rstd * (acc[i][j][1] - mu * sj.y) + b4[j].y;
-            v2 = rstd * (acc[i][j][2] - mu * sj.z) + b4[j].z; v3 = rstd * (acc[i][j][3] - mu * sj.w) + b4[j].w;
+            // two packed fmas per register pair, pairs as the accumulator holds them ((0,1), (2,3)): left to itself hipcc pairs
+            // (0,2) / (1,3) and spends six moves per four values on it.  Same two roundings per value as the scalar form.
+            typedef float f2_t __attribute__((ext_vector_type(2)));
+            const f2_t nmu = {-st.x, -st.x}, rs = {st.y, st.y};
+            const f2_t t01 = __builtin_elementwise_fma(nmu, (f2_t){sj.x, sj.y}, (f2_t){acc[i][j][0], acc[i][j][1]});
+            const f2_t t23 = __builtin_elementwise_fma(nmu, (f2_t){sj.z, sj.w}, (f2_t){acc[i][j][2], acc[i][j][3]});
+            const f2_t w01 = __builtin_elementwise_fma(rs, t01, (f2_t){b4[j].x, b4[j].y});
+            const f2_t w23 = __builtin_elementwise_fma(rs, t23, (f2_t){b4[j].z, b4[j].w});
+            v0 = w01.x; v1 = w01.y; v2 = w23.x; v3 = w23.y;
           } else {
             v0 = acc[i][j][0] + b4[j].x; v1 = acc[i][j][1] + b4[j].y; v2 = acc[i][j][2] + b4[j].z; v3 = acc[i][j][3] + b4[j].w;
           }
           if (MODE == VTC_EPI_GELU) {
-            v0 = quick_gelu<sizeof(T) == 4>(v0); v1 = quick_gelu<sizeof(T) == 4>(v1);
-            v2 = quick_gelu<sizeof(T) == 4>(v2); v3 = quick_gelu<sizeof(T) == 4>(v3);
+            if constexpr (sizeof(T) == 4) {
+              v0 = quick_gelu<true>(v0); v1 = quick_gelu<true>(v1); v2 = quick_gelu<true>(v2); v3 = quick_gelu<true>(v3);
+            } else {
+              const gelu_f2_t g01 = quick_gelu2((gelu_f2_t){v0, v1}), g23 = quick_gelu2((gelu_f2_t){v2, v3});
+              v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y;
+            }
           }
           uint2 pk;
-          pk.x = (unsigned)cvt16<OutT>(v0) | ((unsigned)cvt16<OutT>(v1) << 16);
-          pk.y = (unsigned)cvt16<OutT>(v2) | ((unsigned)cvt16<OutT>(v3) << 16);
+          pk.x = pack16<OutT>(v0, v1);
+          pk.y = pack16<OutT>(v2, v3);
           *reinterpret_cast<uint2 *>(buf + l15 * TSB + j * 32 + g * 8) = pk;
         }
       };
@@ -427,30 +464,37 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     // TM * 16 means wait in its LDS scratch behind the transposition buffer.
     // (fold_stat == NULL: this update does not re-centre -- the towers do it once per layer, in c_proj's epilogue)
     [[maybe_unused]] float *mean_prev = tr + 16 * TS;
+    // (requested here, with the first residual rows below and before the re-join barrier; written to the scratch after it)
+    constexpr int NQM = (TM * 16 + 63) / 64;
+    [[maybe_unused]] float mprev[NQM];
     if constexpr (SPLIT && CENTER) {
       static_assert((16 * TS + TM * 16) * 4 <= SCRATCH_PER_WAVE, "folded LayerNorm: previous means in the wave's scratch");
-      {
 #pragma unroll
-        for (int q = 0; q < (TM * 16 + 63) / 64; ++q) {
-          const int r = lane + 64 * q;
-          if (TM * 16 % 64 == 0 || r < TM * 16) mean_prev[r] = p.epi.fold_stat[2 * (size_t)(m0 + wr * TM * 16 + r)];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
+      for (int q = 0; q < NQM; ++q) mprev[q] = p.epi.fold_stat[2 * (size_t)(m0 + wr * TM * 16 + min(lane + 64 * q, TM * 16 - 1))];
     }
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
     auto x_load = [&](int pp, int k) -> float4 {
       if constexpr (SPLIT) {
         const int m = m0 + (wr * TM + pp / H) * 16 + (lane >> 4) + 4 * k;
         const size_t e = (size_t)m * ldo + ncol0 + 64 * (pp % H) + l15 * 4;
-        const uint2 hi = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(p.epi.y16) + e);
-        const uint2 lo = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(p.epi.y16lo) + e);
+        const v2u_t hi = *reinterpret_cast<const v2u_t *>(reinterpret_cast<const unsigned short *>(p.epi.y16) + e);
+        const v2u_t lo = *reinterpret_cast<const v2u_t *>(reinterpret_cast<const unsigned short *>(p.epi.y16lo) + e);
         return make_float4(__uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(lo.x), __uint_as_float(lo.y));
       } else {
         return *reinterpret_cast<const float4 *>(x_ptr(pp, k));
       }
     };
+    // rows with m % skip_mod == 0 are left alone: ONE division per lane and tile, then a running remainder along the lane's rows
+    // (the per-row `m % skip_mod` was ~18 vector instructions x 32 rows per wave and tile)
+    [[maybe_unused]] unsigned skip_rem = 1, skip_step = 0, skip_m = 0;
+    if constexpr (MODE == VTC_EPI_RESID || MODE == EPI_RESID_LN) {
+      if (p.epi.skip_mod > 0) {
+        skip_m = (unsigned)p.epi.skip_mod;
+        skip_rem = (unsigned)(m0 + wr * TM * 16 + (lane >> 4)) % skip_m;
+        skip_step = 4u % skip_m;
+      }
+    }
+    [[maybe_unused]] bool live_k[4] = {true, true, true, true};
     if (MODE == VTC_EPI_RESID || MODE == EPI_RESID_LN) {
 #pragma unroll
       for (int a = 0; a < XD - 1; ++a)
@@ -465,6 +509,17 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     if (MODE == EPI_L2DIST) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) rn[i] = p.epi.rown[m0 + (wr * TM + i) * 16 + l15];
+    }
+    rejoin();
+    if constexpr (SPLIT && CENTER) {
+#pragma unroll
+      for (int q = 0; q < NQM; ++q) {
+        const int r = lane + 64 * q;
+        if (TM * 16 % 64 == 0 || r < TM * 16) mean_prev[r] = mprev[q];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
@@ -496,7 +551,14 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
           v.x = fin(v.x, cadd[hh][0]); v.y = fin(v.y, cadd[hh][1]); v.z = fin(v.z, cadd[hh][2]); v.w = fin(v.w, cadd[hh][3]);
           size_t orow = (size_t)m;
           bool live = true;
-          if ((MODE == VTC_EPI_RESID || MODE == EPI_RESID_LN) && p.epi.skip_mod > 0 && (m % p.epi.skip_mod) == 0) live = false;
+          if constexpr (MODE == VTC_EPI_RESID || MODE == EPI_RESID_LN) {
+            if (hh == 0) {                                       // row (i, k): next in this lane's walk
+              live_k[k] = skip_rem != 0;
+              skip_rem += skip_step;
+              skip_rem = min(skip_rem, skip_rem - skip_m);       // unsigned: the wrapped difference loses unless skip_rem >= skip_m
+            }
+            live = live_k[k];
+          }
           if (MODE == EPI_PATCH) {
             const int np = m % p.epi.P, ft = m / p.epi.P;
             const int tt = ft % p.epi.F, item = ft / p.epi.F;
@@ -535,30 +597,25 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
                                                      MODE == EPI_RESID_LN ? 16 : VTC_RESID_AUX);
             } else {
               // producer side of the folded LayerNorm: the updated row as (hi, lo) + this wave's partial statistics
-              const unsigned short q0 = cvt16<T>(y.x), q1 = cvt16<T>(y.y), q2 = cvt16<T>(y.z), q3 = cvt16<T>(y.w);
               uint2 pk, pl;
-              pk.x = (unsigned)q0 | ((unsigned)q1 << 16);
-              pk.y = (unsigned)q2 | ((unsigned)q3 << 16);
-              pl.x = (unsigned)cvt16<T>(y.x - up16<T>(q0)) | ((unsigned)cvt16<T>(y.y - up16<T>(q1)) << 16);
-              pl.y = (unsigned)cvt16<T>(y.z - up16<T>(q2)) | ((unsigned)cvt16<T>(y.w - up16<T>(q3)) << 16);
-              const size_t e = (size_t)m * ldo + ncolh + cc;
+              pk.x = pack16<T>(y.x, y.y);
+              pk.y = pack16<T>(y.z, y.w);
+              pl.x = pack16<T>(y.x - up16<T>((unsigned short)(pk.x & 0xFFFFu)), y.y - up16<T>((unsigned short)(pk.x >> 16)));
+              pl.y = pack16<T>(y.z - up16<T>((unsigned short)(pk.y & 0xFFFFu)), y.w - up16<T>((unsigned short)(pk.y >> 16)));
               // cache policy of the (hi, lo) stores: the wave's next x loads sit behind them in the in-order vmcnt queue, so how
-              // soon a store is ACKNOWLEDGED sets the pace of the pass loop (0 plain, 1 nt, 2 sc1 write-through; measured: DESIGN 4.1)
+              // soon a store is ACKNOWLEDGED sets the pace of the pass loop (0 plain, 1 nt; measured: DESIGN 4.1)
 #ifndef VTC_SPLIT_ST
 #define VTC_SPLIT_ST 0
 #endif
-              uint2 *ph = reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(p.epi.y16) + e);
-              uint2 *pq = reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(p.epi.y16lo) + e);
+              const size_t e = (size_t)m * ldo + ncolh + cc;
+              v2u_t *ph = reinterpret_cast<v2u_t *>(reinterpret_cast<unsigned short *>(p.epi.y16) + e);
+              v2u_t *pq = reinterpret_cast<v2u_t *>(reinterpret_cast<unsigned short *>(p.epi.y16lo) + e);
               if constexpr (VTC_SPLIT_ST == 1) {
-                typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
-                __builtin_nontemporal_store((v2u_t){pk.x, pk.y}, reinterpret_cast<v2u_t *>(ph));
-                __builtin_nontemporal_store((v2u_t){pl.x, pl.y}, reinterpret_cast<v2u_t *>(pq));
-              } else if constexpr (VTC_SPLIT_ST == 2) {
-                asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(ph), "v"(pk) : "memory");
-                asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(pq), "v"(pl) : "memory");
+                __builtin_nontemporal_store((v2u_t){pk.x, pk.y}, ph);
+                __builtin_nontemporal_store((v2u_t){pl.x, pl.y}, pq);
               } else {
-                *ph = pk;
-                *pq = pl;
+                *ph = (v2u_t){pk.x, pk.y};
+                *pq = (v2u_t){pl.x, pl.y};
               }
               // (sum, sum of squared deviations from the 64-column mean): merged exactly like a two-pass variance
               // (fold_stats_kernel).  Over the 16 lanes of the row: xor 1, 2 in the quad, then half-row and row mirrors.
@@ -598,6 +655,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
   } else {
     // Generic path: edge tiles (M or N not a multiple of the tile, odd leading dimension).
     // Fully unrolled: a runtime index into acc[][] would send the accumulators to scratch.
+    rejoin();
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = m0 + (wr * TM + i) * 16 + (lane & 15);
@@ -1182,10 +1240,10 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
       cur ^= 1;
     }
     VTC_STAMP(0);       // K loop (incl. the stagger barrier)
-    if (wr == 0) __builtin_amdgcn_s_barrier();   // re-join: waves 4-7 finish their last MFMA cluster
-    VTC_STAMP(1);       // re-join wait
+    VTC_STAMP(1);       // (the re-join wait is inside the epilogue now: waves 0-3 wait for waves 4-7's last MFMA cluster AFTER requesting the
+                        //  tile's bias / statistics / first residual rows)
 
-    tile_epilogue<T, MODE, OutT, WM, WN, TM, TN, STAGE / NW>(acc, p, m0, n0, (cur ^ 1) * STAGE);
+    tile_epilogue<T, MODE, OutT, WM, WN, TM, TN, STAGE / NW, true>(acc, p, m0, n0, (cur ^ 1) * STAGE);
     if constexpr (MODE == EPI_RESID_LN) {
       int *ticket = reinterpret_cast<int *>(lds + 2 * STAGE);       // one word behind the two stages (run_phased asks for it)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // EVERY storing wave drains its write-through stores ...

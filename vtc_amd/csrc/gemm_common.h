@@ -191,6 +191,14 @@ __device__ __forceinline__ float quick_gelu(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554670f * x));   // 1.702 * log2(e)
 }
 
+// two values at a time in the 16-bit modes: the scale, the 1 + e and the final product as packed fp32 operations (v_pk_mul_f32 /
+// v_pk_add_f32), exp2 and rcp per value -- the same operations and roundings as quick_gelu<false> on each
+typedef float gelu_f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gelu_f2_t quick_gelu2(gelu_f2_t x) {
+  const gelu_f2_t t = x * (gelu_f2_t){-2.4554670f, -2.4554670f};
+  const gelu_f2_t d = (gelu_f2_t){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + (gelu_f2_t){1.0f, 1.0f};
+  return x * (gelu_f2_t){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
 
 int num_cus();
 

@@ -251,7 +251,12 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
   }
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // The thread index is made opaque HERE, once per tile: everything the epilogue derives from it (row / column offsets, bias and
+  // statistics addresses) is then recomputed per tile instead of being hoisted out of the persistent tile loop, where it sat in
+  // registers across the K loop and was spilled (the reload at the top of the epilogue was one more dependent round trip per tile).
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int g = lane >> 4;
   const int ldo = p.ldo;

@@ -60,7 +60,7 @@ __device__ __forceinline__ void mma_qk(float, const uint4 &k, const uint4 &q, f3
 }
 
 template <typename T, int NT>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && NT <= 4) ? 4 : 1) void attn_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   constexpr int SZ = sizeof(T);
   constexpr int VS = 16 * NT + 4;           // Vt row stride in elements (keys), keeps 8/16-byte alignment

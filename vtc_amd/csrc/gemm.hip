@@ -469,6 +469,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     // TM * 16 means wait in its LDS scratch behind the transposition buffer.
     // (fold_stat == NULL: this update does not re-centre -- the towers do it once per layer, in c_proj's epilogue)
     [[maybe_unused]] float *mean_prev = tr + 16 * TS;
+    // ... and the partial statistics this epilogue produces (one (sum, squared deviations) pair per row of the wave's 64 columns) are
+    // collected behind them and leave in ONE full-width store after the last pass: written where they arise they were 32 stores of
+    // four lanes x 8 bytes per wave and tile inside the (hi, lo) store stream -- a third of its instructions, every one a partial line
+    [[maybe_unused]] float2 *stat_buf = reinterpret_cast<float2 *>(tr + 16 * TS + TM * 16);
     // (requested here, with the first residual rows below and before the re-join barrier; written to the scratch after it)
     constexpr int NQM = (TM * 16 + 63) / 64;
     [[maybe_unused]] float mprev[NQM];
@@ -630,8 +634,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
               const float d0 = y.x - mp, d1 = y.y - mp, d2 = y.z - mp, d3 = y.w - mp;
               float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
               q += dpp_f<0xB1>(q); q += dpp_f<0x4E>(q); q += dpp_f<0x141>(q); q += dpp_f<0x140>(q);
-              if (l15 == 0)
-                *reinterpret_cast<float2 *>(p.epi.fold_part + 2 * ((size_t)(ncolh >> 6) * p.M + m)) = make_float2(s1, q);
+              if (l15 == 0) {
+                if constexpr (H == 1) stat_buf[i * 16 + r] = make_float2(s1, q);
+                else *reinterpret_cast<float2 *>(p.epi.fold_part + 2 * ((size_t)(ncolh >> 6) * p.M + m)) = make_float2(s1, q);
+              }
             }
           } else {
             store16<nt_out>(o, v);
@@ -656,6 +662,14 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (SPLIT && H == 1) {
+      static_assert((16 * TS + TM * 16 + 2 * TM * 16) * 4 <= SCRATCH_PER_WAVE, "folded LayerNorm: partial statistics in the wave's scratch");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (2 * lane < TM * 16) {          // two rows per lane: the wave's TM * 16 rows of plane ncol0 / 64 are contiguous
+        const float4 v = *reinterpret_cast<const float4 *>(stat_buf + 2 * lane);
+        *reinterpret_cast<float4 *>(p.epi.fold_part + 2 * ((size_t)(ncol0 >> 6) * p.M + m0 + wr * TM * 16 + 2 * lane)) = v;
+      }
     }
   } else {
     // Generic path: edge tiles (M or N not a multiple of the tile, odd leading dimension).

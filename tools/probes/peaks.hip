@@ -76,6 +76,27 @@ __global__ __launch_bounds__(512) void mfma_bf16_var_kernel(const uint4 *__restr
   if (r == 12345.678f) sink[0] = r;
 }
 
+// calibration of s_memtime (the clock of the kernels' cycle stamps): ticks across a register-resident MFMA loop of known length
+__global__ __launch_bounds__(256) void mfma_ticks_kernel(const uint4 *__restrict__ seed, float *__restrict__ sink, unsigned long long *ticks, int iters) {
+  const uint4 s0 = seed[threadIdx.x & 63], s1 = seed[64 + (threadIdx.x & 63)];
+  const bf16x8 a = __builtin_bit_cast(bf16x8, s0), b = __builtin_bit_cast(bf16x8, s1);
+  f32x4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  unsigned long long t0, t1;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) : "v"(r) : "memory");
+  if (r == 12345.678f) sink[0] = r;
+  if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+}
+
 static float time_ms(hipEvent_t a, hipEvent_t b) { float ms; hipEventElapsedTime(&ms, a, b); return ms; }
 
 int main() {
@@ -131,6 +152,19 @@ int main() {
     t = time_ms(e0, e1) / 3 * 1e-3;
     flops = (double)cus * (threads / 64) * iters * 16 * (2.0 * 16 * 16 * 4);
     printf("MFMA f32  16x16x4,  %d wave(s)/SIMD, random operands: %.1f TFLOP/s\n", wps, flops / t / 1e12);
+  }
+  // ---- what does s_memtime count?  ticks over a loop of 16 x iters MFMAs per wave (one wave per SIMD) against its wall time
+  {
+    unsigned long long *ticks; hipMalloc(&ticks, 8);
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(mfma_ticks_kernel, dim3(cus), dim3(256), 0, 0, (const uint4 *)seed, sink, ticks, iters);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      unsigned long long h; hipMemcpy(&h, ticks, 8, hipMemcpyDeviceToHost);
+      const double t = time_ms(e0, e1) * 1e-3, n = 16.0 * iters;
+      printf("s_memtime: %.1f ticks per 16x16x32 bf16 MFMA (one wave per SIMD), %.0f MHz tick rate by wall time, %.1f ns per MFMA\n", (double)h / n,
+             (double)h / t / 1e6, t / n * 1e9);
+    }
   }
   // ---- sustained: ~1.5 s of back-to-back bf16 MFMA launches (two waves per SIMD, sixteen operand pairs), one reading per ~100 ms
   //      window, and the clock / socket power rocm-smi reports half a second in (the 2.4 ms bursts above run before DVFS reacts)

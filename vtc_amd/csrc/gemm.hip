@@ -1244,6 +1244,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
           __builtin_amdgcn_s_barrier();
           lgkm_wait_subtile(aS, wD[0]);
           if constexpr (DEEP == 2) lgkm_wait_w4(wD[1]);
+          VTC_PHASE_STAMP(1);
           // (d) the MFMA cluster
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1253,6 +1254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
 #pragma unroll
               for (int j = 0; j < 2; ++j) Mma<T>::run(wD[wreg][j][ks], aS[i][ks], acc[qm * 4 + i][qn * 2 + j]);
           __builtin_amdgcn_s_setprio(0);
+          VTC_PHASE_STAMP(0);
           __builtin_amdgcn_s_barrier();
         });
       }

@@ -58,7 +58,7 @@ struct GemmParams {
   int col_group;   // phased kernel: column tiles per group of the tile walk (0 = all NT columns in one group)
   int super_tiles; // phased kernel: row tiles per super-row of the tile walk (0 = SUPER_ROWS / 256)
   int stagger_groups, stagger_ticks;   // phased kernel: workgroup (slot % groups) starts (slot % groups) * ticks x 10 ns late
-#ifdef VTC_GEMM_STAMPS
+#if defined(VTC_GEMM_STAMPS) || defined(VTC_GEMM_PHASE_STAMPS)
   unsigned long long *dbg;   // diagnostic build: per-wave phase cycle sums
 #endif
   GemmEpi epi;

@@ -951,7 +951,7 @@ __device__ __attribute__((noinline)) void fused_ln_rows(const float *out, int M,
 template <int MODE, typename OutT, typename T, int DEEP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands (bf16 or IEEE half)");
-  static_assert(DEEP >= 0 && DEEP <= 2, "0 = one quarter in flight, 1 = deep (W0 re-read), 2 = deep (W0 kept in registers)");
+  static_assert(DEEP >= 0 && DEEP <= 3, "0 = one quarter in flight, 1 = deep (W0 re-read), 2 = deep (W0 kept in registers), 3 = two 32-MFMA phases per K-tile");
   constexpr int WM = 2, WN = 4, TM = 8, TN = 4, NW = 8, BM = 256, BN = 256;
   if (p.epi.m_dev) {        // the row count lives in device memory (GemmEpi::m_dev): the grid was sized for the host's upper bound
     p.M = *p.epi.m_dev;
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   }
 
   u32x4 aS[4][2], wS[2][2];     // register subtile: 4 activation x 2 weight fragments x 2 K halves
-  [[maybe_unused]] u32x4 wD[DEEP == 2 ? 2 : 1][2][2];   // the deep variants' weight fragments (DEEP 2: W0 and W1 apart)
+  [[maybe_unused]] u32x4 wD[DEEP >= 2 ? 2 : 1][2][2];   // the deep variants' weight fragments (DEEP 2: W0 and W1 apart)
   bool relax_first = false;     // the previous tile's epilogue issued exactly NST stores last (see the phase-end wait)
   VTC_STAMP_INIT();
   while (true) {
@@ -1181,6 +1181,66 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");
           } else
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        });
+      } else if constexpr (DEEP == 3) {
+        // ---- TWO phases per K-tile, 32 MFMAs each: half as many hand-overs between the two halves of the workgroup (the phase stamps
+        // put 90-110 cycles on each: profiles/r04_mfma_busy.md).  Phase 0 reads A0, W0, W1 (16 fragment reads) and multiplies the upper
+        // two quadrants; phase 1 reads A1 (8) and multiplies the lower two with the weight fragments still in registers.  Plain double
+        // buffering: K-tile t+1 streams into the other stage while K-tile t is read -- A0, W0, W1 issued in phase 0 (their previous
+        // contents were last read in phase 0 of K-tile t-1: two barriers ago for either half), A1 in phase 1; each waited for one phase
+        // before it is read, before that phase's first barrier (vmcnt(6) in phase 0: A1; vmcnt(2) in phase 1: A0, W0, W1).  The stage
+        // the epilogue transposes through is the one just read: tile boundaries need no special case beyond the relaxed first wait.
+        constexpr int NST = TM * (sizeof(OutT) == 2 ? 2 : 4);
+        const bool first = t == 0;
+        const bool nx1 = t + 1 == ksteps && has_next;
+        const int sm1 = nx1 ? m0n : m0, sn1 = nx1 ? n0n : n0, kk1 = t + 1 < ksteps ? t + 1 : 0;
+        const bool fA1 = sm1 + BM <= p.M, fW1 = sn1 + BN <= p.N;
+        if constexpr (CAN_GATHER) {
+          if (gather && nx1) gather_offsets(m0n);       // every activation quarter from here on is the next tile's
+        }
+        static_for<2>([&](auto ph_c) __attribute__((always_inline)) {
+          constexpr int ph = decltype(ph_c)::value;
+          if constexpr (ph == 0) {
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                lds_read16(wD[qn][j][0], st_cur + w_rd + coff0, (qn * 2 + j) * 16 * ROWB);
+                lds_read16(wD[qn][j][1], st_cur + w_rd + coff1, (qn * 2 + j) * 16 * ROWB);
+              }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            lds_read16(aS[i][0], st_cur + a_rd + coff0, (ph * 4 + i) * 16 * ROWB);
+            lds_read16(aS[i][1], st_cur + a_rd + coff1, (ph * 4 + i) * 16 * ROWB);
+          }
+          if constexpr (ph == 0) {
+            stage_quarter(0, sm1, sn1, kk1, st_nxt, fA1, fW1);
+            stage_quarter(1, sm1, sn1, kk1, st_nxt, fA1, fW1);
+            stage_quarter(2, sm1, sn1, kk1, st_nxt, fA1, fW1);
+            // A1 of THIS K-tile has landed (first K-tile after an interior epilogue: its NST stores sit between A1 and these)
+            if (first && relax_first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          } else {
+            stage_quarter(3, sm1, sn1, kk1, st_nxt, fA1, fW1);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // A0, W0, W1 of K-tile t+1 have landed
+          }
+          __builtin_amdgcn_s_barrier();
+          lgkm_wait_subtile(aS, wD[0]);
+          lgkm_wait_w4(wD[1]);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            const int qn = ph == 0 ? qq : 1 - qq;         // quadrant walk (0,0) (0,1) (1,1) (1,0)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma<T>::run(wD[qn][j][ks], aS[i][ks], acc[ph * 4 + i][qn * 2 + j]);
+          }
+          __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_s_barrier();
         });
       } else {
@@ -1341,6 +1401,9 @@ int run_phased(const GemmParams &p, hipStream_t stream) {
   if constexpr (MODE != EPI_RESID_LN && MODE != EPI_L2MIN) {
     if (p.K >= 128) {
       if (g_deep == 1) return run_phased_d<MODE, OutT, T, 1>(p, stream);
+#ifdef VTC_GEMM_DEEP3
+      if (g_deep == 3) return run_phased_d<MODE, OutT, T, 3>(p, stream);
+#endif
 #ifdef VTC_GEMM_DEEP2
       if (g_deep == 2) return run_phased_d<MODE, OutT, T, 2>(p, stream);
 #endif

@@ -1014,21 +1014,32 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   // per-lane source offset of a piece whose group index is even; the odd one (second piece) uses ^ 64
   const unsigned a_vo = (unsigned)(lane >> 3) * (unsigned)p.lda_bytes + (((lane & 7) ^ (lane >> 4)) << 4);
   const unsigned w_vo = (unsigned)(lane >> 3) * (unsigned)p.ldw_bytes + (((lane & 7) ^ (lane >> 4)) << 4);
+  // second piece of a quarter: eight rows further in the source, 1 KiB further in LDS (the instruction offset moves both)
+  const unsigned a_vo2 = (a_vo ^ 64u) + 8u * (unsigned)p.lda_bytes - 1024u, w_vo2 = (w_vo ^ 64u) + 8u * (unsigned)p.ldw_bytes - 1024u;
+  // byte offsets of this wave's row groups inside a tile's rows: A0, A1 / W0, W1
+  const unsigned offA0 = (unsigned)ga0 * 8u * (unsigned)p.lda_bytes, offA1 = (unsigned)(ga0 + 8) * 8u * (unsigned)p.lda_bytes;
+  const unsigned offW0 = (unsigned)gw0 * 8u * (unsigned)p.ldw_bytes, offW1 = (unsigned)(gw0 + 4) * 8u * (unsigned)p.ldw_bytes;
+  // first row of the current and of the next tile's operands
+  const char *tbA = p.A + (size_t)m0 * p.lda_bytes, *tbW = p.W + (size_t)n0 * p.ldw_bytes;
+  const char *tbAn = p.A + (size_t)m0n * p.lda_bytes, *tbWn = p.W + (size_t)n0n * p.ldw_bytes;
   // Two pieces: 16 rows x 128 B of operand `base` starting at tile row (row0 + 8 grp), K byte kb, into
   // lds_dst .. +2 KiB.  Interior tiles: wave-uniform 64-bit base + 32-bit lane offset, one M0 write (the
   // instruction offset moves both the source and the LDS destination; the second base is pre-decremented).
-  auto stage2 = [&](const char *base, int row0, int nrows, int ld_bytes, unsigned vo, int grp, int kb, unsigned lds_dst,
-                    bool fast) __attribute__((always_inline)) {
+  // (Scalar work per call matters: the K loop loses ~0.1 % per scalar instruction added to a phase's memory part -- profiles/
+  //  r04_experiments.txt 15.  Hence: the tile's row base `tile_base` is worked out once per tile (one 64-bit multiply), the wave's
+  //  row-group offset `grp_off` once per kernel, and the second piece shares the first piece's scalar base -- its "+ 8 rows - 1024"
+  //  sits in the lane offset `vo2`.)
+  auto stage2 = [&](const char *base, const char *tile_base, unsigned grp_off, int row0, int nrows, int ld_bytes, unsigned vo, unsigned vo2, int grp,
+                    int kb, unsigned lds_dst, bool fast) __attribute__((always_inline)) {
     if (fast) {
-      const char *sb0 = base + (size_t)(row0 + grp * 8) * ld_bytes + kb;
-      const char *sb1 = sb0 + (ptrdiff_t)8 * ld_bytes - 1024;
+      const char *sb0 = tile_base + (grp_off + (unsigned)kb);
       asm volatile(
-          "s_mov_b32 m0, %4\n\t"
+          "s_mov_b32 m0, %3\n\t"
           "s_nop 0\n\t"
           "global_load_lds_dwordx4 %0, %2\n\t"
-          "global_load_lds_dwordx4 %1, %3 offset:1024"
+          "global_load_lds_dwordx4 %1, %2 offset:1024"
           :
-          : "v"(vo), "v"(vo ^ 64u), "s"(sb0), "s"(sb1), "s"(lds_dst)
+          : "v"(vo), "v"(vo2), "s"(sb0), "s"(lds_dst)
           : "memory");
     } else {
 #pragma unroll
@@ -1071,7 +1082,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
     return ((size_t)c * p.epi.res + i) * p.epi.res * 2;
   };
   // quarter qi (0 = A0, 1 = W0, 2 = W1, 3 = A1) of K-tile kk of the tile at (sm, sn) into stage st
-  auto stage_quarter = [&](int qi, int sm, int sn, int kk, unsigned st, bool fastA, bool fastW) __attribute__((always_inline)) {
+  auto stage_quarter = [&](int qi, int sm, int sn, int kk, unsigned st, bool fastA, bool fastW, const char *ta, const char *tw) __attribute__((always_inline)) {
     if (qi == 0 || qi == 3) {
       const int grp = ga0 + (qi == 3 ? 8 : 0);
       if constexpr (CAN_GATHER) {
@@ -1090,10 +1101,10 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
           return;
         }
       }
-      stage2(p.A, sm, p.M, p.lda_bytes, a_vo, grp, kk * ROWB, st + grp * 1024, fastA);
+      stage2(p.A, ta, qi == 3 ? offA1 : offA0, sm, p.M, p.lda_bytes, a_vo, a_vo2, grp, kk * ROWB, st + grp * 1024, fastA);
     } else {
       const int grp = gw0 + (qi == 2 ? 4 : 0);
-      stage2(p.W, sn, p.N, p.ldw_bytes, w_vo, grp, kk * ROWB, st + A_BYTES + grp * 1024, fastW);
+      stage2(p.W, tw, qi == 2 ? offW1 : offW0, sn, p.N, p.ldw_bytes, w_vo, w_vo2, grp, kk * ROWB, st + A_BYTES + grp * 1024, fastW);
     }
   };
 
@@ -1102,7 +1113,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
     const bool fa = m0 + BM <= p.M, fw = n0 + BN <= p.N;
     if (gather) gather_offsets(m0);
 #pragma unroll
-    for (int qi = 0; qi < 4; ++qi) stage_quarter(qi, m0, n0, 0, lds_base, fa, fw);
+    for (int qi = 0; qi < 4; ++qi) stage_quarter(qi, m0, n0, 0, lds_base, fa, fw, tbA, tbW);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -1131,6 +1142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
         const bool to_next = kn == ksteps && has_next;
         const int sm = to_next ? m0n : m0, sn = to_next ? n0n : n0, kk = kn < ksteps ? kn : 0;
         const bool fastA = sm + BM <= p.M, fastW = sn + BN <= p.N;
+        const char *ta = to_next ? tbAn : tbA, *tw = to_next ? tbWn : tbW;
         if constexpr (CAN_GATHER) {
           if (gather && to_next) gather_offsets(m0n);     // from here on the next tile's K-tile 0 streams in
         }
@@ -1153,7 +1165,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
             }
           }
           // (b) one quarter of the next K-tile
-          stage_quarter(ph, sm, sn, kk, st_nxt, fastA, fastW);
+          stage_quarter(ph, sm, sn, kk, st_nxt, fastA, fastW, ta, tw);
           // (c) everybody has issued; the reads land while we wait here
           __builtin_amdgcn_s_barrier();
           lgkm_wait_subtile(aS, wS);
@@ -1196,6 +1208,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
         const bool nx1 = t + 1 == ksteps && has_next;
         const int sm1 = nx1 ? m0n : m0, sn1 = nx1 ? n0n : n0, kk1 = t + 1 < ksteps ? t + 1 : 0;
         const bool fA1 = sm1 + BM <= p.M, fW1 = sn1 + BN <= p.N;
+        const char *ta1 = nx1 ? tbAn : tbA, *tw1 = nx1 ? tbWn : tbW;
         if constexpr (CAN_GATHER) {
           if (gather && nx1) gather_offsets(m0n);       // every activation quarter from here on is the next tile's
         }
@@ -1216,14 +1229,14 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
             lds_read16(aS[i][1], st_cur + a_rd + coff1, (ph * 4 + i) * 16 * ROWB);
           }
           if constexpr (ph == 0) {
-            stage_quarter(0, sm1, sn1, kk1, st_nxt, fA1, fW1);
-            stage_quarter(1, sm1, sn1, kk1, st_nxt, fA1, fW1);
-            stage_quarter(2, sm1, sn1, kk1, st_nxt, fA1, fW1);
+            stage_quarter(0, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
+            stage_quarter(1, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
+            stage_quarter(2, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
             // A1 of THIS K-tile has landed (first K-tile after an interior epilogue: its NST stores sit between A1 and these)
             if (first && relax_first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NST) : "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
           } else {
-            stage_quarter(3, sm1, sn1, kk1, st_nxt, fA1, fW1);
+            stage_quarter(3, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // A0, W0, W1 of K-tile t+1 have landed
           }
           __builtin_amdgcn_s_barrier();
@@ -1253,10 +1266,12 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
         const bool nx1 = t + 1 == ksteps && has_next;
         const int sm1 = nx1 ? m0n : m0, sn1 = nx1 ? n0n : n0, kk1 = t + 1 < ksteps ? t + 1 : 0;
         const bool fA1 = sm1 + BM <= p.M, fW1 = sn1 + BN <= p.N;
+        const char *ta1 = nx1 ? tbAn : tbA, *tw1 = nx1 ? tbWn : tbW;
         // K-tile t+2 (-> st_cur, behind this K-tile's reads); t = ksteps - 2: K-tile 0 of the next tile; t = ksteps - 1: nothing
         const bool nx2 = t + 2 >= ksteps && has_next;
         const int sm2 = nx2 ? m0n : m0, sn2 = nx2 ? n0n : n0, kk2 = t + 2 < ksteps ? t + 2 : 0;
         const bool fA2 = sm2 + BM <= p.M, fW2 = sn2 + BN <= p.N;
+        const char *ta2 = nx2 ? tbAn : tbA, *tw2 = nx2 ? tbWn : tbW;
         static_for<4>([&](auto ph_c) __attribute__((always_inline)) {
           constexpr int ph = decltype(ph_c)::value;
           constexpr int qm = ph >> 1, qn = (ph == 1 || ph == 2) ? 1 : 0;
@@ -1278,11 +1293,11 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
           }
           // (b) this phase's quarter(s); (c) the counted waits, BEFORE the phase's first barrier (their data is read in a later phase)
           if constexpr (ph == 0) {
-            stage_quarter(QA, sm1, sn1, kk1, st_nxt, fA1, fW1);
-            if (first) stage_quarter(0, sm1, sn1, kk1, st_nxt, fA1, fW1);        // A0 of K-tile 1: the previous tile's ph2 did not issue it
+            stage_quarter(QA, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
+            if (first) stage_quarter(0, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);        // A0 of K-tile 1: the previous tile's ph2 did not issue it
           } else if constexpr (ph == 1) {
-            if (first) stage_quarter(QB, sm1, sn1, kk1, st_nxt, fA1, fW1);       // ... nor QB in its ph3 (QB before A1: ph3's count)
-            stage_quarter(3, sm1, sn1, kk1, st_nxt, fA1, fW1);
+            if (first) stage_quarter(QB, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);       // ... nor QB in its ph3 (QB before A1: ph3's count)
+            stage_quarter(3, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
             // A1 of THIS K-tile (issued four quarters ago) has landed.  First K-tile after an interior epilogue: its NST stores sit
             // between A1 and this K-tile's quarters in the in-order queue, and nothing younger than them is needed yet.
             if (first && relax_first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST) : "memory");
@@ -1292,10 +1307,10 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
               if constexpr (CAN_GATHER) {
                 if (gather && nx2 && t + 2 == ksteps) gather_offsets(m0n);       // every activation quarter from here on is the next tile's
               }
-              stage_quarter(0, sm2, sn2, kk2, st_cur, fA2, fW2);
+              stage_quarter(0, sm2, sn2, kk2, st_cur, fA2, fW2, ta2, tw2);
             }
           } else {
-            if (!last) stage_quarter(QB, sm2, sn2, kk2, st_cur, fA2, fW2);
+            if (!last) stage_quarter(QB, sm2, sn2, kk2, st_cur, fA2, fW2, ta2, tw2);
             if constexpr (DEEP == 1) lgkm_wait_w4(wD[0]);                         // W0's second read retired before the barrier: re-filled next phase
             // A0, QA, QB of K-tile t+1 have landed (A1 and this K-tile's two quarters stay in flight)
             if (last) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -1340,8 +1355,12 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();          // the transposition area is the next K-tile's DMA target
     VTC_STAMP(3);       // post-epilogue barrier
     li += nb_x; m0 = m0n; n0 = n0n;
+    tbA = tbAn; tbW = tbWn;
     has_next = li + nb_x < nt_x;
-    if (has_next) decode(start_x + li + nb_x, m0n, n0n);
+    if (has_next) {
+      decode(start_x + li + nb_x, m0n, n0n);
+      tbAn = p.A + (size_t)m0n * p.lda_bytes; tbWn = p.W + (size_t)n0n * p.ldw_bytes;
+    }
   }
 }
 

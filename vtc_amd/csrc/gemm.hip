@@ -1006,6 +1006,11 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   const unsigned a_rd = (wr * 128 + (lane & 15)) * ROWB;
   const unsigned w_rd = A_BYTES + (wc * 64 + (lane & 15)) * ROWB;
   const unsigned coff0 = ((0 + g) ^ swz) << 4, coff1 = ((4 + g) ^ swz) << 4;
+  // The four fragment read addresses of the stage being read live in registers of their own and move to the other stage once per
+  // K-tile (four vector adds): formed per use from (stage, a_rd, coff) they were ~10 vector adds per K-tile in the memory parts of the
+  // phases, where every vector instruction delays the partner wave's MFMA issue (profiles/r04_experiments.txt 15).
+  unsigned ra0 = lds_base + a_rd + coff0, ra1 = lds_base + a_rd + coff1, rw0 = lds_base + w_rd + coff0, rw1 = lds_base + w_rd + coff1;
+  int rd_step = STAGE;     // to the other stage and back
 
   // ---- LDS-DMA quarters ----
   // first 8-row group of this wave's two (consecutive) pieces of quarter A0 / W0; A1 = +8 groups, W1 = +4
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   //  sits in the lane offset `vo2`.)
   auto stage2 = [&](const char *base, const char *tile_base, unsigned grp_off, int row0, int nrows, int ld_bytes, unsigned vo, unsigned vo2, int grp,
                     int kb, unsigned lds_dst, bool fast) __attribute__((always_inline)) {
-    if (fast) {
+    if (__builtin_expect(fast, 1)) {
       const char *sb0 = tile_base + (grp_off + (unsigned)kb);
       asm volatile(
           "s_mov_b32 m0, %3\n\t"
@@ -1153,15 +1158,15 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
           if constexpr (ph != 2) {
   #pragma unroll
             for (int j = 0; j < 2; ++j) {
-              lds_read16(wS[j][0], st_cur + w_rd + coff0, (qn * 2 + j) * 16 * ROWB);
-              lds_read16(wS[j][1], st_cur + w_rd + coff1, (qn * 2 + j) * 16 * ROWB);
+              lds_read16(wS[j][0], rw0, (qn * 2 + j) * 16 * ROWB);
+              lds_read16(wS[j][1], rw1, (qn * 2 + j) * 16 * ROWB);
             }
           }
           if constexpr (ph == 0 || ph == 2) {
   #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              lds_read16(aS[i][0], st_cur + a_rd + coff0, (qm * 4 + i) * 16 * ROWB);
-              lds_read16(aS[i][1], st_cur + a_rd + coff1, (qm * 4 + i) * 16 * ROWB);
+              lds_read16(aS[i][0], ra0, (qm * 4 + i) * 16 * ROWB);
+              lds_read16(aS[i][1], ra1, (qm * 4 + i) * 16 * ROWB);
             }
           }
           // (b) one quarter of the next K-tile
@@ -1219,14 +1224,14 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
             for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
               for (int j = 0; j < 2; ++j) {
-                lds_read16(wD[qn][j][0], st_cur + w_rd + coff0, (qn * 2 + j) * 16 * ROWB);
-                lds_read16(wD[qn][j][1], st_cur + w_rd + coff1, (qn * 2 + j) * 16 * ROWB);
+                lds_read16(wD[qn][j][0], rw0, (qn * 2 + j) * 16 * ROWB);
+                lds_read16(wD[qn][j][1], rw1, (qn * 2 + j) * 16 * ROWB);
               }
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            lds_read16(aS[i][0], st_cur + a_rd + coff0, (ph * 4 + i) * 16 * ROWB);
-            lds_read16(aS[i][1], st_cur + a_rd + coff1, (ph * 4 + i) * 16 * ROWB);
+            lds_read16(aS[i][0], ra0, (ph * 4 + i) * 16 * ROWB);
+            lds_read16(aS[i][1], ra1, (ph * 4 + i) * 16 * ROWB);
           }
           if constexpr (ph == 0) {
             stage_quarter(0, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
@@ -1280,15 +1285,15 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
           if constexpr (ph == 0 || ph == 1 || (ph == 3 && DEEP == 1)) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-              lds_read16(wD[wreg][j][0], st_cur + w_rd + coff0, (qn * 2 + j) * 16 * ROWB);
-              lds_read16(wD[wreg][j][1], st_cur + w_rd + coff1, (qn * 2 + j) * 16 * ROWB);
+              lds_read16(wD[wreg][j][0], rw0, (qn * 2 + j) * 16 * ROWB);
+              lds_read16(wD[wreg][j][1], rw1, (qn * 2 + j) * 16 * ROWB);
             }
           }
           if constexpr (ph == 0 || ph == 2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              lds_read16(aS[i][0], st_cur + a_rd + coff0, (qm * 4 + i) * 16 * ROWB);
-              lds_read16(aS[i][1], st_cur + a_rd + coff1, (qm * 4 + i) * 16 * ROWB);
+              lds_read16(aS[i][0], ra0, (qm * 4 + i) * 16 * ROWB);
+              lds_read16(aS[i][1], ra1, (qm * 4 + i) * 16 * ROWB);
             }
           }
           // (b) this phase's quarter(s); (c) the counted waits, BEFORE the phase's first barrier (their data is read in a later phase)
@@ -1334,6 +1339,8 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
         });
       }
       cur ^= 1;
+      ra0 += rd_step; ra1 += rd_step; rw0 += rd_step; rw1 += rd_step;
+      rd_step = -rd_step;
     }
     VTC_STAMP(0);       // K loop (incl. the stagger barrier)
     VTC_STAMP(1);       // (the re-join wait is inside the epilogue now: waves 0-3 wait for waves 4-7's last MFMA cluster AFTER requesting the

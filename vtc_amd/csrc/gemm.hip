@@ -1138,6 +1138,11 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // The K loop exists twice: ALL_FAST = every quarter it stages (this tile's and, at its end, the next tile's first K-tile) lies
+    // inside the operands, so the per-quarter "interior?" test, its two branches (one of them taken) and the clamped slow path are not
+    // in the instruction stream at all -- every tile of the towers; the other copy keeps them for edge tiles.
+    auto kloop = [&](auto all_fast_c) __attribute__((always_inline)) {
+    constexpr bool ALL_FAST = decltype(all_fast_c)::value;
     for (int t = 0; t < ksteps; ++t) {
       const unsigned st_cur = lds_base + cur * STAGE, st_nxt = lds_base + (cur ^ 1) * STAGE;
       if constexpr (DEEP == 0) {
@@ -1146,7 +1151,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
         const int kn = t + 1;
         const bool to_next = kn == ksteps && has_next;
         const int sm = to_next ? m0n : m0, sn = to_next ? n0n : n0, kk = kn < ksteps ? kn : 0;
-        const bool fastA = sm + BM <= p.M, fastW = sn + BN <= p.N;
+        const bool fastA = ALL_FAST || sm + BM <= p.M, fastW = ALL_FAST || sn + BN <= p.N;
         const char *ta = to_next ? tbAn : tbA, *tw = to_next ? tbWn : tbW;
         if constexpr (CAN_GATHER) {
           if (gather && to_next) gather_offsets(m0n);     // from here on the next tile's K-tile 0 streams in
@@ -1212,7 +1217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
         const bool first = t == 0;
         const bool nx1 = t + 1 == ksteps && has_next;
         const int sm1 = nx1 ? m0n : m0, sn1 = nx1 ? n0n : n0, kk1 = t + 1 < ksteps ? t + 1 : 0;
-        const bool fA1 = sm1 + BM <= p.M, fW1 = sn1 + BN <= p.N;
+        const bool fA1 = ALL_FAST || sm1 + BM <= p.M, fW1 = ALL_FAST || sn1 + BN <= p.N;
         const char *ta1 = nx1 ? tbAn : tbA, *tw1 = nx1 ? tbWn : tbW;
         if constexpr (CAN_GATHER) {
           if (gather && nx1) gather_offsets(m0n);       // every activation quarter from here on is the next tile's
@@ -1270,12 +1275,12 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
         // nobody reads any more -- the counted waits stay uniform)
         const bool nx1 = t + 1 == ksteps && has_next;
         const int sm1 = nx1 ? m0n : m0, sn1 = nx1 ? n0n : n0, kk1 = t + 1 < ksteps ? t + 1 : 0;
-        const bool fA1 = sm1 + BM <= p.M, fW1 = sn1 + BN <= p.N;
+        const bool fA1 = ALL_FAST || sm1 + BM <= p.M, fW1 = ALL_FAST || sn1 + BN <= p.N;
         const char *ta1 = nx1 ? tbAn : tbA, *tw1 = nx1 ? tbWn : tbW;
         // K-tile t+2 (-> st_cur, behind this K-tile's reads); t = ksteps - 2: K-tile 0 of the next tile; t = ksteps - 1: nothing
         const bool nx2 = t + 2 >= ksteps && has_next;
         const int sm2 = nx2 ? m0n : m0, sn2 = nx2 ? n0n : n0, kk2 = t + 2 < ksteps ? t + 2 : 0;
-        const bool fA2 = sm2 + BM <= p.M, fW2 = sn2 + BN <= p.N;
+        const bool fA2 = ALL_FAST || sm2 + BM <= p.M, fW2 = ALL_FAST || sn2 + BN <= p.N;
         const char *ta2 = nx2 ? tbAn : tbA, *tw2 = nx2 ? tbWn : tbW;
         static_for<4>([&](auto ph_c) __attribute__((always_inline)) {
           constexpr int ph = decltype(ph_c)::value;
@@ -1341,6 +1346,14 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
       cur ^= 1;
       ra0 += rd_step; ra1 += rd_step; rw0 += rd_step; rw1 += rd_step;
       rd_step = -rd_step;
+    }
+    };
+    if constexpr (MODE != EPI_L2MIN && MODE != EPI_PATCH && MODE != EPI_RESID_LN) {   // (those three keep one copy: register budgets)
+      const bool this_in = m0 + BM <= p.M && n0 + BN <= p.N, next_in = !has_next || (m0n + BM <= p.M && n0n + BN <= p.N);
+      if (this_in && next_in) kloop(std::true_type{});
+      else kloop(std::false_type{});
+    } else {
+      kloop(std::false_type{});
     }
     VTC_STAMP(0);       // K loop (incl. the stagger barrier)
     VTC_STAMP(1);       // (the re-join wait is inside the epilogue now: waves 0-3 wait for waves 4-7's last MFMA cluster AFTER requesting the

@@ -951,7 +951,7 @@ __device__ __attribute__((noinline)) void fused_ln_rows(const float *out, int M,
 template <int MODE, typename OutT, typename T, int DEEP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands (bf16 or IEEE half)");
-  static_assert(DEEP >= 0 && DEEP <= 3, "0 = one quarter in flight, 1 = deep (W0 re-read), 2 = deep (W0 kept in registers), 3 = two 32-MFMA phases per K-tile");
+  static_assert(DEEP >= 0 && DEEP <= 4, "0 = one quarter in flight, 1 = deep (W0 re-read), 2 = deep (W0 kept in registers), 3 = two 32-MFMA phases per K-tile, 4 = deep, every quarter re-filled two phases after its last read");
   constexpr int WM = 2, WN = 4, TM = 8, TN = 4, NW = 8, BM = 256, BN = 256;
   if (p.epi.m_dev) {        // the row count lives in device memory (GemmEpi::m_dev): the grid was sized for the host's upper bound
     p.M = *p.epi.m_dev;
@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   }
 
   u32x4 aS[4][2], wS[2][2];     // register subtile: 4 activation x 2 weight fragments x 2 K halves
-  [[maybe_unused]] u32x4 wD[DEEP >= 2 ? 2 : 1][2][2];   // the deep variants' weight fragments (DEEP 2: W0 and W1 apart)
+  [[maybe_unused]] u32x4 wD[(DEEP == 2 || DEEP == 3) ? 2 : 1][2][2];   // the deep variants' weight fragments (DEEP 2: W0 and W1 apart)
   bool relax_first = false;     // the previous tile's epilogue issued exactly NST stores last (see the phase-end wait)
   VTC_STAMP_INIT();
   while (true) {
@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
           constexpr int qm = ph >> 1, qn = (ph == 1 || ph == 2) ? 1 : 0;
           constexpr int wreg = DEEP == 2 ? qn : 0;                        // DEEP 2: W0 and W1 live in registers of their own
           // (a) this quadrant's new fragments
-          if constexpr (ph == 0 || ph == 1 || (ph == 3 && DEEP == 1)) {
+          if constexpr (ph == 0 || ph == 1 || (ph == 3 && (DEEP == 1 || DEEP == 4))) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               lds_read16(wD[wreg][j][0], rw0, (qn * 2 + j) * 16 * ROWB);
@@ -1302,7 +1302,22 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
             }
           }
           // (b) this phase's quarter(s); (c) the counted waits, BEFORE the phase's first barrier (their data is read in a later phase)
-          if constexpr (ph == 0) {
+          if constexpr (ph == 0 && DEEP == 4) {
+            // DEEP 4: the re-fill order follows the order of the last reads (A0 in ph0, W1 in ph1, A1 in ph2, W0 in ph3), each quarter
+            // two phases behind its last read: A0(t+2) in ph2, W1(t+2) in ph3, A1(t+1) in ph0, W0(t+1) in ph1 -- no quarter needs
+            // the early lgkmcnt of DEEP 1's ph3 (a fragment-read round trip inside a memory part), and ONE counted wait per K-tile
+            // (ph3: vmcnt(4) leaves A0, W1 of K-tile t+2 in flight; W0 of K-tile t+1 gets two phases, everything else more).
+            if (first) stage_quarter(0, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);        // A0 of K-tile 1: the previous tile's ph2 did not issue it
+            stage_quarter(3, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
+          } else if constexpr (ph == 1 && DEEP == 4) {
+            if (first) stage_quarter(2, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);        // ... nor W1 in its ph3
+            stage_quarter(1, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
+          } else if constexpr (ph == 3 && DEEP == 4) {
+            if (!last) stage_quarter(2, sm2, sn2, kk2, st_cur, fA2, fW2, ta2, tw2);
+            // A0, W0 (and W1, A1) of K-tile t+1 have landed; last K-tile of a tile: nothing was issued in ph2 / ph3
+            if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          } else if constexpr (ph == 0) {
             stage_quarter(QA, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
             if (first) stage_quarter(0, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);        // A0 of K-tile 1: the previous tile's ph2 did not issue it
           } else if constexpr (ph == 1) {
@@ -1440,6 +1455,9 @@ int run_phased(const GemmParams &p, hipStream_t stream) {
   if constexpr (MODE != EPI_RESID_LN && MODE != EPI_L2MIN) {
     if (p.K >= 128) {
       if (g_deep == 1) return run_phased_d<MODE, OutT, T, 1>(p, stream);
+#ifdef VTC_GEMM_DEEP4
+      if (g_deep == 4) return run_phased_d<MODE, OutT, T, 4>(p, stream);
+#endif
 #ifdef VTC_GEMM_DEEP3
       if (g_deep == 3) return run_phased_d<MODE, OutT, T, 3>(p, stream);
 #endif

@@ -36,6 +36,12 @@ def init_from_env(backend: Optional[str] = None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal knobs: several ranks on ONE card (VTC_LOCAL_DEVICE=0) over gloo (VTC_DIST_BACKEND=gloo)
+    if "VTC_LOCAL_DEVICE" in os.environ and world > 1:
+        # Ranks that SHARE a card: the one-launch CAM's grid barrier needs its whole grid resident at once, which the occupancy check
+        # of an ordinary launch can only promise against the process's own kernels -- with other processes' kernels on the same CUs
+        # the barrier times out (NaN embeddings + the device-visible error word, vtc_amd/csrc/cam.hip).  The multi-launch CAM has no
+        # such requirement.  (One process per GPU -- the production layout -- is not affected.)
+        os.environ.setdefault("VTC_CAM_FUSED_MAX_ROWS", "0")
     local = int(os.environ.get("VTC_LOCAL_DEVICE", local))
     backend = os.environ.get("VTC_DIST_BACKEND", backend)
     if world > 1 and not dist.is_initialized():

@@ -81,31 +81,45 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NT <= 4) ? 4 : 1) void attn
   const size_t ld = (size_t)3 * p.W * SZ;   // qkv row bytes
   auto row_of = [&](int tok) -> long { return tok == 0 ? base : base + first + (long)(tok - 1) * p.pstride; };
 
-  // ---- V -> LDS, transposed ------------------------------------------------------------
-  {
-    const char *vbase = p.qkv + (size_t)(2 * p.W + h * 64) * SZ;
-#pragma unroll
-    for (int it = 0; it < (16 * NT * NCH) / 64; ++it) {
-      const int idx = it * 64 + lane;
-      const int tok = idx / NCH, ch = idx - tok * NCH;
-      uint4 raw = make_uint4(0, 0, 0, 0);
-      if (tok < L) raw = *reinterpret_cast<const uint4 *>(vbase + (size_t)row_of(tok) * ld + ch * 16);
-      const T *e = reinterpret_cast<const T *>(&raw);
-#pragma unroll
-      for (int j = 0; j < EPC; ++j) vt[(ch * EPC + j) * VS + tok] = e[j];
-    }
-  }
-
-  // ---- K fragments -> registers ----------------------------------------------------------
+  // ---- V -> LDS (transposed) and K fragments -> registers ------------------------------------
+  // Every load of a batch is requested before the first one is used, and the K fragments with the first batch: a V row past the
+  // sequence is clamped to the last row and zeroed afterwards, not skipped -- a branch per load made hipcc wait for each load in
+  // turn (`if (tok < L) raw = load` x 8: nine dependent global round trips per (sequence, head) with the K fragments behind them,
+  // ~10 of the ~17 us an item took; profiles/r04_experiments.txt 19).
   uint4 kf[NT][KS];
   {
+    const char *vbase = p.qkv + (size_t)(2 * p.W + h * 64) * SZ;
     const char *kbase = p.qkv + (size_t)(p.W + h * 64) * SZ;
+    constexpr int NIT = (16 * NT * NCH) / 64, VB = NIT < 8 ? NIT : 8;       // loads per lane, per batch (8 x 16 B = 32 registers)
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      const int tok = min(kt * 16 + c16, L - 1);
-      const char *r = kbase + (size_t)row_of(tok) * ld;
+    for (int b0 = 0; b0 < NIT; b0 += VB) {
+      uint4 raw[VB];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kf[kt][ks] = *reinterpret_cast<const uint4 *>(r + (4 * ks + g) * 16);
+      for (int u = 0; u < VB; ++u) {
+        if (b0 + u >= NIT) continue;                      // (the last batch may be short: compile-time after unrolling)
+        const int idx = (b0 + u) * 64 + lane;
+        const int tok = idx / NCH, ch = idx - tok * NCH;
+        raw[u] = *reinterpret_cast<const uint4 *>(vbase + (size_t)row_of(min(tok, L - 1)) * ld + ch * 16);
+      }
+      if (b0 == 0) {
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+          const int tok = min(kt * 16 + c16, L - 1);
+          const char *r = kbase + (size_t)row_of(tok) * ld;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) kf[kt][ks] = *reinterpret_cast<const uint4 *>(r + (4 * ks + g) * 16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < VB; ++u) {
+        if (b0 + u >= NIT) continue;
+        const int idx = (b0 + u) * 64 + lane;
+        const int tok = idx / NCH, ch = idx - tok * NCH;
+        const uint4 v = tok < L ? raw[u] : make_uint4(0, 0, 0, 0);
+        const T *e = reinterpret_cast<const T *>(&v);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) vt[(ch * EPC + j) * VS + tok] = e[j];
+      }
     }
   }
   __syncthreads();  // Vt visible to every lane of the wave (waves do not share LDS regions)

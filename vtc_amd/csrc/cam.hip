@@ -198,7 +198,9 @@ __device__ __forceinline__ void proj_phase(float *wlds, const CamFusedParams &p,
         if constexpr (TOK) return *reinterpret_cast<const float4 *>(src + 16 * (pc * CH + c));
         else return bin.ld16(soff + 64 * (pc * CH + c));
       };
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      // four independent accumulator chains (one per component of a chunk): a single chain of D / 4 dependent fp32 MFMAs is
+      // ~36 cycles of latency each (2.4 us at D = 512) -- a visible share of a phase that is a chain of latencies
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
       float4 xt[D / 16];            // the lane's share of the row tile, every load in flight at once (one latency per tile)
 #pragma unroll
       for (int q = 0; q < D / 16; ++q) xt[q] = piece(q / CH, q % CH);
@@ -215,10 +217,11 @@ __device__ __forceinline__ void proj_phase(float *wlds, const CamFusedParams &p,
         if constexpr (TOK) sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         const float4 wq = *reinterpret_cast<const float4 *>(wl + 16 * q);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.x, v.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.y, v.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.z, v.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.w, v.w, acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.y, v.y, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.z, v.z, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.w, v.w, acc3, 0, 0, 0);
       }
+      acc = (acc + acc1) + (acc2 + acc3);
       float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
       [[maybe_unused]] float nrm = 1.0f;
       if constexpr (LN) {

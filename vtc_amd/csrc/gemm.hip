@@ -21,9 +21,11 @@
 //   * bf16: v_mfma_f32_16x16x32_bf16; fp32: 4 x v_mfma_f32_16x16x4_f32 per 16-byte chunk (exact
 //     fp32; the k order inside a chunk is permuted identically for both operands);
 //   * the MFMA "A" operand is the WEIGHT fragment and "B" the ACTIVATION fragment, so a lane ends
-//     up holding 4 consecutive output columns of one output row: bias / QuickGELU / residual /
-//     scatter epilogues run straight from the accumulators with 16-byte (fp32) or 8-byte (bf16)
-//     accesses, no LDS round trip, all loads of a row issued before their first use;
+//     up holding 4 consecutive output columns of one output row; interior tiles (every tile of the
+//     towers) transpose their outputs through the LDS stage the last K-step freed and store whole
+//     128 / 256-byte row segments (tile_epilogue: bias / folded LayerNorm / QuickGELU / residual on
+//     the (hi, lo) stream / scatter / distance applied on the way), edge tiles store straight from
+//     the accumulators; a tile's small vectors are requested back to back before their first use;
 //   * PERSISTENT workgroups: the grid is one (big) or two (small) workgroups per CU; each walks a
 //     strided list of tiles, and the first K-slab of the NEXT tile is already in flight during the
 //     last K-step of the current one, so short-K problems (K = 512/768 here) do not pay a cold
@@ -37,8 +39,10 @@
 
 // Production source: the ablation / timing-probe branches of rounds 1-2 (builds that gave WRONG results on purpose: stores,
 // LDS reads, DMA or waits removed, 32x32x16 MFMA probe) are gone from this file -- their measurements are in DESIGN.md 4.1 and
-// the code in the history (commit 3ac3430).  What remains is the cycle-stamp diagnostic (correct results, slower), kept out of
-// line in gemm_stamps.h and compiled only with -DVTC_GEMM_STAMPS, which __graft_entry__.build() refuses.
+// the code in the history (commit 3ac3430).  What remains are the cycle-stamp diagnostics (correct results, slower), kept out of
+// line in gemm_stamps.h and compiled only with -DVTC_GEMM_STAMPS / -DVTC_GEMM_PHASE_STAMPS, and three alternative K-loop schedules
+// of the 256 x 256 kernel that give bit-identical results and measured level or slower (-DVTC_GEMM_DEEP2 / 3 / 4 +
+// VTC_GEMM_DEEP=2|3|4: profiles/r04_experiments.txt 1, 14, 16); __graft_entry__.build() refuses every -DVTC_* flag.
 #if defined(VTC_ABLATE_STORES) || defined(VTC_ABLATE_DMA) || defined(VTC_ABLATE_HALF_DMA) || defined(VTC_ABLATE_DMA_EXEC1) || \
     defined(VTC_ABLATE_VMWAIT) || defined(VTC_ABLATE_LDSREAD) || defined(VTC_PROBE_MFMA32) || defined(VTC_PHASED_WAIT_FIRST) || \
     defined(VTC_PHASED_ONE_BARRIER) || defined(VTC_NO_RELAXED_FIRST) || defined(VTC_ROW_PANEL_PROBE)

@@ -161,13 +161,13 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
     for (int e = 0; e < 4; ++e) col[j][e].init();
   const size_t rstride = (size_t)p.epi.nblk_c * p.M;     // elements between the planes (key 1, key 2, key 3, bound)
   const int cblk = nbase >> 6;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  // (the row loop exists twice: interior waves -- all of them but the last row / column of tiles -- run it without the two selects
+  //  and the validity bit per value that edge waves need: ~350 of ~3 750 vector instructions per wave and tile)
+  auto row_pass = [&](int i, auto interior_c, Min4 &row) __attribute__((always_inline)) {
+    constexpr bool INTERIOR = decltype(interior_c)::value;
     const int m = mbase + 16 * i + l15;
-    const bool mv = m < p.M;
+    const bool mv = INTERIOR || m < p.M;
     const float rn = mv ? p.epi.rown[m] : 0.f;
-    Min4 row;
-    row.init();
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -176,7 +176,7 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
         // as a signed-integer max, which needs no canonicalisation; its key then sorts first, as it must
         const unsigned bits = (unsigned)max(__float_as_int((rn - 2.0f * acc[i][j][e]) + cn[j][e]), 0);
         unsigned kr = key_bfi(127u, (unsigned)(16 * j + 4 * g + e), bits), kc = key_bfi(127u, (unsigned)(16 * i + l15), bits);
-        if (!interior) {
+        if constexpr (!INTERIOR) {
           const bool v = mv && ((cvalid >> (4 * j + e)) & 1);
           kr = v ? kr : VTC_L2MIN_INF;
           kc = v ? kc : VTC_L2MIN_INF;
@@ -184,6 +184,15 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
         row.insert(kr);
         if (cols_too) col[j][e].insert(kc);
       }
+  };
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mbase + 16 * i + l15;
+    const bool mv = m < p.M;
+    Min4 row;
+    row.init();
+    if (interior) row_pass(i, std::true_type{}, row);
+    else row_pass(i, std::false_type{}, row);
     // the row's 64 columns of this wave sit in the four lanes l15 + 16 g: merge (xor 16, xor 32)
     {
       const bool odd = (g & 1) != 0, up = g >= 2;

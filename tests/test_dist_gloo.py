@@ -161,3 +161,23 @@ def test_bench_gpus_n_launches_its_own_ranks():
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=300)
     assert r2.returncode != 0 and "refusing" in (r2.stderr + r2.stdout)
+
+
+def test_ranks_pinned_to_one_card_select_the_multi_launch_cam(monkeypatch):
+    """Several ranks on ONE device (VTC_LOCAL_DEVICE, the rehearsal layout): the one-launch CAM's grid barrier cannot be resident next to
+    other processes' kernels (5-rank rehearsal: time-out, NaN), so vtc_amd/dist.py selects the multi-launch CAM -- and leaves the
+    production layout (one process per GPU, no VTC_LOCAL_DEVICE) alone."""
+    from vtc_amd import dist as vdist
+    calls = {}
+    monkeypatch.setattr(vdist.dist, "is_initialized", lambda: False)
+    monkeypatch.setattr(vdist.dist, "init_process_group", lambda **kw: calls.update(kw))
+    monkeypatch.setattr(vdist.torch.cuda, "is_available", lambda: False)
+    for k in ("VTC_CAM_FUSED_MAX_ROWS", "VTC_LOCAL_DEVICE", "VTC_DIST_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("LOCAL_RANK", "1")
+    rank, local, world = vdist.init_from_env()
+    assert (rank, local, world) == (1, 1, 2) and calls["backend"] == "gloo" and "VTC_CAM_FUSED_MAX_ROWS" not in os.environ
+    monkeypatch.setenv("VTC_LOCAL_DEVICE", "0"); monkeypatch.setenv("VTC_DIST_BACKEND", "gloo")
+    rank, local, world = vdist.init_from_env()
+    assert local == 0 and os.environ.get("VTC_CAM_FUSED_MAX_ROWS") == "0"
+    monkeypatch.delenv("VTC_CAM_FUSED_MAX_ROWS", raising=False)

@@ -495,12 +495,22 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       for (int q = 0; q < NQM; ++q) mprev[q] = p.epi.fold_stat[2 * (size_t)(m0 + wr * TM * 16 + min(lane + 64 * q, TM * 16 - 1))];
     }
     typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    [[maybe_unused]] char *hi_base = nullptr, *lo_base = nullptr;
+    [[maybe_unused]] unsigned split_off0 = 0, split_row4 = 0;
+    if constexpr (SPLIT) {
+      const int m0s = __builtin_amdgcn_readfirstlane(m0);
+      const int wrs = __builtin_amdgcn_readfirstlane(wr), ncs = __builtin_amdgcn_readfirstlane(ncol0);
+      const size_t row0 = (size_t)(m0s + wrs * TM * 16) * ldo + ncs;
+      hi_base = reinterpret_cast<char *>(reinterpret_cast<unsigned short *>(p.epi.y16) + row0);
+      lo_base = reinterpret_cast<char *>(reinterpret_cast<unsigned short *>(p.epi.y16lo) + row0);
+      split_off0 = (unsigned)(((lane >> 4) * ldo + l15 * 4) * 2);
+      split_row4 = (unsigned)ldo * 8u;
+    }
+    auto split_off = [&](int pp, int k) -> unsigned { return split_off0 + (unsigned)(4 * (pp / H) + k) * split_row4 + (unsigned)(128 * (pp % H)); };
     auto x_load = [&](int pp, int k) -> float4 {
       if constexpr (SPLIT) {
-        const int m = m0 + (wr * TM + pp / H) * 16 + (lane >> 4) + 4 * k;
-        const size_t e = (size_t)m * ldo + ncol0 + 64 * (pp % H) + l15 * 4;
-        const v2u_t hi = *reinterpret_cast<const v2u_t *>(reinterpret_cast<const unsigned short *>(p.epi.y16) + e);
-        const v2u_t lo = *reinterpret_cast<const v2u_t *>(reinterpret_cast<const unsigned short *>(p.epi.y16lo) + e);
+        const v2u_t hi = *reinterpret_cast<const v2u_t *>(hi_base + split_off(pp, k));
+        const v2u_t lo = *reinterpret_cast<const v2u_t *>(lo_base + split_off(pp, k));
         return make_float4(__uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(lo.x), __uint_as_float(lo.y));
       } else {
         return *reinterpret_cast<const float4 *>(x_ptr(pp, k));
@@ -629,9 +639,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
 #ifndef VTC_SPLIT_ST
 #define VTC_SPLIT_ST 0
 #endif
-              const size_t e = (size_t)m * ldo + ncolh + cc;
-              v2u_t *ph = reinterpret_cast<v2u_t *>(reinterpret_cast<unsigned short *>(p.epi.y16) + e);
-              v2u_t *pq = reinterpret_cast<v2u_t *>(reinterpret_cast<unsigned short *>(p.epi.y16lo) + e);
+              v2u_t *ph = reinterpret_cast<v2u_t *>(hi_base + split_off(pp, k));
+              v2u_t *pq = reinterpret_cast<v2u_t *>(lo_base + split_off(pp, k));
               if constexpr (VTC_SPLIT_ST == 1) {
                 __builtin_nontemporal_store((v2u_t){pk.x, pk.y}, ph);
                 __builtin_nontemporal_store((v2u_t){pl.x, pl.y}, pq);

@@ -378,6 +378,11 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
         }
       };
       static_assert(2 * 16 * TSB <= SCRATCH_PER_WAVE, "two transposition buffers per wave");
+      char *out_base16;
+      {
+        const int m0s = __builtin_amdgcn_readfirstlane(m0), wrs = __builtin_amdgcn_readfirstlane(wr), ncs = __builtin_amdgcn_readfirstlane(ncol0);
+        out_base16 = reinterpret_cast<char *>(reinterpret_cast<unsigned short *>(p.out) + (size_t)(m0s + wrs * TM * 16) * ldo + ncs);
+      }
       put(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -393,11 +398,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
           hi[k] = *reinterpret_cast<const uint2 *>(buf + r * TSB + c * 16 + 8);
         }
         if (i + 1 < TM) put(i + 1);
-        const int mrow0 = m0 + (wr * TM + i) * 16;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const int r = (lane >> 3) + 8 * k, c = lane & 7;
-          unsigned short *o = reinterpret_cast<unsigned short *>(p.out) + (size_t)(mrow0 + r) * ldo + ncol0 + c * 8;
+          // wave-uniform base (this wave's first output element) + a 32-bit lane offset: the `saddr` form of the store
+          char *o = out_base16 + (unsigned)(((i * 16 + (lane >> 3) + 8 * k) * ldo + (lane & 7) * 8) * 2);
           store16<nt_out>(o, make_uint4(lo[k].x, lo[k].y, hi[k].x, hi[k].y));
         }
       }

@@ -21,9 +21,11 @@ Top-level objects beside the contract's fields:
   headline_batch_independence[_max_err]
                 items [0:16] and [B-16:B] of the timed batch re-encoded as two B = 16 forwards (the shape the tests and the
                 cpu_baseline leg hold to the oracle): max abs error of the embeddings and of the cosine block; > 1e-3 fails the run.
-  sweep_10000_ms / sweep_50000_ms (+ _hbm_frac, _phases_ms_per_rank)
+  sweep_10000_ms / sweep_50000_ms (+ _roofline, _phases_ms_per_rank)
                 the second half of BASELINE's metric: N x N similarity + R@1/5/10 in both directions, parity mode
-                (EXACT), sharded over the ranks; fraction of 8 TB/s at the algorithmic 2 x 8 N^2 bytes.
+                (EXACT), sharded over the ranks; sweep_N_roofline: the distance GEMM (and the whole sweep) against the
+                bf16 MFMA peak + PMC bytes per sweep (profiles/); the fused sweep never writes the matrix, so no HBM
+                "fraction" on the materialised-matrix convention is printed any more.
   cpu_baseline  the oracle (plain PyTorch fp32 restatement of the reference, kind "port") on this box's host cores,
                 BASELINE.md section 4 protocol on a bounded sample (rank 0, N = 1 only).
   extra         secondary measurements of the same path (config 2, dense-text variants, 16-frame stress encoder,
@@ -313,6 +315,21 @@ def pmc_traffic(workload_tag):
         if j.get("workload") == workload_tag:
             return round(float(j["traffic_bytes_per_launch"]), 1), {k: j.get(k) for k in ("commit", "date", "source")} | {"file": os.path.basename(f)}
     return None, None
+
+
+def sweep_pmc_traffic(n):
+    """HBM bytes of ONE whole sweep at N = n (every launch of it: prologue, distance GEMM, selection, re-rank, hit counting) from
+    this round's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/sweep_profile.py (profiles/*_sweep_traffic.json, FETCH_SIZE
+    x 2 on gfx950), beside the bytes a materialised fp32 matrix would cost; None when no pass of this round exists for that N."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sweep_traffic.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        e = j.get("sweeps", {}).get(str(n))
+        if e:
+            return dict(e, file=os.path.basename(f), commit=j.get("commit"), date=j.get("date"))
+    return None
 
 
 def launches():
@@ -807,10 +824,9 @@ def main():
                 result[f"sweep_{N}_ms_stats"] = sw["host"]
                 result[f"sweep_{N}_gpu_ms_stats"] = sw["gpu"]
                 result[f"sweep_{N}_phases_ms_per_rank"] = sw["phases"]
-                # algorithmic HBM bytes with the fp32 matrix materialised: 8 N^2 per direction, whole job -- a
-                # CONVENTION (BASELINE's 60 % target is stated on it); the block-minima path moves far fewer bytes, and what
-                # binds it is the distance GEMM + its VALU epilogue: see sweep_N_roofline
-                result[f"sweep_{N}_hbm_frac"] = round(2 * 8.0 * N * N / dts / 1e9 / (PEAK_HBM_GBS * world), 4)
+                # (rounds 1-4 printed sweep_N_hbm_frac = 2 x 8 N^2 bytes / time / 8 TB/s here -- the bytes of a MATERIALISED fp32 matrix,
+                # which this sweep never writes: a "fraction" above 1 is not a measurement, so the figure is gone.
+                # What bounds the sweep is its distance GEMM (bf16 MFMA, 2 N^2 512 FLOP) + that GEMM's VALU epilogue: sweep_N_roofline.)
                 cl = sw.get("classes", {})
                 gk_ = cl.get("gemm_bf16", {"ms": 0.0, "work": 0.0, "launches": 0})
                 other_ms = sum(v["ms"] for k, v in cl.items() if k != "gemm_bf16")
@@ -819,10 +835,14 @@ def main():
                         "bound": "mfma+valu", "kernel": "distance GEMM with the block-minima epilogue (gemm_phased_kernel<EPI_L2MIN>)",
                         "gemm_ms": round(gk_["ms"], 4), "gemm_launches": gk_["launches"], "gemm_tflops": round(gk_["work"] / gk_["ms"] / 1e9, 1),
                         "frac": round(gk_["work"] / (gk_["ms"] * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        # the whole job's distance FLOPs (one [N/G, N] GEMM per rank) over the WHOLE sweep's wall time and all ranks' peak
+                        "frac_whole_sweep": round(2.0 * N * N * 512 / dts / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
                         "select_rerank_prologue_ms": round(other_ms, 4),
-                        "kernel_ms_sum": round(gk_["ms"] + other_ms, 4)}
+                        "kernel_ms_sum": round(gk_["ms"] + other_ms, 4),
+                        "traffic": sweep_pmc_traffic(N)}
                 result[f"sweep_{N}"] = {"mode": "EXACT (fp64-certified ranks: the parity mode)", "recall_t_from_v": sw["r_ab"], "recall_v_from_t": sw["r_ba"],
-                                        "algorithmic_GBps": round(2 * 8.0 * N * N / dts / 1e9, 1), "this_rank_ms": round(sw["mine"], 3),
+                                        "materialised_matrix_equivalent_GBps": round(2 * 8.0 * N * N / dts / 1e9, 1),      # NOT bytes moved: what writing + reading 2 fp32 matrices in this time would take
+                                        "this_rank_ms": round(sw["mine"], 3),
                                         "path": vdist.sweep_path(N, L.SWEEP_EXACT, world)}
                 if not args.no_extra:
                     for name, prec in (("f32", L.SWEEP_F32), ("bf16x3", L.SWEEP_BF16X3), ("bf16", L.SWEEP_BF16)):

@@ -177,6 +177,12 @@ int vtc_text_forward_ragged(const vtc_text_w *w, const int64_t *ids, int n_seq, 
 size_t vtc_cam_workspace_bytes(const vtc_cam_w *w, int B, int nc, int dtype);
 int vtc_cam_forward(const vtc_cam_w *w, const float *main_feats, const float *comm_feats, const int64_t *comments,
                     int ctx, int B, int nc, float *adapted, void *ws, size_t ws_bytes, int dtype, void *stream);
+/* Small batches run the whole module as ONE launch with software grid barriers (cam.hip).  A barrier that cannot complete --
+ * a kernel this process cannot see holds CUs: another process on the card, a collective -- gives up after ~0.4 s: THAT call's
+ * `adapted` rows are NaN, and every later call on the device takes the multi-launch path (same results; one line on stderr).
+ * vtc_cam_fused_gave_up(device) = 1 once that has happened in this process (a host read of a pinned word, no synchronisation;
+ * it speaks for a given forward once the forward's stream has been synchronised). */
+int vtc_cam_fused_gave_up(int device);
 
 /* ---- small fp32 ops of the wrappers (model/model.py:26-27, 338, 357-362, 369) -------- */
 int vtc_normalize_rows(const float *x, float *out, int n, int d, void *stream);
@@ -212,7 +218,11 @@ int vtc_clip_loss(const float *sim, int n, float *loss, void *ws, size_t ws_byte
 /* ids[nq,depth] (int64) / dists[nq,depth] (fp32, may be NULL) = the `depth` rows of `gallery`
  * nearest to each row of `queries` by squared L2 = |q|^2 + |g|^2 - 2 q.g (fp32), ascending,
  * ties by lowest gallery index.  The fp32 distance matrix is materialised in `ws` in
- * row blocks of `rows_per_block` queries (0 = as many as fit). */
+ * row blocks of `rows_per_block` queries (0 = as many as fit).
+ * LIMITS (refused with a status + vtc_last_error, nothing is launched): d % 64 == 0 -- zero-pad the feature columns, squared L2
+ * distances are unchanged (faiss.IndexFlatL2 takes any d; vtc_amd/host/metric.py pads for its callers) -- and
+ * 1 <= depth <= min(64, n_gallery): one list entry per lane of a wavefront; the reference searches depth max(k)+1 = 11
+ * (model/metric.py:145).  The same limits hold for vtc_l2_topk_bidir and the sharded entry points below. */
 size_t vtc_l2_topk_workspace_bytes(int n_gallery, int n_queries, int d, int precision, int rows_per_block);
 int vtc_l2_topk(const float *gallery, const float *queries, int n_gallery, int n_queries, int d, int depth,
                 int precision, int rows_per_block, int64_t *ids, float *dists, void *ws, size_t ws_bytes,

@@ -82,25 +82,25 @@ def near_ties(features_a: np.ndarray, features_b: np.ndarray, k_vals: Sequence[i
     return n
 
 
-def eval_result_dict(res_vis: np.ndarray, res_text: np.ndarray) -> dict:
-    """evaluation/eval.py:121-138: both directions, k in {1,5,10}, JSON keys."""
-    t_from_i = recall_at_k(res_vis, res_text, [1, 5, 10])
-    i_from_t = recall_at_k(res_text, res_vis, [1, 5, 10])
+def eval_result_dict(res_vis: np.ndarray, res_text: np.ndarray, dtype=np.float32) -> dict:
+    """evaluation/eval.py:121-138: both directions, k in {1,5,10}, JSON keys.  ``dtype=np.float64``: ground-truth ranks."""
+    t_from_i = recall_at_k(res_vis, res_text, [1, 5, 10], dtype)
+    i_from_t = recall_at_k(res_text, res_vis, [1, 5, 10], dtype)
     return {
         "R1_title_from_im": t_from_i[0][1], "R5_title_from_im": t_from_i[1][1], "R10_title_from_im": t_from_i[2][1],
         "R1_im_from_title": i_from_t[0][1], "R5_im_from_title": i_from_t[1][1], "R10_im_from_title": i_from_t[2][1],
     }
 
 
-def compute_recall_table(tensor_v: torch.Tensor, tensor_t: torch.Tensor):
+def compute_recall_table(tensor_v: torch.Tensor, tensor_t: torch.Tensor, dtype=np.float32):
     """compute_recall, evaluation/retrieval_evaluation.py:23-47 (one caption per video:
     ``tensor_t.numpy().squeeze()`` must be 2-D, SURVEY 3.3 caveat).  Returns
     (video_to_text[3], text_to_video[3]) in percent for R@1/5/10, named as the reference's
     DataFrame columns name them (:39-43: 'Video to Text' = tvr, 'Text to Video' = vtr)."""
     t = tensor_t.numpy().squeeze()
     assert t.ndim == 2, "only the one-caption-per-video case is defined"
-    vtr = np.array(recall_at_k(tensor_v.numpy(), t, [1, 5, 10]))[:, 1] * 100.0
-    tvr = np.array(recall_at_k(t, tensor_v.numpy(), [1, 5, 10]))[:, 1] * 100.0
+    vtr = np.array(recall_at_k(tensor_v.numpy(), t, [1, 5, 10], dtype))[:, 1] * 100.0
+    tvr = np.array(recall_at_k(t, tensor_v.numpy(), [1, 5, 10], dtype))[:, 1] * 100.0
     return tvr, vtr
 
 

@@ -163,21 +163,70 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert r2.returncode != 0 and "refusing" in (r2.stderr + r2.stdout)
 
 
-def test_ranks_pinned_to_one_card_select_the_multi_launch_cam(monkeypatch):
-    """Several ranks on ONE device (VTC_LOCAL_DEVICE, the rehearsal layout): the one-launch CAM's grid barrier cannot be resident next to
-    other processes' kernels (5-rank rehearsal: time-out, NaN), so vtc_amd/dist.py selects the multi-launch CAM -- and leaves the
-    production layout (one process per GPU, no VTC_LOCAL_DEVICE) alone."""
+def test_ranks_sharing_a_card_select_the_multi_launch_cam(monkeypatch):
+    """Several ranks on ONE device -- however they got there (VTC_LOCAL_DEVICE rehearsals, LOCAL_RANK modulo the device count, a narrowed
+    HIP_VISIBLE_DEVICES): the one-launch CAM's grid barrier cannot be resident next to other processes' kernels (5-rank rehearsal:
+    time-out, NaN), so vtc_amd/dist.py detects shared cards from the gathered (host, card id) pairs and sets the per-model
+    VTC_CAM_NO_FUSED flag (no environment variable a library static may already have read) -- and leaves the production
+    layout (one process per GPU) alone."""
+    from vtc_amd import _lib as L
     from vtc_amd import dist as vdist
-    calls = {}
-    monkeypatch.setattr(vdist.dist, "is_initialized", lambda: False)
-    monkeypatch.setattr(vdist.dist, "init_process_group", lambda **kw: calls.update(kw))
-    monkeypatch.setattr(vdist.torch.cuda, "is_available", lambda: False)
-    for k in ("VTC_CAM_FUSED_MAX_ROWS", "VTC_LOCAL_DEVICE", "VTC_DIST_BACKEND"):
-        monkeypatch.delenv(k, raising=False)
-    monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("LOCAL_RANK", "1")
-    rank, local, world = vdist.init_from_env()
-    assert (rank, local, world) == (1, 1, 2) and calls["backend"] == "gloo" and "VTC_CAM_FUSED_MAX_ROWS" not in os.environ
-    monkeypatch.setenv("VTC_LOCAL_DEVICE", "0"); monkeypatch.setenv("VTC_DIST_BACKEND", "gloo")
-    rank, local, world = vdist.init_from_env()
-    assert local == 0 and os.environ.get("VTC_CAM_FUSED_MAX_ROWS") == "0"
-    monkeypatch.delenv("VTC_CAM_FUSED_MAX_ROWS", raising=False)
+    from vtc_amd import towers
+    monkeypatch.setattr(towers, "_CAM_SHARED_CARD", False)
+    monkeypatch.setattr(vdist, "card_identity", lambda local: ("hostA", "GPU-1"))
+    assert vdist.mark_shared_cards(0, identities=[("hostA", "GPU-1"), ("hostA", "GPU-2"), ("hostB", "GPU-1")]) is False
+    assert towers._CAM_SHARED_CARD is False
+    assert vdist.mark_shared_cards(0, identities=[("hostA", "GPU-1"), ("hostA", "GPU-2"), ("hostA", "GPU-1")]) is True
+    assert towers._CAM_SHARED_CARD is True
+    # the flag reaches a module that was packed BEFORE the process group existed: it is applied per forward
+    class _W:
+        flags = 0
+    w = _W()
+    if towers._CAM_SHARED_CARD:
+        w.flags |= L.CAM_NO_FUSED
+    assert w.flags & L.CAM_NO_FUSED
+    towers.set_cam_shared_card(False)
+
+
+def _shared_card_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from vtc_amd import dist as vdist
+    from vtc_amd import towers
+    # ranks 0 and 2 claim the same card, rank 1 another
+    vdist.card_identity = lambda local: ("box", "GPU-A" if rank != 1 else "GPU-B")
+    vdist.init_from_env(backend="gloo")
+    out.put((rank, towers._CAM_SHARED_CARD))
+    dist.destroy_process_group()
+
+
+def test_shared_card_detection_over_gloo_world_3():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_shared_card_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p_ in ps:
+        p_.start()
+    got = dict(q.get(timeout=120) for _ in range(3))
+    for p_ in ps:
+        p_.join(60)
+    assert got == {0: True, 1: False, 2: True}
+
+
+def test_single_rank_path_of_sharded_recall_is_the_plain_recall():
+    """the N = 1 line of a scaling run (`bench.py --gpus 1` -> sharded_recall(world=1)) must be the same computation as
+    the single-GPU headline's (RecallAtK.compute_both): no collective, whole-matrix shard bounds, target offset 0, the reference's
+    denominators.  CPU half of the check (the injected top-k is the oracle's); the GPU half -- the HIP sweep on both sides -- is
+    tests/test_gpu_sweep.py::test_sharded_recall_world_1_equals_recallatk_compute_both."""
+    from vtc_amd import dist as vdist
+    rng = np.random.default_rng(4)
+    n = 300
+    a = rng.standard_normal((n, 32)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = a + 0.7 * rng.standard_normal((n, 32)).astype(np.float32)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    assert vdist.shard_bounds(n, 0, 1) == (0, n)
+    ph = {}
+    r_ab, r_ba = vdist.sharded_recall(torch.from_numpy(a), torch.from_numpy(b), n, [1, 5, 10], 0, 1, topk=_cpu_topk, phases=ph)
+    assert r_ab == dict(E.recall_at_k(a, b, [1, 5, 10])) and r_ba == dict(E.recall_at_k(b, a, [1, 5, 10]))
+    assert vdist.sweep_path(n, 3, 1).startswith("two searches") and vdist.sweep_path(10000, 3, 1).startswith("one distance matrix")
+    assert not vdist.one_matrix_sharded(10000, 3, 1, 11)

@@ -28,5 +28,7 @@ def test_eval_cli_matches_oracle_recall(cfg, n, tmp_path):
     assert saved["synthetic"] is True and saved["n_pairs"] == n
     fv, ft = fv.cpu().numpy(), ft.cpu().numpy()
     assert fv.shape == (n, 512) and np.allclose(np.linalg.norm(fv, axis=1), 1, atol=1e-5)
-    if E.near_ties(fv, ft) == 0 and E.near_ties(ft, fv) == 0:
-        assert {k: v for k, v in out.items() if k.startswith("R")} == E.eval_result_dict(fv, ft)
+    # the EXACT sweep has the fp64 neighbour ids on every row: equality with the ground-truth ranks is unconditional
+    # (no near-tie guard); the near-tie count is reported, not used
+    print(f"[parity] {cfg}: near ties (fp64 gap < 1e-6) {E.near_ties(fv, ft)} / {E.near_ties(ft, fv)} of {n} queries per direction")
+    assert {k: v for k, v in out.items() if k.startswith("R")} == E.eval_result_dict(fv, ft, np.float64)

@@ -45,10 +45,17 @@ def test_ragged_chunked_eval_matches_per_video_loop(branch):
     ref_v, ref_c = E.mean_chunks(ref_v), torch.stack(ref_c)
     assert (v_emb.cpu() - ref_v).abs().max() < 1e-5 and (c_emb.cpu() - ref_c).abs().max() < 1e-5
     assert not np.allclose(np.linalg.norm(v_emb.cpu().numpy(), axis=1), 1.0, atol=1e-4)      # mean is NOT renormalised
-    tvr, vtr = E.compute_recall_table(ref_v, ref_c)
-    if E.near_ties(ref_v.numpy(), ref_c.numpy()) == 0 and E.near_ties(ref_c.numpy(), ref_v.numpy()) == 0:
-        np.testing.assert_allclose(table["Video to Text"], tvr)
-        np.testing.assert_allclose(table["Text to Video"], vtr)
+    # ranks: the table is computed from the GPU's embeddings, so hold it to the fp64 ranks of THOSE embeddings without a
+    # near-tie guard (the EXACT sweep's contract), and report how the oracle's own embeddings rank (end-to-end view)
+    tvr, vtr = E.compute_recall_table(v_emb.cpu(), c_emb.cpu(), np.float64)
+    np.testing.assert_array_equal(table["Video to Text"], tvr)
+    np.testing.assert_array_equal(table["Text to Video"], vtr)
+    tvr_o, vtr_o = E.compute_recall_table(ref_v, ref_c, np.float64)
+    nt = E.near_ties(ref_v.numpy(), ref_c.numpy()) + E.near_ties(ref_c.numpy(), ref_v.numpy())
+    print(f"[parity] chunked eval ({branch}): near ties {nt}; oracle-embedding table {tvr_o.tolist()} / {vtr_o.tolist()}")
+    if nt == 0:       # 6 videos: a 1e-6 gap between neighbours would be the only way the two embedding sets rank differently
+        np.testing.assert_array_equal(table["Video to Text"], tvr_o)
+        np.testing.assert_array_equal(table["Text to Video"], vtr_o)
 
 
 def test_ragged_chunked_eval_vit_b32_bf16_vs_per_video_oracle_loop():

@@ -71,6 +71,7 @@ SIGNATURES = {
     "vtc_text_forward_ragged": (C.c_int, [C.POINTER(TextW), ip, C.c_int, ip, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
     "vtc_cam_workspace_bytes": (C.c_size_t, [C.POINTER(CamW), C.c_int, C.c_int, C.c_int]),
     "vtc_cam_forward": (C.c_int, [C.POINTER(CamW), fp, fp, ip, C.c_int, C.c_int, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
+    "vtc_cam_fused_gave_up": (C.c_int, [C.c_int]),
     "vtc_normalize_rows": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),
     "vtc_mean_groups": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp]),
     "vtc_nonfinite_flag": (C.c_int, [fp, C.c_size_t, vp, vp]),

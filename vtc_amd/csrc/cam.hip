@@ -513,6 +513,7 @@ bool cam_fused_supported(const vtc_cam_w *w, int B, int nc, int dtype) {
 // -> this call reports "busy" and vtc_cam_forward takes the multi-launch path (same results).  No synchronisation.
 #include <mutex>
 namespace {
+int *g_cam_err_words[64] = {};     // per device: pinned, device-visible; set by a grid barrier that gave up, never reset
 struct CamInFlight { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool any = false; };
 CamInFlight g_cam_inflight[64];
 std::mutex g_cam_mu;
@@ -540,18 +541,28 @@ int launch_cam_fused(const vtc_cam_w *w, const float *main_feats, const float *c
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
   std::lock_guard<std::mutex> lk(g_cam_mu);
   // the error word of this device: pinned, device-visible, allocated once.  A grid barrier that gave up (the launch lost its
-  // residency guarantee: it cannot under a cooperative launch, so this is a defect report, not a mode) wrote NaN embeddings AND
-  // set this word; every later call on the device fails with a message instead of returning rc 0 beside NaN.
-  static int *err_words[64] = {};
-  if (!err_words[dev]) {
+  // residency guarantee: it cannot under a cooperative launch) wrote NaN embeddings AND set this word.
+  if (!g_cam_err_words[dev]) {
     int *h = nullptr;
     if (hipHostMalloc((void **)&h, 64, hipHostMallocMapped) != hipSuccess || !h) return -1;     // no error word: take the multi-launch path
     *h = 0;
-    err_words[dev] = h;
+    g_cam_err_words[dev] = h;
   }
-  VTC_CHECK(*(volatile int *)err_words[dev] == 0,
-            "cam_fused: an earlier one-launch CAM on device %d gave up at a grid barrier (its embeddings were written as NaN); "
-            "re-run with VTC_CAM_NO_FUSED in the model flags", dev);
+  int **err_words = g_cam_err_words;
+  // a barrier that gave up (a co-resident kernel this process cannot see held CUs: another stream's persistent
+  // GEMM, RCCL, another process on the card) is a property of the MOMENT, not of the device -- so it must not fail every later
+  // call.  The call it hit wrote NaN embeddings (loud) and set the word; from then on this device takes the multi-launch path
+  // (same results, no grid barrier), said once on stderr; vtc_cam_fused_gave_up() lets the host ask at its next synchronisation.
+  if (*(volatile int *)err_words[dev] != 0) {
+    static bool told[64] = {};
+    if (!told[dev]) {
+      told[dev] = true;
+      fprintf(stderr, "[vtc_amd] cam_fused: an earlier one-launch CAM on device %d gave up at a grid barrier (that call's embeddings were "
+                      "written as NaN: vtc_cam_fused_gave_up(%d) != 0); the one-launch path is now OFF for this device, the multi-launch "
+                      "path takes over\n", dev, dev);
+    }
+    return -1;
+  }
   if (cam_fused_busy_locked(dev, stream)) return -1;
   CamFusedParams p;
   {
@@ -623,4 +634,13 @@ int launch_cam_fused(const vtc_cam_w *w, const float *main_feats, const float *c
     fprintf(stderr, "\n");
   }
   return 0;
+}
+
+// 1 when a one-launch CAM on `device` has ever given up at a grid barrier in this process (the call it happened in returned NaN
+// embeddings; later calls take the multi-launch path).  A host read of a pinned word: no synchronisation, callable any time --
+// meaningful for a given forward once the stream it ran on has been synchronised.
+extern "C" int vtc_cam_fused_gave_up(int device) {
+  if (device < 0 || device >= 64) return 0;
+  std::lock_guard<std::mutex> lk(g_cam_mu);
+  return g_cam_err_words[device] && *(volatile int *)g_cam_err_words[device] != 0 ? 1 : 0;
 }

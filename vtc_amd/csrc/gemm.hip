@@ -40,9 +40,9 @@
 // Production source: the ablation / timing-probe branches of rounds 1-2 (builds that gave WRONG results on purpose: stores,
 // LDS reads, DMA or waits removed, 32x32x16 MFMA probe) are gone from this file -- their measurements are in DESIGN.md 4.1 and
 // the code in the history (commit 3ac3430).  What remains are the cycle-stamp diagnostics (correct results, slower), kept out of
-// line in gemm_stamps.h and compiled only with -DVTC_GEMM_STAMPS / -DVTC_GEMM_PHASE_STAMPS, and three alternative K-loop schedules
-// of the 256 x 256 kernel that give bit-identical results and measured level or slower (-DVTC_GEMM_DEEP2 / 3 / 4 +
-// VTC_GEMM_DEEP=2|3|4: profiles/r04_experiments.txt 1, 14, 16); __graft_entry__.build() refuses every -DVTC_* flag.
+// line in gemm_stamps.h and compiled only with -DVTC_GEMM_STAMPS / -DVTC_GEMM_PHASE_STAMPS.  The three alternative K-loop schedules
+// of round 4 (DEEP 2 / 3 / 4: bit-identical results, measured level or slower -- profiles/r04_experiments.txt 1, 14, 16) left the
+// product source in round 5 (commit 7fd3e13 has them); __graft_entry__.build() refuses every -DVTC_* flag.
 #if defined(VTC_ABLATE_STORES) || defined(VTC_ABLATE_DMA) || defined(VTC_ABLATE_HALF_DMA) || defined(VTC_ABLATE_DMA_EXEC1) || \
     defined(VTC_ABLATE_VMWAIT) || defined(VTC_ABLATE_LDSREAD) || defined(VTC_PROBE_MFMA32) || defined(VTC_PHASED_WAIT_FIRST) || \
     defined(VTC_PHASED_ONE_BARRIER) || defined(VTC_NO_RELAXED_FIRST) || defined(VTC_ROW_PANEL_PROBE)
@@ -961,23 +961,23 @@ __device__ __attribute__((noinline)) void fused_ln_rows(const float *out, int M,
 // misses the L2 (every activation quarter's first touch does) no longer parks the workgroup.  With two stages the depth comes from
 // re-filling the stage that is being READ, quarter by quarter, as the walk frees it:
 //     K-tile t reads stage X (t even/odd), stage Y holds K-tile t+1:
-//       ph0: read A0, W0 (12)   issue QA(t+1) -> Y                  QA = W0 (DEEP 1) / W1 (DEEP 2)
+//       ph0: read A0, W0 (12)   issue W0(t+1) -> Y
 //       ph1: read W1 (4)        issue A1(t+1) -> Y   vmcnt(8): A1(t) has landed            [read in ph2]
 //       ph2: read A1 (8)        issue A0(t+2) -> X   (A0 of X: last read in ph0)
-//       ph3: DEEP 1: read W0 again (4), retired BEFORE the phase's first barrier; DEEP 2: W0 stays in registers, no read
-//                               issue QB(t+2) -> X   vmcnt(6): A0, QA, QB of K-tile t+1 have landed  [read in ph0 / ph1 of t+1]
-//     QB = W1 (DEEP 1: last read in ph1) / W0 (DEEP 2: last read in ph0).
+//       ph3: read W0 again (4), retired BEFORE the phase's first barrier
+//                               issue W1(t+2) -> X   vmcnt(6): A0, W0, W1 of K-tile t+1 have landed  [read in ph0 / ph1 of t+1]
+//     (W1 of X: last read in ph1).
 // Rules kept (guide 5, "Read a staged buffer one phase AFTER the wait that retires it"; WAR: "restage >= 2 phases after the last
 // ds_read, or 1 phase after when an lgkmcnt before the reading phase's first barrier retired those reads"): every wait sits before
 // the first barrier of its phase and its data is read in a later phase (the lagging half of the workgroup has then waited too);
-// every quarter is re-filled two phases after its last read (DEEP 1's W0: one phase, behind the early lgkmcnt of ph3).
+// every quarter is re-filled two phases after its last read (W0: one phase, behind the early lgkmcnt of ph3).
 // Tile boundaries: the last K-tile of a tile issues nothing in ph2 / ph3 (its stage X is the epilogue's transposition scratch), and
 // the first K-tile of the next tile issues those two quarters on top of its own in ph0 / ph1 -- the in-order vmcnt counts come out
 // the same (8 and 6), plus the epilogue's NST stores in the relaxed first wait.
 template <int MODE, typename OutT, typename T, int DEEP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands (bf16 or IEEE half)");
-  static_assert(DEEP >= 0 && DEEP <= 4, "0 = one quarter in flight, 1 = deep (W0 re-read), 2 = deep (W0 kept in registers), 3 = two 32-MFMA phases per K-tile, 4 = deep, every quarter re-filled two phases after its last read");
+  static_assert(DEEP == 0 || DEEP == 1, "0 = one quarter in flight, 1 = deep (W0 re-read)");
   constexpr int WM = 2, WN = 4, TM = 8, TN = 4, NW = 8, BM = 256, BN = 256;
   if (p.epi.m_dev) {        // the row count lives in device memory (GemmEpi::m_dev): the grid was sized for the host's upper bound
     p.M = *p.epi.m_dev;
@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   }
 
   u32x4 aS[4][2], wS[2][2];     // register subtile: 4 activation x 2 weight fragments x 2 K halves
-  [[maybe_unused]] u32x4 wD[(DEEP == 2 || DEEP == 3) ? 2 : 1][2][2];   // the deep variants' weight fragments (DEEP 2: W0 and W1 apart)
+  [[maybe_unused]] u32x4 wD[1][2][2];   // the deep loop's weight fragments
   bool relax_first = false;     // the previous tile's epilogue issued exactly NST stores last (see the phase-end wait)
   VTC_STAMP_INIT();
   while (true) {
@@ -1231,70 +1231,9 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
           __builtin_amdgcn_s_barrier();
         });
-      } else if constexpr (DEEP == 3) {
-        // ---- TWO phases per K-tile, 32 MFMAs each: half as many hand-overs between the two halves of the workgroup (the phase stamps
-        // put 90-110 cycles on each: profiles/r04_mfma_busy.md).  Phase 0 reads A0, W0, W1 (16 fragment reads) and multiplies the upper
-        // two quadrants; phase 1 reads A1 (8) and multiplies the lower two with the weight fragments still in registers.  Plain double
-        // buffering: K-tile t+1 streams into the other stage while K-tile t is read -- A0, W0, W1 issued in phase 0 (their previous
-        // contents were last read in phase 0 of K-tile t-1: two barriers ago for either half), A1 in phase 1; each waited for one phase
-        // before it is read, before that phase's first barrier (vmcnt(6) in phase 0: A1; vmcnt(2) in phase 1: A0, W0, W1).  The stage
-        // the epilogue transposes through is the one just read: tile boundaries need no special case beyond the relaxed first wait.
-        constexpr int NST = TM * (sizeof(OutT) == 2 ? 2 : 4);
-        const bool first = t == 0;
-        const bool nx1 = t + 1 == ksteps && has_next;
-        const int sm1 = nx1 ? m0n : m0, sn1 = nx1 ? n0n : n0, kk1 = t + 1 < ksteps ? t + 1 : 0;
-        const bool fA1 = ALL_FAST || sm1 + BM <= p.M, fW1 = ALL_FAST || sn1 + BN <= p.N;
-        const char *ta1 = nx1 ? tbAn : tbA, *tw1 = nx1 ? tbWn : tbW;
-        if constexpr (CAN_GATHER) {
-          if (gather && nx1) gather_offsets(m0n);       // every activation quarter from here on is the next tile's
-        }
-        static_for<2>([&](auto ph_c) __attribute__((always_inline)) {
-          constexpr int ph = decltype(ph_c)::value;
-          if constexpr (ph == 0) {
-#pragma unroll
-            for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-              for (int j = 0; j < 2; ++j) {
-                lds_read16(wD[qn][j][0], rw0, (qn * 2 + j) * 16 * ROWB);
-                lds_read16(wD[qn][j][1], rw1, (qn * 2 + j) * 16 * ROWB);
-              }
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            lds_read16(aS[i][0], ra0, (ph * 4 + i) * 16 * ROWB);
-            lds_read16(aS[i][1], ra1, (ph * 4 + i) * 16 * ROWB);
-          }
-          if constexpr (ph == 0) {
-            stage_quarter(0, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
-            stage_quarter(1, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
-            stage_quarter(2, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
-            // A1 of THIS K-tile has landed (first K-tile after an interior epilogue: its NST stores sit between A1 and these)
-            if (first && relax_first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NST) : "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-          } else {
-            stage_quarter(3, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // A0, W0, W1 of K-tile t+1 have landed
-          }
-          __builtin_amdgcn_s_barrier();
-          lgkm_wait_subtile(aS, wD[0]);
-          lgkm_wait_w4(wD[1]);
-          __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) {
-            const int qn = ph == 0 ? qq : 1 - qq;         // quadrant walk (0,0) (0,1) (1,1) (1,0)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) Mma<T>::run(wD[qn][j][ks], aS[i][ks], acc[ph * 4 + i][qn * 2 + j]);
-          }
-          __builtin_amdgcn_s_setprio(0);
-          __builtin_amdgcn_s_barrier();
-        });
       } else {
         // ---- deep pipeline (see the kernel's header comment) ----
-        constexpr int QA = DEEP == 2 ? 2 : 1, QB = DEEP == 2 ? 1 : 2;     // quarter ids: 0 = A0, 1 = W0, 2 = W1, 3 = A1
+        constexpr int QA = 1, QB = 2;                                     // quarter ids: 0 = A0, 1 = W0, 2 = W1, 3 = A1
         constexpr int NST = TM * (sizeof(OutT) == 2 ? 2 : 4);             // 16-byte stores per wave in tile_epilogue's fast paths (its LAST vm ops)
         const bool first = t == 0, last = t == ksteps - 1;                // of this tile (ksteps >= 2: never both)
         // K-tile t+1 (-> st_nxt): of this tile, or K-tile 0 of the next tile (no next tile: K-tile 0 of this one again, into a stage
@@ -1311,9 +1250,9 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
         static_for<4>([&](auto ph_c) __attribute__((always_inline)) {
           constexpr int ph = decltype(ph_c)::value;
           constexpr int qm = ph >> 1, qn = (ph == 1 || ph == 2) ? 1 : 0;
-          constexpr int wreg = DEEP == 2 ? qn : 0;                        // DEEP 2: W0 and W1 live in registers of their own
+          constexpr int wreg = 0;
           // (a) this quadrant's new fragments
-          if constexpr (ph == 0 || ph == 1 || (ph == 3 && (DEEP == 1 || DEEP == 4))) {
+          if constexpr (ph == 0 || ph == 1 || ph == 3) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               lds_read16(wD[wreg][j][0], rw0, (qn * 2 + j) * 16 * ROWB);
@@ -1328,22 +1267,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
             }
           }
           // (b) this phase's quarter(s); (c) the counted waits, BEFORE the phase's first barrier (their data is read in a later phase)
-          if constexpr (ph == 0 && DEEP == 4) {
-            // DEEP 4: the re-fill order follows the order of the last reads (A0 in ph0, W1 in ph1, A1 in ph2, W0 in ph3), each quarter
-            // two phases behind its last read: A0(t+2) in ph2, W1(t+2) in ph3, A1(t+1) in ph0, W0(t+1) in ph1 -- no quarter needs
-            // the early lgkmcnt of DEEP 1's ph3 (a fragment-read round trip inside a memory part), and ONE counted wait per K-tile
-            // (ph3: vmcnt(4) leaves A0, W1 of K-tile t+2 in flight; W0 of K-tile t+1 gets two phases, everything else more).
-            if (first) stage_quarter(0, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);        // A0 of K-tile 1: the previous tile's ph2 did not issue it
-            stage_quarter(3, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
-          } else if constexpr (ph == 1 && DEEP == 4) {
-            if (first) stage_quarter(2, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);        // ... nor W1 in its ph3
-            stage_quarter(1, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
-          } else if constexpr (ph == 3 && DEEP == 4) {
-            if (!last) stage_quarter(2, sm2, sn2, kk2, st_cur, fA2, fW2, ta2, tw2);
-            // A0, W0 (and W1, A1) of K-tile t+1 have landed; last K-tile of a tile: nothing was issued in ph2 / ph3
-            if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          } else if constexpr (ph == 0) {
+          if constexpr (ph == 0) {
             stage_quarter(QA, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);
             if (first) stage_quarter(0, sm1, sn1, kk1, st_nxt, fA1, fW1, ta1, tw1);        // A0 of K-tile 1: the previous tile's ph2 did not issue it
           } else if constexpr (ph == 1) {
@@ -1362,14 +1286,13 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
             }
           } else {
             if (!last) stage_quarter(QB, sm2, sn2, kk2, st_cur, fA2, fW2, ta2, tw2);
-            if constexpr (DEEP == 1) lgkm_wait_w4(wD[0]);                         // W0's second read retired before the barrier: re-filled next phase
+            lgkm_wait_w4(wD[0]);                                                  // W0's second read retired before the barrier: re-filled next phase
             // A0, QA, QB of K-tile t+1 have landed (A1 and this K-tile's two quarters stay in flight)
             if (last) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
           }
           __builtin_amdgcn_s_barrier();
           lgkm_wait_subtile(aS, wD[0]);
-          if constexpr (DEEP == 2) lgkm_wait_w4(wD[1]);
           VTC_PHASE_STAMP(1);
           // (d) the MFMA cluster
           __builtin_amdgcn_s_setprio(1);
@@ -1458,7 +1381,7 @@ int run(GemmParams p, hipStream_t stream) {
   return 0;
 }
 
-int g_deep = VTC_GEMM_DEEP_DEFAULT;   // pipeline depth of the 256 x 256 kernel: 0 = one quarter in flight (rounds 1-3), 1 / 2 = deep (VTC_GEMM_DEEP)
+int g_deep = VTC_GEMM_DEEP_DEFAULT;   // pipeline depth of the 256 x 256 kernel: 0 = one quarter in flight (rounds 1-3), 1 = deep (VTC_GEMM_DEEP)
 
 template <int MODE, typename OutT, typename T, int DEEP>
 int run_phased_d(GemmParams p, hipStream_t stream) {
@@ -1480,16 +1403,7 @@ int run_phased(const GemmParams &p, hipStream_t stream) {
   // round-3 loop (register budgets: EPI_L2MIN with the deep loop spills 18 registers and measures the same, r04_experiments.txt 7)
   if constexpr (MODE != EPI_RESID_LN && MODE != EPI_L2MIN) {
     if (p.K >= 128) {
-      if (g_deep == 1) return run_phased_d<MODE, OutT, T, 1>(p, stream);
-#ifdef VTC_GEMM_DEEP4
-      if (g_deep == 4) return run_phased_d<MODE, OutT, T, 4>(p, stream);
-#endif
-#ifdef VTC_GEMM_DEEP3
-      if (g_deep == 3) return run_phased_d<MODE, OutT, T, 3>(p, stream);
-#endif
-#ifdef VTC_GEMM_DEEP2
-      if (g_deep == 2) return run_phased_d<MODE, OutT, T, 2>(p, stream);
-#endif
+      if (g_deep >= 1) return run_phased_d<MODE, OutT, T, 1>(p, stream);
     }
   }
   return run_phased_d<MODE, OutT, T, 0>(p, stream);

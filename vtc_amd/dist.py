@@ -36,12 +36,6 @@ def init_from_env(backend: Optional[str] = None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal knobs: several ranks on ONE card (VTC_LOCAL_DEVICE=0) over gloo (VTC_DIST_BACKEND=gloo)
-    if "VTC_LOCAL_DEVICE" in os.environ and world > 1:
-        # Ranks that SHARE a card: the one-launch CAM's grid barrier needs its whole grid resident at once, which the occupancy check
-        # of an ordinary launch can only promise against the process's own kernels -- with other processes' kernels on the same CUs
-        # the barrier times out (NaN embeddings + the device-visible error word, vtc_amd/csrc/cam.hip).  The multi-launch CAM has no
-        # such requirement.  (One process per GPU -- the production layout -- is not affected.)
-        os.environ.setdefault("VTC_CAM_FUSED_MAX_ROWS", "0")
     local = int(os.environ.get("VTC_LOCAL_DEVICE", local))
     backend = os.environ.get("VTC_DIST_BACKEND", backend)
     if world > 1 and not dist.is_initialized():
@@ -52,7 +46,40 @@ def init_from_env(backend: Optional[str] = None):
         if torch.cuda.is_available():
             torch.cuda.set_device(local)     # every backend: the rank's tensors and launches live on its own card
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if world > 1 and dist.is_initialized():
+        mark_shared_cards(local)
     return rank, local, world
+
+
+def card_identity(local: int):
+    """(host, card) of the device this rank computes on -- the card by its UUID / PCI bus id, which survives HIP_VISIBLE_DEVICES
+    renumbering and LOCAL_RANK modulo games; a CPU-only rank (gloo tests) is its own card."""
+    import socket
+    host = socket.gethostname()
+    if not torch.cuda.is_available():
+        return (host, f"cpu-{os.getpid()}")
+    pr = torch.cuda.get_device_properties(local)
+    card = str(getattr(pr, "uuid", "")) or ""
+    if not card or set(card) <= set("0-"):
+        card = f"pci-{getattr(pr, 'pci_domain_id', 0)}:{getattr(pr, 'pci_bus_id', local)}:{getattr(pr, 'pci_device_id', 0)}"
+    return (host, card)
+
+
+def mark_shared_cards(local: int, identities=None) -> bool:
+    """ranks that SHARE a card (however they came to: VTC_LOCAL_DEVICE, LOCAL_RANK modulo the device count, a narrowed
+    HIP_VISIBLE_DEVICES) must not take the one-launch CAM -- its software grid barrier needs the whole grid resident at once, which
+    an ordinary launch can only promise against the process's OWN kernels; with another process's kernels on the same CUs the
+    barrier gives up (NaN embeddings, vtc_amd/csrc/cam.hip).  Detected directly: one all_gather of (host, card id) after
+    init_process_group; the result travels as the per-model flag VTC_CAM_NO_FUSED (towers.PackedCam), not as an environment
+    variable a library static may already have read.  One process per GPU -- the production layout -- is not affected."""
+    from . import towers
+    mine = card_identity(local)
+    if identities is None:
+        identities = [None] * dist.get_world_size()
+        dist.all_gather_object(identities, mine)
+    shared = sum(1 for i in identities if tuple(i) == tuple(mine)) > 1
+    towers.set_cam_shared_card(shared)
+    return shared
 
 
 def shard_bounds(n: int, rank: int, world: int):

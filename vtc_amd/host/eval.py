@@ -1,7 +1,7 @@
 """Drop-in for the reference's ``evaluation/eval.py`` entry point (evaluation/eval.py:50-196):
 
     python evaluation/eval.py -c configs/pretrained_clip_comments_attention.jsonc [-r ckpt] [-d 0]
-                              [--bs N] [--bv branch] [--nc n] [--am fusion] [--ac mode]
+                              [--bs N] [--bv branch] [--nc n] [--am fusion] [--ac mode] [--dtype bf16|f32]
 
 Same flags, same result JSON keys (R{1,5,10}_title_from_im / _im_from_title, :131-138), same
 loop semantics (encode every pair, stack, Recall@K both directions).  Differences, all inside the
@@ -73,6 +73,11 @@ def main(config: ConfigParser, args, checkpoint_path=None, device="cuda"):
     if checkpoint_path is None and not module_arch.clip_arch.pretrained_weights_available():
         logging.warning("zero-shot eval WITHOUT pretrained CLIP weights: VTC_CLIP_WEIGHTS is unset, the towers are randomly "
                         "initialised and the recall numbers are meaningless (the reference's clip.load downloads ViT-B/32)")
+    dt = module_arch.parse_compute_dtype(getattr(args, "dtype", None))
+    if dt is not None:
+        model.compute_dtype = dt
+    logging.info(f"operand arithmetic: {model.compute_dtype} (the reference computes in fp32, model/model.py:318; "
+                 "--dtype f32 or VTC_COMPUTE_DTYPE=f32 reproduces it to 1e-5, the 16-bit default to 1e-3)")
     dev = torch.device(device)
     if dev.type == "cuda" and dev.index is not None:
         torch.cuda.set_device(dev)            # launches go to the tensors' device anyway (ops.on_device); this keeps torch's
@@ -91,6 +96,12 @@ def main(config: ConfigParser, args, checkpoint_path=None, device="cuda"):
             res_text.append(out[1])
     res_vis, res_text = torch.cat(res_vis), torch.cat(res_text)
     t_from_i, i_from_t = RecallAtK("images", "titles", [1, 5, 10]).compute_both(res_vis, res_text)
+    from .. import _lib as L
+    if res_vis.is_cuda and L.lib().vtc_cam_fused_gave_up(res_vis.device.index or 0):
+        # compute_both has synchronised: the word speaks for every forward of the loop above
+        if not (torch.isfinite(res_vis).all() and torch.isfinite(res_text).all()):
+            raise RuntimeError("vtc_amd eval: a one-launch CAM gave up at a grid barrier during this run (another process or a "
+                               "collective held the card's CUs) and left NaN embeddings; re-run -- the multi-launch CAM is now selected")
     out = {"R1_title_from_im": t_from_i[0][1], "R5_title_from_im": t_from_i[1][1], "R10_title_from_im": t_from_i[2][1],
            "R1_im_from_title": i_from_t[0][1], "R5_im_from_title": i_from_t[1][1], "R10_im_from_title": i_from_t[2][1]}
     if getattr(dataset, "synthetic", False):
@@ -116,6 +127,8 @@ def cli(argv=None):
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--n_pairs", type=int, default=None, help="synthetic datasets only: number of pairs")
+    ap.add_argument("--dtype", type=str, default=None, choices=["bf16", "f32"],
+                    help="operand arithmetic of the towers (default: VTC_COMPUTE_DTYPE, else bf16; the reference is fp32)")
     args = ap.parse_args(argv)
     mods = {"batch_size": args.bs, "arch;args;branch_to_adapt_val": args.bv, "dataset;args;num_comms": args.nc,
             "arch;args;comment_fusion": args.am, "dataset;args;add_comments": args.ac, "dataset;args;n_pairs": args.n_pairs}

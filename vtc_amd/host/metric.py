@@ -61,7 +61,11 @@ class RecallAtK(BaseMetric):
         self.insert_index += fa.shape[0]
 
     def _dev(self):
-        return self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        """The GPU the search runs on: the features' own device when they are on one, else the current one (the reference's
+        callers hand CPU arrays to compute(), metric.py:126-127,177-180; the search itself has no CPU path)."""
+        if self.device is not None and torch.device(self.device).type == "cuda":
+            return torch.device(self.device)
+        return torch.device("cuda", torch.cuda.current_device())
 
     def _prep(self, features_a, features_b):
         """fp32 [N, D] on the GPU; D zero-padded to the sweep's granule of 64 (squared L2 distances are unchanged;

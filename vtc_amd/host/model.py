@@ -49,14 +49,37 @@ for _reg in ("register_module_parameter_registration_hook", "register_module_buf
              "register_module_module_registration_hook"):
     getattr(torch.nn.modules.module, _reg)(_bump_reg_epoch)
 
+_DTYPE_NAMES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "16": torch.bfloat16,
+                "f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "32": torch.float32}
+
+
+def parse_compute_dtype(name):
+    """"bf16" | "f32" (and spellings) -> torch dtype; None stays None."""
+    if name is None or isinstance(name, torch.dtype):
+        return name
+    try:
+        return _DTYPE_NAMES[str(name).strip().lower()]
+    except KeyError:
+        raise ValueError(f"vtc_amd: unknown compute dtype {name!r}; known: bf16, f32") from None
+
+
+def default_compute_dtype():
+    """The arithmetic of a freshly constructed wrapper: ``VTC_COMPUTE_DTYPE`` (bf16 | f32), else 16-bit operands with fp32
+    accumulation (BASELINE configs[1..2]).  NOTE for drop-in users: the reference computes in fp32 end to end
+    (model/model.py:318 ``self.model.float()``); 16-bit mode reproduces its embeddings to 1e-3, fp32 mode to 1e-5."""
+    return parse_compute_dtype(__import__("os").environ.get("VTC_COMPUTE_DTYPE")) or torch.bfloat16
+
+
 class PretrainedCLIPBase(nn.Module):
-    #: arithmetic of the GEMM/attention operands on the HIP path (fp32 everywhere else)
+    #: arithmetic of the GEMM/attention operands on the HIP path (fp32 everywhere else); per instance from
+    #: default_compute_dtype() at construction, assignable afterwards (a change re-packs the weights)
     compute_dtype = torch.bfloat16
     #: multiply temporal_fc and timeattn.out_proj together at pack time (one GEMM instead of two)
     fuse_temporal = True
     nframes = 8  # model/model.py:488,557
 
     def _common_init(self):
+        self.compute_dtype = default_compute_dtype()
         if getattr(self, "residual_activation", None) in ["sub_mean", "bn"]:
             # model/model.py:134-139: running statistics only (forward is eval-mode here, see _check_eval)
             self.mean_center_bn = nn.BatchNorm1d(self.feature_dim, affine=False, momentum=0.2)

@@ -368,6 +368,17 @@ _ACTS = {None: (L.ACT_NONE, 1.0), "none": (L.ACT_NONE, 1.0), "normalize": (L.ACT
          "sub_mean": (L.ACT_SUB_MEAN, 1.0), "bn": (L.ACT_BN, 1.0)}
 
 
+#: True when another rank of the job computes on this process's card (dist.mark_shared_cards): the one-launch CAM is off for
+#: every CAM forward from then on (VTC_CAM_NO_FUSED in vtc_cam_w.flags -- a per-call model flag, so it also reaches modules
+#: packed before the process group existed)
+_CAM_SHARED_CARD = False
+
+
+def set_cam_shared_card(shared: bool):
+    global _CAM_SHARED_CARD
+    _CAM_SHARED_CARD = bool(shared)
+
+
 class PackedCam:
     def __init__(self, sd: SD, dtype, heads: int, init_from_avg: bool, residual_activation):
         if residual_activation not in _ACTS:
@@ -402,6 +413,8 @@ class PackedCam:
     def forward(self, main: torch.Tensor, comm_feats: torch.Tensor, comments: torch.Tensor) -> torch.Tensor:
         """main [B,D], comm_feats [B*nc,D] fp32, comments [B,nc,ctx] int64 -> adapted [B,D]."""
         w = self.w
+        if _CAM_SHARED_CARD:
+            w.flags |= L.CAM_NO_FUSED
         main, comm_feats = ops._gpu(main, torch.float32, "main"), ops._gpu(comm_feats, torch.float32, "comm_feats")
         comments = ops._gpu(comments, torch.int64, "comments")
         B, nc, ctx = comments.shape

@@ -74,12 +74,9 @@ typedef struct {
 
 /* Per-model path switches (vtc_vision_w.flags / vtc_text_w.flags).  They live in the weight struct -- two models in one
  * process may choose differently, nothing is process-wide -- and never change results beyond the stated tolerance
- * (FUSED_*: bit-identical to the LayerNorm-kernel path when both compute every row of the last block, FULL_LAST_LAYER: the two
- * paths drop different dead rows there -- see below). */
+ * (FULL_LAST_LAYER: see below). */
 enum { VTC_TOWER_NO_LN_FOLD = 1,       /* run the LayerNorm kernels even when the blocks carry folded weights (*_wf)              */
-       VTC_TOWER_FUSED_ATTN = 2,       /* QKV projection + attention core as ONE kernel (vtc_qkv_attention) on contiguous
-                                          sequences (ViT, dense text) and the TimeSformer time branch; implies NO_LN_FOLD   */
-       VTC_TOWER_FUSED_ATTN_SPACE = 4, /* ... and on the TimeSformer space branch                                               */
+       /* 2, 4: retired in ABI 6 (the fused QKV + attention kernel of rounds 1-4 left the product: tools/probes/qkv_attn.hip) */
        VTC_TOWER_FULL_LAST_LAYER = 8   /* By default the LAST block's queries, out_proj and MLP run only on the rows that reach the
                                           output (x[:, 0] behind ln_post, model/timesformer_clip_alt.py:281; the EOT row behind
                                           ln_final): on every other row of that block they are dead -- nothing reads them (its keys
@@ -297,13 +294,6 @@ int vtc_attention(const void *qkv, void *out, float *cls_out, int n_seq, int L, 
  * offs ? offs[o] : o * ctx, query q[o].  out [n_out, W] fp32.  fp32 arithmetic throughout. */
 int vtc_single_query_attention(const void *qkv, const void *q, float *out, int n_out, int L, int heads, int s2, int a0, int a1, int a2,
                                int a3, int pstride, const int *eot, const int *offs, int ctx, int dtype, void *stream);
-
-/* QKV projection + attention core in one kernel (16-bit operand formats only): what vtc_gemm(h, w_qkv, b_qkv) followed by
- * vtc_attention computes, bit for bit, without the packed qkv matrix in HBM.  h: LayerNorm output [rows, W]; w_qkv
- * in_proj_weight [3W, W]; out [rows, W] (operand format; same row map as vtc_attention); rows = row count of h / out.
- * Replaces model/timesformer_clip_alt.py:50-58 (in_proj, scaling, attn) per attention branch. */
-int vtc_qkv_attention(const void *h, const void *w_qkv, const float *b_qkv, void *out, float *cls_out, int n_seq, int L, int heads,
-                      int causal, int s2, int a0, int a1, int a2, int a3, int pstride, long long rows, int dtype, void *stream);
 
 /* ---- adapter-only training step: backward + optimizer primitives, fp32 -------------------
  * Replace, for PretrainedCLIP_finaltf with frozen towers (configs/pretrained_clip_comments_attn_frozen.jsonc), what

@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     declared -= {"vtc_block_w", "vtc_vision_w", "vtc_text_w", "vtc_cam_w"}
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     lib = L.lib()                       # raises if the .so or any symbol is missing
-    assert lib.vtc_abi_version() == L.ABI_VERSION == 5
+    assert lib.vtc_abi_version() == L.ABI_VERSION == 6
     for name in declared:
         assert hasattr(lib, name)
 
@@ -52,7 +52,8 @@ def test_no_process_wide_switches_in_the_abi():
     from vtc_amd import towers
     lib = L.lib()
     assert not any(hasattr(lib, n) for n in ("vtc_set_ln_fold", "vtc_set_fused_attention"))
-    assert towers.tower_flags() == 0 and towers.tower_flags(ln_fold=False, fused_attn=3) == 7
+    assert not hasattr(lib, "vtc_qkv_attention")          # ABI 6: the fused QKV + attention kernel left the product (tools/probes/)
+    assert towers.tower_flags() == 0 and towers.tower_flags(ln_fold=False, full_last_layer=True) == 9
 
 
 def test_argument_errors_are_reported_not_thrown():
@@ -263,7 +264,7 @@ def test_build_refuses_probe_macros():
     src = open(os.path.join(ROOT, "vtc_amd", "csrc", "gemm.hip")).read()
     assert "#error" in src and "VTC_PROBE_MFMA32" in src.split("#error")[0][-800:]       # named only in the guard
     for probe in ("VTC_ABLATE_STORES", "VTC_PROBE_MFMA32", "VTC_ABLATE_DMA", "VTC_GEMM_EXP", "VTC_QKVA_SKIP"):
-        for f in ("gemm.hip", "gemm_common.h", "qkv_attn.hip"):
+        for f in ("gemm.hip", "gemm_common.h"):
             body = open(os.path.join(ROOT, "vtc_amd", "csrc", f)).read()
             uses = [ln for ln in body.splitlines() if probe in ln and "defined(" not in ln and not ln.lstrip().startswith("//")]
             assert not uses, (f, probe, uses[:2])

@@ -55,7 +55,7 @@ def test_uint8_frames_at_full_size_through_the_patch_gather():
     alt = unit(towers.PackedVision(cuda_sd, "v.", torch.bfloat16).forward(x.bfloat16().cuda()).cpu().numpy())
     assert np.abs(alt - got16).max() < 5e-4
     sdi = A.synth_visual(a, 172, prefix="v.")
-    img = torch.randint(0, 256, (37, 3, 224, 224), dtype=torch.uint8, generator=g)
+    img = torch.randint(0, 256, (13, 3, 224, 224), dtype=torch.uint8, generator=g)
     refi = unit(CR.encode_image((img.float() / 255.0 - MEAN) / STD, sdi, a, "v.").numpy())
     goti = unit(towers.PackedVision({k: v.cuda() for k, v in sdi.items()}, "v.", torch.bfloat16).forward(img.cuda()).cpu().numpy())
     assert np.abs(goti - refi).max() < 1e-3

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("seed", [0, 7])
+@pytest.mark.parametrize("seed", [0, pytest.param(7, marks=pytest.mark.extended)])
 def test_wrappers_odd_shapes_vs_oracle(seed):
     import fuzz_wrappers
     worst = fuzz_wrappers.run_cases(16, seed=seed, verbose=False)

@@ -403,53 +403,6 @@ def test_entry_points_from_two_threads_and_two_streams():
             assert torch.equal(o, wv)
 
 
-# ---- QKV projection + attention core in one kernel (qkv_attn.hip) ---------------------------------------------------
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("heads", [2, 8, 12])
-def test_fused_qkv_attention_equals_gemm_plus_attention(dtype, heads):
-    """vtc_qkv_attention == vtc_attention(vtc_gemm(h, W_in, b_in)) BIT FOR BIT (both round q, k, v to the operand format
-    before the core), for every row map of the towers: contiguous sequences (ViT L=50, text L=77 causal, CAM L=6, odd
-    lengths), the time map (F = 8, 16) and the space map (cls replicated per frame, cls outputs to cls_out); sequence
-    counts that do not fill the last tile; W = 128 (two K-steps) .. 768."""
-    L, ops = _ops()
-    W = heads * 64
-    g = torch.Generator().manual_seed(heads)
-    wq = (torch.randn(3 * W, W, generator=g) * W ** -0.5).cuda().to(dtype)
-    bq = torch.randn(3 * W, generator=g).cuda()
-
-    def both(h, n_seq, L_, **kw):
-        cls_a = cls_b = None
-        if kw.pop("with_cls", False):
-            cls_a, cls_b = torch.zeros(n_seq, W, device="cuda"), torch.zeros(n_seq, W, device="cuda")
-        qkv = ops.gemm(h, wq, bq)
-        want = ops.attention(qkv, n_seq, L_, heads, cls_out=cls_a, **kw)
-        got = ops.qkv_attention(h, wq, bq, n_seq, L_, heads, cls_out=cls_b, **kw)
-        return got, want, cls_b, cls_a
-
-    # contiguous sequences
-    for L_, n_seq, causal in ((50, 13, False), (77, 7, True), (6, 70, False), (8, 33, False), (16, 17, False), (1, 40, False),
-                              (23, 12, True), (80, 4, True), (64, 9, False)):
-        h = torch.randn(n_seq * L_, W, generator=g).cuda().to(dtype)
-        got, want, _, _ = both(h, n_seq, L_, causal=causal)
-        assert torch.equal(got, want), (L_, n_seq, causal, float((got.float() - want.float()).abs().max()))
-    # time / space maps of model/timesformer_clip_alt.py:271-275 (row b*T = cls, row b*T + 1 + n*F + t)
-    for F, B, P in ((8, 3, 49), (16, 2, 49), (4, 5, 4), (8, 2, 9)):
-        T = 1 + P * F
-        h = torch.randn(B * T, W, generator=g).cuda().to(dtype)
-        got, want, _, _ = both(h, B * P, F, s2=P, a0=1, a1=T, a2=F, a3=0, pstride=1)
-        assert torch.equal(got.reshape(B, T, W)[:, 1:], want.reshape(B, T, W)[:, 1:]), ("time", F)
-        assert got.reshape(B, T, W)[:, 0].abs().max() == 0            # cls rows are not part of any time sequence
-        got, want, cg, cw = both(h, B * F, 1 + P, s2=F, a0=0, a1=T, a2=0, a3=1, pstride=F, with_cls=True)
-        assert torch.equal(got.reshape(B, T, W)[:, 1:], want.reshape(B, T, W)[:, 1:]), ("space", F)
-        assert torch.equal(cg, cw), ("space cls", F)
-    # many tiles per workgroup (persistent walk, next-tile prefetch under the attention phase): 300 groups x heads tiles
-    F, B, P = 8, 200, 49
-    T = 1 + P * F
-    h = torch.randn(B * T, W, generator=g).cuda().to(dtype)
-    got, want, _, _ = both(h, B * P, F, s2=P, a0=1, a1=T, a2=F, a3=0, pstride=1)
-    assert torch.equal(got.reshape(B, T, W)[:, 1:], want.reshape(B, T, W)[:, 1:])
-
-
 # ---- residual GEMM + the following LayerNorm in one launch (EPI_RESID_LN) ------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,skip", [(100608, 768, 768, 393), (100608, 768, 3072, 0), (118272, 512, 512, 0), (56789, 512, 2048, 0),

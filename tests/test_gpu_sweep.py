@@ -154,8 +154,17 @@ def test_l2_topk_exact_mode_dense_near_ties_take_the_fp64_brute_force():
     assert np.array_equal(ids.cpu().numpy(), E.l2_topk(small, q, 11, np.float64)[0])
 
 
-@pytest.mark.parametrize("na,nb,d", [(300, 300, 64), (1000, 777, 512), (4099, 4099, 512), (40, 3000, 128), (3000, 40, 128)])
-@pytest.mark.parametrize("prec", ["exact", "f32", "bf16x3"])
+def _bidir_cases():
+    out = []
+    for prec in ("exact", "f32", "bf16x3"):
+        for na, nb, d in ((300, 300, 64), (1000, 777, 512), (4099, 4099, 512), (40, 3000, 128), (3000, 40, 128)):
+            # the approximate modes' 4099-row case spends 13 s each in the fp64 oracle's gap scan: extended
+            marks = [pytest.mark.extended] if (na == 4099 and prec != "exact") else []
+            out.append(pytest.param(na, nb, d, prec, marks=marks, id=f"{prec}-{na}-{nb}-{d}"))
+    return out
+
+
+@pytest.mark.parametrize("na,nb,d,prec", _bidir_cases())
 def test_l2_topk_bidir_equals_two_searches(na, nb, d, prec):
     """vtc_l2_topk_bidir reads the second direction off the columns of the first direction's distance blocks: it
     must return what two vtc_l2_topk calls return (EXACT: the fp64 ids on every row of both directions)."""
@@ -217,7 +226,7 @@ def test_recall_compute_both_matches_two_computes_and_oracle():
     assert two[0] == E.recall_at_k(a, b, [1, 5, 10]) and two[1] == E.recall_at_k(b, a, [1, 5, 10])
 
 
-@pytest.mark.parametrize("prec", ["exact", "f32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["exact", pytest.param("f32", marks=pytest.mark.extended), pytest.param("bf16x3", marks=pytest.mark.extended)])
 def test_stress_size_50k_bidir_equals_two_searches_and_oracle_sample(prec):
     """BASELINE configs[4]: the 50k x 50k sweep (D = 512, depth 11).  At this size the distance matrix is walked in
     five 2 GiB row blocks, the column lists are carried from block to block and merged over segments -- none of which

@@ -1,3 +1,7 @@
+// PROBE (not part of libvtc_hip.so since round 5, ABI 6): kept with its measurements in profiles/r05_experiments.txt 1.
+// Builds against vtc_amd/csrc (gemm_common.h); the towers.hip / ops.py hooks that called it are in the history (commit cbaba74 + the
+// round-5 FOLD variant below).  Measured at 1 024 videos, time branch, per layer: this kernel 1.74 ms stand-alone / 1.95 ms inside the
+// tower (2.09 ms with the folded LayerNorm) against 1.20 ms (folded QKV GEMM) + 0.49 ms (attention core) -- slower.
 // qkv_attn.hip -- QKV projection + attention core in ONE kernel:  out = softmax(q k^T / 8 [+ causal]) v,  [q|k|v] = h W_in^T + b
 //
 // Replaces, for the 16-bit operand modes, the pair {QKV GEMM -> packed qkv [rows, 3W] in HBM -> attention kernel} behind
@@ -37,13 +41,17 @@ constexpr int Q_OFF = STAGE, K_OFF = Q_OFF + BM * 128, V_OFF = K_OFF + BM * 128;
 constexpr int VS = 292;                        // V^T row stride in elements: 146 dwords = 18 mod 64 -> 16 d-rows hit 16 distinct bank pairs
 constexpr int B_OFF = V_OFF + 64 * VS * 2;     // the tile's 192 bias values (q | k | v slices of in_proj_bias), fp32
 constexpr int T_OFF = B_OFF + BN * 4;          // per-row tables (tile-invariant): V^T slot and (sequence, token) of dense local row r
-constexpr int LDS_BYTES = T_OFF + BM * 4;      // 162048 <= 163840
+constexpr int S_OFF = T_OFF + BM * 4;          // folded LayerNorm: the tile's 192 values of s (row sums of the gamma-scaled weights), fp32
+constexpr int LDS_BYTES = S_OFF + BN * 4;      // 162816 <= 163840
 static_assert(LDS_BYTES <= 163840, "one workgroup owns the CU's LDS");
 
 struct QkvAttnParams {
   const char *A;        // LayerNorm output h [rows, W], operand format
   const char *Wq;       // in_proj_weight [3W, W], operand format
-  const float *bias;    // in_proj_bias [3W]
+  const float *bias;    // in_proj_bias [3W]  (folded LayerNorm: c = bias + W beta)
+  // Folded LayerNorm (gemm.hip EPI_STORE_FOLD, towers.hip ln_proj): A = the residual stream's `hi` plane, Wq = the gamma-scaled
+  // weights, and q|k|v = rstd_m (acc - mean_m s_n) + c_n with (mean, rstd) = fold_stat[2 row], s = fold_s[3W].  NULL: plain bias.
+  const float *fold_stat, *fold_s;
   char *out;            // attention output [rows, W], operand format, same row map as the input
   float *cls_out;       // space branch: token 0's output goes here, [n_seq, W] fp32 (else nullptr)
   int n_seq, L, heads, causal;
@@ -74,7 +82,8 @@ __device__ __forceinline__ void wg_barrier_lds() {
 
 // NT = 16-key tiles per sequence (L <= 16 NT)
 // U = attention units a wave keeps in flight
-template <typename T, int NT, int U>
+// FOLD = the folded-LayerNorm transform in the accumulator -> LDS pass (QkvAttnParams::fold_stat)
+template <typename T, int NT, int U, bool FOLD>
 __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -152,6 +161,15 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   };
   float bias_next = bias_of(start_x + li);
   if (tid < BN) reinterpret_cast<float *>(lds + B_OFF)[tid] = bias_next;
+  auto fs_of = [&](int tile) -> float {
+    const int head = tile % p.heads, n = min(tid, BN - 1);
+    return FOLD ? p.fold_s[(n >> 6) * W + head * 64 + (n & 63)] : 0.f;
+  };
+  [[maybe_unused]] float fs_next = 0.f;
+  if constexpr (FOLD) {
+    fs_next = fs_of(start_x + li);
+    if (tid < BN) reinterpret_cast<float *>(lds + S_OFF)[tid] = fs_next;
+  }
   bool first = true;
 
   while (true) {
@@ -168,7 +186,20 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     first = false;
     wg_barrier_lds();
-    if (has_next) bias_next = bias_of(tile + nb_x);    // consumed after the accumulator -> LDS pass (one register across the K loop)
+    if (has_next) {                                    // consumed after the accumulator -> LDS pass (one register each across the K loop)
+      bias_next = bias_of(tile + nb_x);
+      if constexpr (FOLD) fs_next = fs_of(tile + nb_x);
+    }
+    // folded LayerNorm: (mean, rstd) of dense local row tid, requested here (the K loop's vmcnt(0) waits retire it) and held in TWO
+    // registers across the K loop; behind the K loop the rows' statistics meet in stage 0, which is free until the next tile's
+    // first slab is issued (holding the lane's own four rows cost 8 registers and sent 32 to scratch)
+    [[maybe_unused]] float2 fst_row = make_float2(0.f, 1.f);
+    if constexpr (FOLD) {
+      if (tid < BM) {
+        const unsigned st = tab_st[min(tid, r_used - 1)];
+        fst_row = *reinterpret_cast<const float2 *>(p.fold_stat + 2 * (size_t)row_of(seq0 + (int)(st >> 8), (int)(st & 255)));
+      }
+    }
 
     // ================= GEMM phase: acc[m][n] = sum_k H[row(m)][k] Wh[n][k] =================
     f32x4 acc[TM][TN];
@@ -222,31 +253,52 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
         for (int i = tid & 7; i < nseq - 1; i += 8)
           for (int c = L; c < Lp; ++c) vt[(tid >> 3) * VS + i * Lp + c] = 0;
       }
-      // bias of the lane's output columns: n = wc*96 + 16j + 4g .. +3, segment n / 64 (q, k, v), d = n % 64
-      float4 b4[TN];
+      // bias (folded LayerNorm: c, and s) of the lane's output columns: n = wc*96 + 16j + 4g .. +3, segment n / 64 (q, k, v), d = n % 64.
+      // Column block j outermost: its four (eight) column constants live in registers only while the TM row fragments pass
+      // (all TN blocks' constants at once cost 24 + 24 registers next to the 96 accumulators: spills in the folded form).
+      [[maybe_unused]] float2 fst[TM];
+      if constexpr (FOLD) {
+        float2 *stat_lds = reinterpret_cast<float2 *>(lds);          // stage 0: nobody reads it any more, nothing streams into it yet
+        if (tid < BM) stat_lds[tid] = fst_row;
+        wg_barrier_lds();
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4 *>(lds + B_OFF + (wc * 96 + 16 * j + 4 * g) * 4);
+        for (int i = 0; i < TM; ++i) fst[i] = stat_lds[wr * 64 + 16 * i + c16];
+      }
+      int vslot[TM];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int m = wr * 64 + 16 * i + c16;            // dense local token index
-        if (m < r_used) {
-          const int vslot = tab_slot[m];
-          const unsigned rowb = m * 128, rs = (m >> 1) & 7;
+      for (int i = 0; i < TM; ++i) vslot[i] = tab_slot[min(wr * 64 + 16 * i + c16, BM - 1)];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int n = wc * 96 + 16 * j + 4 * g;      // (n >> 6) is wave-uniform per j: 0 = q, 1 = k, 2 = v
-            const int seg = n >> 6, d = n & 63;
-            const float v0 = acc[i][j][0] + b4[j].x, v1 = acc[i][j][1] + b4[j].y, v2 = acc[i][j][2] + b4[j].z, v3 = acc[i][j][3] + b4[j].w;
+      for (int j = 0; j < TN; ++j) {
+        const int n = wc * 96 + 16 * j + 4 * g;      // (n >> 6) is wave-uniform per j: 0 = q, 1 = k, 2 = v
+        const int seg = n >> 6, d = n & 63;
+        const float4 b4 = *reinterpret_cast<const float4 *>(lds + B_OFF + n * 4);
+        [[maybe_unused]] float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (FOLD) s4 = *reinterpret_cast<const float4 *>(lds + S_OFF + n * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int m = wr * 64 + 16 * i + c16;            // dense local token index
+          if (m < r_used) {
+            float v0, v1, v2, v3;
+            if constexpr (FOLD) {       // the two roundings per value of gemm.hip's folded epilogue: fma(rstd, fma(-mean, s, acc), c)
+              const float nmu = -fst[i].x, rs = fst[i].y;
+              v0 = __builtin_fmaf(rs, __builtin_fmaf(nmu, s4.x, acc[i][j][0]), b4.x);
+              v1 = __builtin_fmaf(rs, __builtin_fmaf(nmu, s4.y, acc[i][j][1]), b4.y);
+              v2 = __builtin_fmaf(rs, __builtin_fmaf(nmu, s4.z, acc[i][j][2]), b4.z);
+              v3 = __builtin_fmaf(rs, __builtin_fmaf(nmu, s4.w, acc[i][j][3]), b4.w);
+            } else {
+              v0 = acc[i][j][0] + b4.x; v1 = acc[i][j][1] + b4.y; v2 = acc[i][j][2] + b4.z; v3 = acc[i][j][3] + b4.w;
+            }
             const unsigned short h0 = cvt16<T>(v0), h1 = cvt16<T>(v1), h2 = cvt16<T>(v2), h3 = cvt16<T>(v3);
             if (seg < 2) {
+              const unsigned rowb = m * 128, rs_ = (m >> 1) & 7;
               uint2 pk;
               pk.x = (unsigned)h0 | ((unsigned)h1 << 16);
               pk.y = (unsigned)h2 | ((unsigned)h3 << 16);
-              const unsigned off = (seg ? K_OFF : Q_OFF) + rowb + ((((unsigned)d >> 3) ^ rs) << 4) + ((d & 7) << 1);
+              const unsigned off = (seg ? K_OFF : Q_OFF) + rowb + ((((unsigned)d >> 3) ^ rs_) << 4) + ((d & 7) << 1);
               *reinterpret_cast<uint2 *>(lds + off) = pk;
             } else {
-              vt[(d + 0) * VS + vslot] = h0; vt[(d + 1) * VS + vslot] = h1;
-              vt[(d + 2) * VS + vslot] = h2; vt[(d + 3) * VS + vslot] = h3;
+              vt[(d + 0) * VS + vslot[i]] = h0; vt[(d + 1) * VS + vslot[i]] = h1;
+              vt[(d + 2) * VS + vslot[i]] = h2; vt[(d + 3) * VS + vslot[i]] = h3;
             }
           }
         }
@@ -256,7 +308,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
 
     // the next tile's bias slice and first K-slab stream in under the attention phase (stage 0 and the bias slot are free)
     if (has_next) {
-      if (tid < BN) reinterpret_cast<float *>(lds + B_OFF)[tid] = bias_next;
+      if (tid < BN) {
+        reinterpret_cast<float *>(lds + B_OFF)[tid] = bias_next;
+        if constexpr (FOLD) reinterpret_cast<float *>(lds + S_OFF)[tid] = fs_next;
+      }
       tile_offsets_of(tile + nb_x, a_off, w_off);
       stage_slab(a_off, w_off, 0, lds_base);
     }
@@ -427,12 +482,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(const QkvAttnParams p)
   }
 }
 
-template <typename T, int NT, int U>
+template <typename T, int NT, int U, bool FOLD = false>
 int run(const QkvAttnParams &p, hipStream_t stream) {
   static PerDeviceOnce attr;
-  if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&qkv_attn_kernel<T, NT, U>), LDS_BYTES, "qkv_attention")) return 1;
+  if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&qkv_attn_kernel<T, NT, U, FOLD>), LDS_BYTES, "qkv_attention")) return 1;
   const int tiles = p.n_groups * p.heads;
-  hipLaunchKernelGGL((qkv_attn_kernel<T, NT, U>), dim3(min(tiles, num_cus())), dim3(512), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((qkv_attn_kernel<T, NT, U, FOLD>), dim3(min(tiles, num_cus())), dim3(512), LDS_BYTES, stream, p);
   VTC_LAUNCH_CHECK("qkv_attention");
   return 0;
 }
@@ -442,6 +497,11 @@ int dispatch(const QkvAttnParams &p, hipStream_t stream) {
   static const int force_u = [] { const char *e = getenv("VTC_QKVA_U"); return e ? atoi(e) : 0; }();   // diagnostics
   const int nt = cdiv(p.L, 16);
   const bool two = force_u ? force_u == 2 : nt <= 2;     // short sequences: two independent chains per wave pay
+  if (p.fold_stat) {        // folded LayerNorm: the TimeSformer time branch (L = frames <= 16)
+    if (nt == 1) return two ? run<T, 1, 2, true>(p, stream) : run<T, 1, 1, true>(p, stream);
+    vtc_set_error("qkv_attention: the folded-LayerNorm form covers sequences of at most 16 tokens (L=%d)", p.L);
+    return 1;
+  }
   switch (nt) {
     case 1: return two ? run<T, 1, 2>(p, stream) : run<T, 1, 1>(p, stream);
     case 2: return two ? run<T, 2, 2>(p, stream) : run<T, 2, 1>(p, stream);
@@ -462,13 +522,16 @@ bool qkv_attention_supported(int L, int heads, int W, int dtype, size_t rows) {
 }
 
 int launch_qkv_attention(const void *h, const void *w_qkv, const float *b_qkv, void *out, float *cls_out, int n_seq, int L, int heads,
-                         int causal, int s2, int a0, int a1, int a2, int a3, int pstride, size_t rows, int dtype, hipStream_t stream) {
+                         int causal, int s2, int a0, int a1, int a2, int a3, int pstride, size_t rows, int dtype, hipStream_t stream,
+                         const float *fold_stat, const float *fold_s) {
   VTC_CHECK(n_seq > 0 && L > 0 && heads > 0 && s2 > 0, "qkv_attention: bad sizes n_seq=%d L=%d heads=%d s2=%d", n_seq, L, heads, s2);
   VTC_CHECK(qkv_attention_supported(L, heads, heads * 64, dtype, rows), "qkv_attention: unsupported problem (L=%d heads=%d dtype=%d)", L, heads, dtype);
   VTC_CHECK(!cls_out || L >= 2, "qkv_attention: cls_out needs sequences of at least two tokens");
   VTC_CHECK(((uintptr_t)h & 15) == 0 && ((uintptr_t)w_qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "qkv_attention: operands must be 16-byte aligned");
   QkvAttnParams p;
   p.A = (const char *)h; p.Wq = (const char *)w_qkv; p.bias = b_qkv; p.out = (char *)out; p.cls_out = cls_out;
+  VTC_CHECK((fold_stat == nullptr) == (fold_s == nullptr), "qkv_attention: folded LayerNorm needs both the row statistics and s");
+  p.fold_stat = fold_stat; p.fold_s = fold_s;
   p.n_seq = n_seq; p.L = L; p.heads = heads; p.causal = causal;
   p.s2 = s2; p.a0 = a0; p.a1 = a1; p.a2 = a2; p.a3 = a3; p.pstride = pstride;
   p.W = heads * 64;
@@ -483,5 +546,5 @@ extern "C" int vtc_qkv_attention(const void *h, const void *w_qkv, const float *
                                  int heads, int causal, int s2, int a0, int a1, int a2, int a3, int pstride, long long rows, int dtype,
                                  void *stream) {
   return launch_qkv_attention(h, w_qkv, b_qkv, out, cls_out, n_seq, L, heads, causal, s2, a0, a1, a2, a3, pstride, (size_t)rows, dtype,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, nullptr, nullptr);
 }

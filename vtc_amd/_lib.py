@@ -21,9 +21,9 @@ PROF_CLASSES = ("gemm_bf16", "gemm_f32", "attention", "norm", "embed", "topk")
 PROF_REGIONS = ("other", "attn", "mlp")
 VTC_F16 = 3
 # vtc_vision_w.flags / vtc_text_w.flags (include/vtc_hip.h VTC_TOWER_*): per-model path switches
-TOWER_NO_LN_FOLD, TOWER_FUSED_ATTN, TOWER_FUSED_ATTN_SPACE, TOWER_FULL_LAST_LAYER = 1, 2, 4, 8
+TOWER_NO_LN_FOLD, TOWER_FULL_LAST_LAYER = 1, 8
 CAM_NO_FUSED = 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
 
@@ -107,8 +107,6 @@ SIGNATURES = {
     "vtc_debug_launch_count": (C.c_longlong, []),
     "vtc_attention": (C.c_int, [vp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, vp]),
-    "vtc_qkv_attention": (C.c_int, [vp, vp, fp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                    C.c_int, C.c_int, C.c_longlong, C.c_int, vp]),
     # adapter-only training step (backward + optimizer primitives)
     "vtc_transpose_f32": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),
     "vtc_colsum_f32": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),

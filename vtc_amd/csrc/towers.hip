@@ -31,7 +31,7 @@ void vtc_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 extern "C" const char *vtc_last_error(void) { return g_err; }
-extern "C" int vtc_abi_version(void) { return 5; }
+extern "C" int vtc_abi_version(void) { return 6; }
 int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res, const float *mean, const float *stdv, hipStream_t stream);
 int patch_k_padded(int patch);
 int launch_pixels_u8_to_operand(const void *px, void *out, int dtype, int n_frames, int res, const float *mean, const float *stdv, hipStream_t stream);
@@ -50,19 +50,11 @@ bool cam_fused_supported(const vtc_cam_w *w, int B, int nc, int dtype);
 size_t cam_fused_bar_bytes();
 int launch_cam_fused(const vtc_cam_w *w, const float *main_feats, const float *comm_feats, const int64_t *comments, int ctx, int B, int nc,
                      float *adapted, float *x, float *big, float *att, int *bar, hipStream_t stream);
-bool qkv_attention_supported(int L, int heads, int W, int dtype, size_t rows);
-int launch_qkv_attention(const void *h, const void *w_qkv, const float *b_qkv, void *out, float *cls_out, int n_seq, int L, int heads,
-                         int causal, int s2, int a0, int a1, int a2, int a3, int pstride, size_t rows, int dtype, hipStream_t stream);
-
 namespace {
 
-// QKV projection + attention core in one kernel (qkv_attn.hip) instead of {QKV GEMM -> packed qkv in HBM -> attention
-// kernel}: vtc_vision_w.flags / vtc_text_w.flags, VTC_TOWER_FUSED_ATTN (contiguous sequences + the time branch) and
-// VTC_TOWER_FUSED_ATTN_SPACE.  Bit-identical results.  Off unless the model asks: measured on MI355X the fused kernel's GEMM
-// phase runs at 0.99 PFLOP/s but its QKV -> LDS, attention and store phases are serial per tile (28 % of its time with the
-// matrix pipe idle), while the stand-alone attention kernel streams its packed qkv at 4.8-5.1 TB/s -- the two-kernel path wins
-// by 1-4 % per step.  (Rounds 1-2 kept these choices in process-wide switches; they are per model now.)
-inline bool fused_attn_enabled(int flags) { return (flags & VTC_TOWER_FUSED_ATTN) != 0; }
+// (Rounds 1-4 carried a fused QKV projection + attention-core kernel behind per-model flags; it measured slower than GEMM + core in
+// every configuration -- in round 5 also with the folded LayerNorm kept, on the time branch alone: 2.09 ms against 1.20 + 0.49 per
+// layer at 1 024 videos, profiles/r05_experiments.txt 1 -- and left the product: tools/probes/qkv_attn.hip.)
 
 struct Bump {
   char *base;
@@ -96,7 +88,7 @@ int gemm(const void *A, const void *W, const float *bias, void *out, int M, int 
 // projection reads xb against gamma-scaled weights and applies mean / rstd in its epilogue.  The LayerNorm kernels' 1.2 GB
 // read + 0.6 GB write per launch (config 3, 1 024 videos) become a 0.6 GB write in the residual epilogue.  Needs every tile
 // interior: rows padded to 256 (the pad rows hold garbage that no kernel outside the GEMMs reads), W a multiple of 256.
-// flags & VTC_TOWER_NO_LN_FOLD (or any fused-attention flag): the LayerNorm kernels.
+// flags & VTC_TOWER_NO_LN_FOLD: the LayerNorm kernels.
 struct Fold {
   bool on = false;
   void *xb = nullptr;       // [rows_pad, W] operand format: the residual stream as the projections read it (hi of the pair)
@@ -114,7 +106,7 @@ int fold_merge_rows(Fold &f, float *x, int n, int W, const int *row_index, int r
 }
 inline int pad256(int rows) { return (rows + 255) / 256 * 256; }
 bool fold_usable(const vtc_block_w *blocks, int layers, int W, int dtype, bool timesformer, int flags) {
-  if ((flags & (VTC_TOWER_NO_LN_FOLD | VTC_TOWER_FUSED_ATTN | VTC_TOWER_FUSED_ATTN_SPACE)) || dtype == VTC_F32 || W % 256 != 0) return false;
+  if ((flags & VTC_TOWER_NO_LN_FOLD) || dtype == VTC_F32 || W % 256 != 0) return false;
   for (int l = 0; l < layers; ++l)
     if (!blocks[l].qkv_wf || !blocks[l].fc_wf || (timesformer && !blocks[l].tqkv_wf)) return false;
   return true;
@@ -130,6 +122,16 @@ struct Rows {
   Rows(int n_, const int *dev_) : n(n_), dev(dev_) {}
   const int *dev_pad() const { return dev ? dev + 1 : nullptr; }
 };
+
+// the stream as the pair (xb, xl) + row statistics in operand format `dtype` (no residual GEMM of this format in front: layer 0, or
+// a format boundary -- back through fp32)
+int fold_enter(Fold &f, const float *x, const Rows &rows, int W, int dtype, hipStream_t s) {
+  if (f.fmt == dtype) return 0;
+  if (f.fmt >= 0) RUN(launch_split_merge_rows(f.xb, f.xl, const_cast<float *>(x), rows.n, W, nullptr, 1, f.fmt, s, rows.dev));
+  RUN(launch_cast_rowstats(x, f.xb, f.xl, f.stat, rows.n, W, dtype, s, rows.dev));
+  f.fmt = dtype;
+  return 0;
+}
 
 // out = epi(LN(x; g, bt) w^T + bias)
 // (col0, ncols: only the output columns [col0, col0 + ncols) -- rows col0.. of the weight -- are computed, at their places in the
@@ -149,11 +151,7 @@ int ln_proj(Fold &f, const float *x, const float *g, const float *bt, const void
     N = ncols;
   }
   if (f.on) {
-    if (f.fmt != dtype) {       // no residual GEMM of this format in front: layer 0, or a format boundary (back through fp32)
-      if (f.fmt >= 0) RUN(launch_split_merge_rows(f.xb, f.xl, const_cast<float *>(x), rows.n, W, nullptr, 1, f.fmt, s, rows.dev));
-      RUN(launch_cast_rowstats(x, f.xb, f.xl, f.stat, rows.n, W, dtype, s, rows.dev));
-      f.fmt = dtype;
-    }
+    RUN(fold_enter(f, x, rows, W, dtype, s));
     GemmEpi e;
     e.mode = mode; e.out_dtype = dtype; e.fold_stat = f.stat; e.fold_s = fs; e.m_dev = rows.dev_pad(); e.ldo = ldo;
     return launch_gemm(f.xb, wf, fc, out, f.rows_pad, N, W, dtype, e, s);
@@ -202,13 +200,6 @@ int attn_part_contig(Fold &f, const vtc_block_w &b, float *x, void *h, void *big
                      int dtype, int flags, hipStream_t s, const void **tail_src = nullptr) {
   const int rows = n_seq * L;
   ProfRegion region(VTC_PROF_REGION_ATTN);
-  if (!f.on && fused_attn_enabled(flags) && qkv_attention_supported(L, heads, W, dtype, (size_t)rows)) {
-    RUN(launch_layernorm(x, b.ln1_g, b.ln1_b, h, rows, W, dtype, nullptr, 1, false, s));
-    RUN(launch_qkv_attention(h, b.qkv_w, b.qkv_b, big, nullptr, n_seq, L, heads, causal, 1, 0, L, 0, 0, 1, (size_t)rows, dtype, s));
-    if (tail_src) { *tail_src = big; return 0; }
-    RUN(gemm(big, b.out_w, b.out_b, x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
-    return 0;
-  }
   RUN(ln_proj(f, x, b.ln1_g, b.ln1_b, b.qkv_w, b.qkv_b, b.qkv_wf, b.qkv_s, b.qkv_c, h, big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));
   if (W != heads * 64) {      // the CAM with head_dim != 64 (ViT-L/14's 768-d features at the reference's default n_heads = 8)
     VTC_CHECK(!causal && W % heads == 0, "attention: head_dim %d/%d", W, heads);
@@ -244,10 +235,10 @@ void plan_tail(Bump &b, Tail &t, int n, int W) {      // sized for fp32 operands
   t.sq = (float *)b.take((size_t)n * W * 4);
 }
 inline bool prune_last(int flags) { return (flags & VTC_TOWER_FULL_LAST_LAYER) == 0; }
-// ... and on the two-kernel attention path the last block's QUERIES are per-row maps too: only the output rows' queries are
+// ... and the last block's QUERIES are per-row maps too: only the output rows' queries are
 // projected (tail_query: LayerNorm kernel + the Q third of in_proj on n rows), the all-rows projection computes the K and V thirds
 // only (ln_proj's column window) and the attention core runs one query per sequence (attention.hip, sq_attn_kernel).
-inline bool prune_last_queries(int flags) { return prune_last(flags) && (flags & (VTC_TOWER_FUSED_ATTN | VTC_TOWER_FUSED_ATTN_SPACE)) == 0; }
+inline bool prune_last_queries(int flags) { return prune_last(flags); }
 // the n output rows of the stream -> t.x (fp32, compact); their queries ln_1(x) Wq^T + bq -> t.big [n, W] (operand format)
 int tail_query(Fold &f, const vtc_block_w &b, float *x, Tail &t, int n, int W, const int *row_index, int row_mul, int dtype, hipStream_t s) {
   RUN(fold_merge_rows(f, x, n, W, row_index, row_mul, s));
@@ -428,29 +419,6 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
       RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, P, 1, dtype, s));
       RUN(launch_cls_global_attention(v.big, v.h, n_items, T, w->heads, dtype, s));
       if (!tail) RUN(resid_proj(fold, v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, 0, s));
-    } else if (tsf && fused_attn_enabled(w->flags) && qkv_attention_supported(1 + P, w->heads, W, dtype, (size_t)rows)) {
-      // Same two branches with QKV + attention core in one kernel each (qkv_attn.hip): the attention output lands in
-      // `big` (as [rows, W]); the packed qkv matrix never exists.
-      RUN(launch_layernorm(v.x, b.lnt_g, b.lnt_b, v.h, rows, W, dtype, nullptr, 1, false, s));
-      RUN(launch_qkv_attention(v.h, b.tqkv_w, b.tqkv_b, v.big, nullptr, n_items * P, F, w->heads, 0, P, 1, T, F, 0, 1, (size_t)rows, dtype, s));
-      if (b.tout_w) {
-        RUN(gemm(v.big, b.tout_w, b.tout_b, v.h, rows, W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
-        RUN(gemm(v.h, b.tfc_w, b.tfc_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, T, s));
-      } else {
-        RUN(gemm(v.big, b.tfc_w, b.tfc_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, T, s));
-      }
-      RUN(launch_layernorm(v.x, b.ln1_g, b.ln1_b, v.h, rows, W, dtype, nullptr, 1, false, s));
-      if (w->flags & VTC_TOWER_FUSED_ATTN_SPACE) {
-        RUN(launch_qkv_attention(v.h, b.qkv_w, b.qkv_b, v.big, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, 1, F, (size_t)rows, dtype, s));
-        RUN(launch_cls_mean(v.cls_tmp, v.big, dtype, n_items, F, T, W, s));
-        tail_src = v.big;
-        if (!tail) RUN(gemm(v.big, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
-      } else {
-        RUN(gemm(v.h, b.qkv_w, b.qkv_b, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, dtype, 0, s));
-        RUN(launch_attention(v.big, v.h, v.cls_tmp, n_items * F, 1 + P, w->heads, 0, F, 0, T, 0, 1, F, dtype, s));
-        RUN(launch_cls_mean(v.cls_tmp, v.h, dtype, n_items, F, T, W, s));
-        if (!tail) RUN(gemm(v.h, b.out_w, b.out_b, v.x, rows, W, W, dtype, VTC_EPI_RESID, VTC_F32, 0, s));
-      }
     } else if (tsf) {
       // temporal branch (timesformer_clip_alt.py:142-149): sequences = the F frames of one (item, patch)
       RUN(ln_proj(fold, v.x, b.lnt_g, b.lnt_b, b.tqkv_w, b.tqkv_b, b.tqkv_wf, b.tqkv_s, b.tqkv_c, v.h, v.big, rows, 3 * W, W, dtype, VTC_EPI_STORE, s));

@@ -154,25 +154,6 @@ def single_query_attention(qkv: torch.Tensor, q: torch.Tensor, n_out: int, L_: i
     return out
 
 
-@on_device
-def qkv_attention(h: torch.Tensor, w_qkv: torch.Tensor, b_qkv: torch.Tensor, n_seq: int, L_: int, heads: int, causal: bool = False,
-                  s2: int = 1, a0: int = 0, a1: Optional[int] = None, a2: int = 0, a3: int = 0, pstride: int = 1,
-                  cls_out: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """attention(gemm(h, w_qkv, b_qkv)) in one kernel (bf16 / f16 operands); same row map as ``attention``."""
-    h, w_qkv = _gpu(h, name="h"), _gpu(w_qkv, h.dtype, "w_qkv")
-    b_qkv = _gpu(b_qkv, torch.float32, "b_qkv")
-    rows, W = h.shape
-    assert W == heads * 64 and w_qkv.shape == (3 * W, W)
-    if a1 is None:
-        a1 = L_
-    if out is None:
-        out = torch.zeros(rows, W, dtype=h.dtype, device=h.device)
-    L.check(L.lib().vtc_qkv_attention(h.data_ptr(), w_qkv.data_ptr(), b_qkv.data_ptr(), out.data_ptr(),
-                                      cls_out.data_ptr() if cls_out is not None else None, n_seq, L_, heads, int(causal), s2, a0,
-                                      a1, a2, a3, pstride, rows, _TDT[h.dtype], _stream()), "vtc_qkv_attention")
-    return out
-
-
 # ---- wrapper-level fp32 ops ---------------------------------------------------------------
 @on_device
 def normalize_rows(x: torch.Tensor) -> torch.Tensor:

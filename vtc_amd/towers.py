@@ -42,19 +42,15 @@ TEXT_HALF_LAYERS = int(__import__("os").environ.get("VTC_TEXT_HALF_LAYERS", "12"
 LN_FOLD_PACK = __import__("os").environ.get("VTC_LN_FOLD_PACK", "1") != "0"
 
 
-def tower_flags(ln_fold: bool = True, fused_attn: int = 0, full_last_layer: bool = False) -> int:
-    """vtc_vision_w.flags / vtc_text_w.flags: ln_fold False = the LayerNorm kernels; fused_attn bit 0 = QKV + attention core
-    in one kernel on contiguous sequences and the time branch, bit 1 = on the space branch (both bit-identical to the
-    LayerNorm-kernel path, measured slower: DESIGN.md 4.2); full_last_layer = compute the last block's out_proj / MLP on every
-    row instead of the output rows only (the rows nothing reads; same embeddings)."""
-    return ((0 if ln_fold else L.TOWER_NO_LN_FOLD) | (L.TOWER_FUSED_ATTN if fused_attn & 1 else 0)
-            | (L.TOWER_FUSED_ATTN_SPACE if fused_attn & 2 else 0) | (L.TOWER_FULL_LAST_LAYER if full_last_layer else 0))
+def tower_flags(ln_fold: bool = True, full_last_layer: bool = False) -> int:
+    """vtc_vision_w.flags / vtc_text_w.flags: ln_fold False = the LayerNorm kernels instead of the folded LayerNorms;
+    full_last_layer = compute the last block's out_proj / MLP on every row instead of the output rows only (the rows nothing
+    reads; same embeddings).  (The fused QKV + attention flags of rounds 1-4 are gone with the kernel: ABI 6.)"""
+    return (0 if ln_fold else L.TOWER_NO_LN_FOLD) | (L.TOWER_FULL_LAST_LAYER if full_last_layer else 0)
 
 
-# defaults of newly packed towers (env VTC_LN_FOLD=0 / VTC_FUSED_ATTN=mask / VTC_FULL_LAST_LAYER=1: A/B runs); a packed tower's
-# `w.flags` may be set per model
+# defaults of newly packed towers (env VTC_LN_FOLD=0 / VTC_FULL_LAST_LAYER=1: A/B runs); a packed tower's `w.flags` may be set per model
 DEFAULT_FLAGS = tower_flags(__import__("os").environ.get("VTC_LN_FOLD", "1") != "0",
-                            int(__import__("os").environ.get("VTC_FUSED_ATTN", "0")),
                             __import__("os").environ.get("VTC_FULL_LAST_LAYER", "0") == "1")
 _WS: Dict[tuple, torch.Tensor] = {}
 

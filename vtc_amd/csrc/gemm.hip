@@ -163,6 +163,8 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
   const int cblk = nbase >> 6;
   // (the row loop exists twice: interior waves -- all of them but the last row / column of tiles -- run it without the two selects
   //  and the validity bit per value that edge waves need: ~350 of ~3 750 vector instructions per wave and tile)
+  // (`cols_too` stays a RUN-TIME test inside the pass -- a not-taken scalar branch per value: made a compile-time choice (per tile, or
+  //  per fragment row) the pass becomes straight-line code and hipcc spills 68-380 registers; round 5, profiles/r05_experiments.txt 3)
   auto row_pass = [&](int i, auto interior_c, Min4 &row) __attribute__((always_inline)) {
     constexpr bool INTERIOR = decltype(interior_c)::value;
     const int m = mbase + 16 * i + l15;
@@ -206,39 +208,48 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
     }
   }
   if (cols_too) {
-    // a column's TM * 16 rows of this wave sit in the 16 lanes of its DPP row: butterfly (quad xor 1, xor 2, then the
-    // mirrors -- after two steps a quad is uniform, after three a half row, so a mirror pairs the right lanes)
+    // A column's TM * 16 rows of this wave sit in the 16 lanes (l15) of its DPP row, and the lane holds 16 such columns (slot c = 4 j + e).
+    // TRANSPOSE-REDUCE (round 5): at every step a lane keeps HALF of its slots, sends the other half to its partner and merges what
+    // it receives -- 8 + 4 + 2 + 1 = 15 merges per lane and one finished column per lane at the end, where the all-reduce butterfly of
+    // round 4 (every lane merging every slot at every step) did 64: ~520 of the ~3 400 vector instructions per wave and tile.
+    // Step partners: l15 ^ 1, ^ 2 (quad_perm), ^ 8 (row_ror:8), ^ 4 (row_shl:4 / row_shr:4 under bank masks); the lane's final slot is
+    // c = 8 b0 + 4 b1 + 2 b3 + b2 (b_k = bit k of l15).
     const size_t cstride = (size_t)p.epi.nblk_r * p.N;
     const int rblk = mbase / (TM * 16);
+#define VTC_DPPU(x, ctrl) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, 0xf, 0xf, false)
+    auto xor4 = [](unsigned x) -> unsigned {       // the value of lane l15 ^ 4: banks 0, 2 read four lanes up, banks 1, 3 four lanes down
+      int r = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0x5, false);          // row_shl:4
+      r = __builtin_amdgcn_update_dpp(r, (int)x, 0x114, 0xf, 0xA, false);              // row_shr:4
+      return (unsigned)r;
+    };
+    // one step on a pair of slots: `up` lanes keep `hi` and send `lo`, the others keep `lo` and send `hi`
+    auto step = [&](const Min4 &lo, const Min4 &hi, bool up, auto fetch) __attribute__((always_inline)) -> Min4 {
+      Min4 k;
+      k.a = up ? hi.a : lo.a; k.b = up ? hi.b : lo.b; k.c = up ? hi.c : lo.c; k.d = up ? hi.d : lo.d;
+      const unsigned sa = up ? lo.a : hi.a, sb = up ? lo.b : hi.b, sc = up ? lo.c : hi.c, sd = up ? lo.d : hi.d;
+      k.merge(fetch(sa), fetch(sb), fetch(sc), fetch(sd));
+      return k;
+    };
+    const bool b0 = (l15 & 1) != 0, b1 = (l15 & 2) != 0, b2 = (l15 & 4) != 0, b3 = (l15 & 8) != 0;
+    Min4 s8[8], s4[4], s2[2];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+    for (int c = 0; c < 8; ++c)
+      s8[c] = step(col[c >> 2][c & 3], col[(c + 8) >> 2][c & 3], b0, [](unsigned x) { return VTC_DPPU(x, 0xB1); });     // quad_perm [1,0,3,2]
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Min4 &c = col[j][e];
-#define VTC_DPPF(x, ctrl) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, 0xf, 0xf, false)
-#define VTC_STEP(ctrl) { const unsigned oa = VTC_DPPF(c.a, ctrl), ob = VTC_DPPF(c.b, ctrl), oc = VTC_DPPF(c.c, ctrl), od = VTC_DPPF(c.d, ctrl); c.merge(oa, ob, oc, od); }
-        VTC_STEP(0xB1)     // quad_perm [1,0,3,2]
-        VTC_STEP(0x4E)     // quad_perm [2,3,0,1]
-        VTC_STEP(0x141)    // row_half_mirror
-        VTC_STEP(0x140)    // row_mirror
-#undef VTC_STEP
-#undef VTC_DPPF
-      }
-      // lanes l15 = 0..3 store plane l15 of their four consecutive columns
-      const int n = nbase + 16 * j + 4 * g;
-      if (l15 < 4 && n < p.N && mbase < p.M) {
-        unsigned *dst = p.epi.colk + (size_t)l15 * cstride + (size_t)rblk * p.N + n;
-        auto pick = [&](const Min4 &q) { return l15 == 0 ? q.a : (l15 == 1 ? q.b : (l15 == 2 ? q.c : q.d)); };
-        const unsigned v0 = pick(col[j][0]), v1 = pick(col[j][1]), v2 = pick(col[j][2]), v3 = pick(col[j][3]);
-        if (n + 3 < p.N && (p.N & 3) == 0) {
-          *reinterpret_cast<uint4 *>(dst) = make_uint4(v0, v1, v2, v3);
-        } else {
-          dst[0] = v0;
-          if (n + 1 < p.N) dst[1] = v1;
-          if (n + 2 < p.N) dst[2] = v2;
-          if (n + 3 < p.N) dst[3] = v3;
-        }
-      }
+    for (int c = 0; c < 4; ++c) s4[c] = step(s8[c], s8[c + 4], b1, [](unsigned x) { return VTC_DPPU(x, 0x4E); });         // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int c = 0; c < 2; ++c) s2[c] = step(s4[c], s4[c + 2], b3, [](unsigned x) { return VTC_DPPU(x, 0x128); });        // row_ror:8
+    const Min4 fin = step(s2[0], s2[1], b2, xor4);
+#undef VTC_DPPU
+    const int cj = (b0 ? 2 : 0) + (b1 ? 1 : 0), ce = (b3 ? 2 : 0) + (b2 ? 1 : 0);
+    const int n = nbase + 16 * cj + 4 * g + ce;
+    // every lane stores the four planes of its own column: a wave covers its 64 columns, 256 contiguous bytes per plane
+    if (n < p.N && mbase < p.M) {
+      unsigned *dst = p.epi.colk + (size_t)rblk * p.N + n;
+      dst[0] = fin.a;
+      dst[cstride] = fin.b;
+      dst[2 * cstride] = fin.c;
+      dst[3 * cstride] = fin.d;
     }
   }
 }

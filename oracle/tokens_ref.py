@@ -1,7 +1,9 @@
 """TEST INFRASTRUCTURE (never imported by the product path): the array-building half of the reference's `_tokenise`
 (dataset_loaders/dataset_loaders.py:224-248) restated in plain Python.  The BPE encoder (`clip.simple_tokenizer`, un-vendored) and
 the RAKE keyword summariser in front of it (`rake_nltk`, absent here) are host text processing and out of scope: this takes the
-encoder's output -- one list of ids per text -- and builds the [n, max_len] int64 array the text tower reads."""
+encoder's output -- one list of ids per text -- and builds the [n, max_len] int64 array the text tower reads.
+PINNED (round 5): tests/golden/tokenise_cases.npz = outputs of the reference's own `_tokenise`, run unmodified under stand-in BPE / RAKE
+objects by tests/golden/make_tokenise_golden.py; tests/test_token_packing.py holds this file and vtc_pack_tokens to them."""
 import numpy as np
 
 SOT, EOT = 49406, 49407

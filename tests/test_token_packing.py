@@ -1,11 +1,43 @@
 """Token packing: the array-building half of the reference's `_tokenise`
-(dataset_loaders/dataset_loaders.py:224-248).  CPU: the oracle restatement against hand-written known answers of that code's
-rules; GPU: vtc_pack_tokens (through the C ABI) against the oracle on ragged batches, empty / exactly-full / over-long texts."""
+(dataset_loaders/dataset_loaders.py:224-248).  CPU: the oracle restatement against the outputs of the reference's OWN `_tokenise`
+(tests/golden/tokenise_cases.npz, made by tests/golden/make_tokenise_golden.py) and against hand-written known answers of that code's
+rules; GPU: vtc_pack_tokens (through the C ABI) against the same fixture and against the oracle on ragged batches, empty /
+exactly-full / over-long texts."""
+import json
+import os
 import numpy as np
 import pytest
 import torch
 
 from oracle import tokens_ref as TR
+
+
+def _tokenise_cases():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tokenise_cases.npz"), allow_pickle=False)
+    for key, c in json.loads(str(z["case"])).items():
+        eo, so = z[key + ".enc_off"], z[key + ".sum_off"]
+        enc = [z[key + ".enc"][eo[i]:eo[i + 1]].tolist() for i in range(c["n"])]
+        summ = [z[key + ".sum"][so[i]:so[i + 1]].tolist() for i in range(c["n"])]
+        yield key, c["max_len"], enc, summ, z[key + ".out"]
+
+
+def test_oracle_equals_the_references_own_tokenise():
+    """The fixture holds what the reference's `_tokenise` (run unmodified, stand-in BPE / RAKE) returned: SOT / EOT framing, the
+    `len(tokens) >= max_len` test, the re-encoded summary, the hard cut `tokens[:max_len - 1] + [eot]`, zero padding, a bare string."""
+    n = 0
+    for key, max_len, enc, summ, want in _tokenise_cases():
+        got = TR.pack_tokens(enc, max_len=max_len, summarise=lambda i: summ[i])
+        assert got.dtype == np.int64 and np.array_equal(got, want), key
+        n += 1
+    assert n >= 10
+
+
+@pytest.mark.gpu
+def test_pack_tokens_kernel_equals_the_references_own_tokenise():
+    from vtc_amd.host import datasets as DS
+    for key, max_len, enc, summ, want in _tokenise_cases():
+        got = DS.pack_token_lists(enc, max_len=max_len, device="cuda", summarise=lambda i: summ[i])
+        assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), want), key
 
 
 def test_oracle_packing_rules():

@@ -681,11 +681,12 @@ def main():
     attn_launches = sum(v["attn"]["launches"] for v in pv.values())
     attn_flop = TSF_ATTN_GFLOP_PER_LAYER_VIDEO * 1e9 * 12 * B
     attn_frac = attn_flop / (attn_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12) if attn_ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic("config3")
+    traffic, traffic_src = pmc_traffic("config3" if args.dtype == "bf16" else "config3_f32")
     n_tok = int((torch.cat([title, comments.reshape(-1, 77)]).argmax(-1) + 1).sum().item())
     roofline = dict(bound="mfma", achieved=round(achieved, 1), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
                     traffic=traffic, traffic_source=traffic_src,
-                    kernel="16-bit-operand MFMA GEMMs of the step (gemm_phased_kernel / gemm_kernel), all epilogues",
+                    kernel=("16-bit-operand MFMA GEMMs of the step (gemm_phased_kernel / gemm_kernel), all epilogues" if args.dtype == "bf16"
+                            else "fp32 MFMA GEMMs of the step (gemm_kernel<float, ...>: v_mfma_f32_16x16x4_f32), all epilogues"),
                     launches_per_step=g["launches"] // n_prof, avg_launch_us=round(1e3 * g["ms"] / max(1, g["launches"]), 2),
                     flop_per_launch=round(g["work"] / max(1, g["launches"]) / 1e9, 3),
                     dominant_instantiation=dominant_gemm(recs, gk, n_prof, peak))

@@ -1,7 +1,6 @@
 """usage: python tools/summarize_sweep.py <rocprofv3 --kernel-trace --stats dir of tools/sweep_profile.py> N sweeps <out.md>
-Per-kernel table of the EXACT one-matrix sweep (vtc_l2_topk_bidir, block-minima path) + R@K counting, and the two fractions:
-the CONVENTION of BASELINE.md (2 x 8 N^2 algorithmic matrix bytes / time / 8 TB/s) and what actually binds -- the distance GEMM
-with its VALU epilogue against the dense bf16 MFMA peak."""
+Per-kernel table of the EXACT one-matrix sweep (vtc_l2_topk_bidir, block-minima path) + R@K counting, and what binds it: the distance
+GEMM with its VALU epilogue against the dense bf16 MFMA peak (GEMM alone, and the whole sweep)."""
 import csv, glob, os, re, sys
 d, N, sweeps, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 rows = list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)[0])))
@@ -31,8 +30,8 @@ g = gemm_ns / 1e9 / sweeps
 lines += ["", f"* distance GEMM (`EPI_L2MIN`: 2 N^2 512 = {flop / 1e12:.3f} TFLOP, never writes the matrix): {g * 1e3:.3f} ms = "
           f"**{flop / g / 1e12:.0f} TFLOP/s = {flop / g / 2.5e15:.3f} of the 2.5 PFLOP/s dense bf16 peak** -- the binding resource "
           "(bound: mfma + valu: K = 512 is 8 K-tiles per 256 x 256 tile, then ~3 k VALU per wave for the block minima)",
-          f"* convention of BASELINE.md / bench.py `sweep_N_hbm_frac`: 2 x 8 N^2 = {16.0 * N * N / 1e9:.2f} GB of algorithmic matrix traffic / "
-          f"{tot / 1e6 / sweeps:.3f} ms = {16.0 * N * N / (tot / 1e9 / sweeps) / 1e12:.2f} TB/s = {16.0 * N * N / (tot / 1e9 / sweeps) / 8e12:.3f} of 8 TB/s "
-          "(kernel time only; bench.py's figure includes launch gaps and the D2H of the counters) -- the bytes actually moved are the key planes, ~3 % of that"]
+          f"* whole sweep: {flop / 1e12:.3f} TFLOP / {tot / 1e6 / sweeps:.3f} ms of kernels = {flop / (tot / 1e9 / sweeps) / 1e12:.0f} TFLOP/s = "
+          f"{flop / (tot / 1e9 / sweeps) / 2.5e15:.3f} of the bf16 MFMA peak.  (Rounds 1-4 also printed 2 x 8 N^2 bytes / time / 8 TB/s here -- the "
+          "bytes of a materialised fp32 matrix, which this sweep never writes; the counter-measured bytes are in profiles/r05_sweep_traffic.md.)"]
 open(out, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

@@ -42,7 +42,7 @@ def test_uint8_frames_at_full_size_through_the_patch_gather():
     for k in list(sdv):
         if k.endswith("temporal_fc.weight"):
             sdv[k] = torch.randn(sdv[k].shape, generator=g) * 0.02
-    u8 = torch.randint(0, 256, (3, 8, 3, 224, 224), dtype=torch.uint8, generator=g)
+    u8 = torch.randint(0, 256, (2, 8, 3, 224, 224), dtype=torch.uint8, generator=g)
     x = (u8.float() / 255.0 - MEAN[None]) / STD[None]
     ref = unit(T.timesformer_alt(x, sdv, a, "v.").numpy())
     cuda_sd = {k: v.cuda() for k, v in sdv.items()}

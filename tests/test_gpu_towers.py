@@ -424,6 +424,7 @@ def test_patch_gather_equals_im2row_path():
             report("patch gather vs im2row, small batch", np.abs(unit(got.cpu().numpy()) - unit(ref.cpu().numpy())).max(), 1e-3)
 
 
+@pytest.mark.extended      # (default run: test_last_block_on_the_output_rows_only_... holds both switch positions of the same four towers to the oracle)
 def test_folded_layernorm_and_layernorm_kernels_agree_with_the_oracle():
     """16-bit modes fold each LayerNorm into the projection behind it (include/vtc_hip.h vtc_block_w *_wf/_s/_c;
     LN(x) W^T + b = rstd (x (g.W)^T - mean s) + c; model/timesformer_clip_alt.py:142-175 ln_time / ln_1 / ln_2).  Both

@@ -1359,6 +1359,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   }
 }
 
+
 }  // namespace
 namespace vtcgemm {
 // CU count of the CURRENT device (cached per device: grids are sized for the card the launch goes to)
@@ -1454,6 +1455,9 @@ int run_cfg(const GemmParams &p, hipStream_t stream) {
 // sweep epilogue: 0 = phased 256 x 256 tiles (row blocks of 128), 1 = 128 x 128 tiles, two workgroups per CU (row blocks of 64)
 int l2min_row_block(int variant) { return variant == 0 ? 128 : 64; }
 int run_l2min(const GemmParams &p, hipStream_t stream) {
+  // (round 5: a third form -- two 4-wave workgroups per CU on 128 x 256 tiles, K = 32 slabs, so that one's epilogue runs under the
+  //  other's K loop -- was built, passes the sweep tests and measures 5.2 ms against 4.6 at 50k: tools/probes/gemm_l2min2.hip,
+  //  profiles/r05_experiments.txt 3)
   if (p.epi.rb == 128) return run_phased<EPI_L2MIN, float, bf16_t>(p, stream);
   return run<bf16_t, EPI_L2MIN, float, 2, 2, 4, 4, 2>(p, stream);
 }

@@ -119,7 +119,7 @@ def test_full_size_properties_10k(prec):
         assert np.array_equal(idn[rows], i64)
 
 
-@pytest.mark.parametrize("n,d", [(300, 64), (1000, 512), (4099, 512)])
+@pytest.mark.parametrize("n,d", [(300, 64), (1000, 512), (4099, 512), (1500, 768)])      # 768: ViT-L/14's embedding width
 def test_l2_topk_exact_mode_has_fp64_ranks(n, d):
     """VTC_SWEEP_EXACT: BF16X3 candidate lists re-ranked in fp64 -> the ids are those of exact fp64 arithmetic on
     EVERY row (no near-tie exemption), the distances are the fp64 distances rounded to fp32."""
@@ -418,3 +418,22 @@ def test_sharded_recall_world_1_equals_recallatk_compute_both(n):
     assert r_ab == dict(E.recall_at_k(a, b, [1, 5, 10], np.float64)) and r_ba == dict(E.recall_at_k(b, a, [1, 5, 10], np.float64))
     assert ph["path"].startswith("one distance matrix" if n >= vdist.BIDIR_MIN_ROWS else "two searches")
     assert vdist.BIDIR_MIN_ROWS == m.bidir_min_rows and vdist.BIDIR_MIN_ROWS_F32 == m.bidir_min_rows_f32
+
+
+def test_exact_sweep_with_rows_whose_components_underflow_when_squared():
+    """the EXACT certificate uses the rows' MEASURED bf16 rounding errors |x - bf16(x)|, accumulated as squares in fp32; a
+    row whose components sit below ~1e-19 squares to flushed zeros, so its measured error (and norm) would read 0.  The prep kernel adds
+    d x FLT_MIN under its roots; whatever the certificate then decides, the ids must still be the fp64 ones -- for tiny rows among
+    ordinary ones, tiny queries, and an all-tiny problem (every key underflows: the fp64 brute force takes over)."""
+    from vtc_amd import _lib as L
+    from vtc_amd import ops
+    rng = np.random.default_rng(21)
+    a = unit(rng.standard_normal((600, 64))).astype(np.float32)
+    b = unit(a + 0.3 * unit(rng.standard_normal((600, 64)))).astype(np.float32)
+    a[100:180] *= np.float32(1e-18)
+    b[50:90] *= np.float32(3e-19)
+    for ga, qb in ((a, b), (b, a), ((a * np.float32(1e-17)).astype(np.float32), (b * np.float32(1e-17)).astype(np.float32))):
+        ids, _ = ops.l2_topk(torch.from_numpy(ga).cuda(), torch.from_numpy(qb).cuda(), 11, precision=L.SWEEP_EXACT)
+        assert np.array_equal(ids.cpu().numpy(), E.l2_topk(ga, qb, 11, np.float64)[0])
+    i1, _, i2, _ = ops.l2_topk_bidir(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 11, precision=L.SWEEP_EXACT)
+    assert np.array_equal(i1.cpu().numpy(), E.l2_topk(a, b, 11, np.float64)[0]) and np.array_equal(i2.cpu().numpy(), E.l2_topk(b, a, 11, np.float64)[0])

@@ -79,6 +79,13 @@ __device__ __forceinline__ void store16(void *o, float4 v) {
   store16<NT>(o, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
 }
 
+// The number of 16-byte stores a wave issues LAST in tile_epilogue's interior fast paths (bf16 / f16 outputs: TM x 2, fp32 outputs:
+// TM x 4, one per (fragment row, k) of the pass loops -- the static_asserts inside the paths hold them to it): gemm_phased_kernel's
+// relaxed first-K-tile waits leave exactly this many vector-memory operations in flight (one definition, not a restated
+// constant).  A fast path that issued FEWER trailing stores would make those waits under-wait and race the LDS-DMA.
+template <typename OutT, int TM>
+constexpr int fast_epilogue_trailing_stores() { return TM * (sizeof(OutT) == 2 ? 2 : 4); }
+
 // ---- epilogue (shared by both kernels).  CONTRACT with gemm_phased_kernel's relaxed first-K-tile waits: on an interior
 // tile a wave issues AT LEAST TM * 2 (bf16 out) or TM * 4 (fp32 out) vector-memory operations here (its 16-byte stores;
 // the residual mode's x loads come on top), so the NST youngest operations before the next tile's first LDS-DMA piece
@@ -389,6 +396,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
         }
       };
       static_assert(2 * 16 * TSB <= SCRATCH_PER_WAVE, "two transposition buffers per wave");
+      static_assert(fast_epilogue_trailing_stores<OutT, TM>() == TM * 2, "16-bit fast path: TM fragment rows x 2 stores (the loop below)");
       char *out_base16;
       {
         const int m0s = __builtin_amdgcn_readfirstlane(m0), wrs = __builtin_amdgcn_readfirstlane(wr), ncs = __builtin_amdgcn_readfirstlane(ncol0);
@@ -441,6 +449,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
     // 128 x 512 row-panel tiles), pass pp = (fragment row i, half hh)
     constexpr int H = TN / 4, NP = TM * H;
     static_assert(TN % 4 == 0 && (H == 1 || sizeof(OutT) == 4), "wide wave tiles: fp32 outputs only");
+    static_assert(sizeof(OutT) == 2 || fast_epilogue_trailing_stores<OutT, TM>() <= NP * 4, "fp32 fast path: NP passes x 4 stores (>= the count the K loop's relaxed waits assume)");
     float *tr = reinterpret_cast<float *>(lds + scratch_off + wave * SCRATCH_PER_WAVE);
     const int l15 = lane & 15;
     const int ncol0 = n0 + wc * TN * 16;
@@ -1234,7 +1243,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
           // slack in the steady-state schedule: issued in phase 0, read after the barrier that ends phase 3, which the
           // lagging half reaches with its waits up to phase 2 done), so phases 0 and 1 leave the stores -- and the
           // quarters issued since -- in flight and only make sure of everything OLDER than the stores.
-          constexpr int NST = TM * (sizeof(OutT) == 2 ? 2 : 4);   // 16-byte stores per wave in tile_epilogue's fast paths (its LAST vm ops)
+          constexpr int NST = fast_epilogue_trailing_stores<OutT, TM>();   // 16-byte stores per wave in tile_epilogue's fast paths (its LAST vm ops)
           if (ph < 2 && t == 0 && relax_first) {
             if constexpr (ph == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NST) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");
@@ -1245,7 +1254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
       } else {
         // ---- deep pipeline (see the kernel's header comment) ----
         constexpr int QA = 1, QB = 2;                                     // quarter ids: 0 = A0, 1 = W0, 2 = W1, 3 = A1
-        constexpr int NST = TM * (sizeof(OutT) == 2 ? 2 : 4);             // 16-byte stores per wave in tile_epilogue's fast paths (its LAST vm ops)
+        constexpr int NST = fast_epilogue_trailing_stores<OutT, TM>();             // 16-byte stores per wave in tile_epilogue's fast paths (its LAST vm ops)
         const bool first = t == 0, last = t == ksteps - 1;                // of this tile (ksteps >= 2: never both)
         // K-tile t+1 (-> st_nxt): of this tile, or K-tile 0 of the next tile (no next tile: K-tile 0 of this one again, into a stage
         // nobody reads any more -- the counted waits stay uniform)

@@ -103,7 +103,9 @@ __global__ __launch_bounds__(256) void sweep_prep_kernel(PrepSide A, PrepSide B,
       if (S.xb) *reinterpret_cast<uint2 *>(S.xb + (size_t)r * d + c) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
     }
     n2 = wave_sum(n2); nt2 = wave_sum(nt2); e2 = wave_sum(e2);
-    const float nt = sqrtf(nt2) * 1.0001f, e = sqrtf(e2) * 1.0001f;
+    // (+ d x FLT_MIN under the roots: a component below ~1e-19 squares to a flushed zero, and up to d such terms may be missing from
+    //  either sum -- ADVICE r4; on unit-norm rows the addend is 6e-36 beside 1e-6 .. 1 and changes no bit)
+    const float nt = sqrtf(nt2 + (float)d * 1.1754944e-38f) * 1.0001f, e = sqrtf(e2 + (float)d * 1.1754944e-38f) * 1.0001f;
     if (lane == 0) {
       S.n2[r] = n2;
       S.st[r] = make_float2(nt, e);

@@ -127,6 +127,7 @@ def sweep_path(n_total: int, precision: int, world: int, depth: int = 11) -> str
     return "one distance matrix, row + column top-k" if one else "two searches per rank ([N/G, N] blocks)"
 
 
+_A2A_SEND: dict = {}      # exchange_column_planes' padded send buffer / pinned host staging buffers, by shape
 A2A_MODE = os.environ.get("VTC_A2A", "single")     # "single": one all_to_all_single on a padded [G, 4, nblk, max shard] buffer; "list": all_to_all on per-rank slices
 
 
@@ -139,6 +140,9 @@ def exchange_column_planes(planes: torch.Tensor, n_total: int, rank: int, world:
     lo, hi = bounds[rank]
     mx = max(b - a for a, b in bounds)
     P, NB = planes.shape[0], planes.shape[1]
+    if planes.dim() != 3 or planes.shape[2] != n_total or not planes.is_contiguous():
+        raise ValueError(f"exchange_column_planes: planes must be a contiguous [4, nblk_pad, n_total = {n_total}] tensor, got "
+                         f"{tuple(planes.shape)} (contiguous: {planes.is_contiguous()})")
     nccl = dist.get_backend() == "nccl"
     if A2A_MODE == "list" and nccl:
         send = [planes[:, :, a:b].contiguous() for a, b in bounds]
@@ -148,15 +152,29 @@ def exchange_column_planes(planes: torch.Tensor, n_total: int, rank: int, world:
     if all(b - a == mx for a, b in bounds):
         send = planes.reshape(P, NB, world, mx).permute(2, 0, 1, 3).contiguous()
     else:
-        send = planes.new_zeros(world, P, NB, mx)
+        # ragged shards: a padded send buffer, kept per (shape, dtype, device) -- the padding columns are sliced off on receipt, so
+        # they need no zeroing and the buffer no re-allocation per call
+        key = (world, P, NB, mx, planes.dtype, planes.device)
+        send = _A2A_SEND.get(key)
+        if send is None:
+            _A2A_SEND.clear()
+            send = _A2A_SEND[key] = planes.new_zeros(world, P, NB, mx)
         for r, (a, b) in enumerate(bounds):
             send[r, :, :, : b - a].copy_(planes[:, :, a:b])
     if nccl:
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send)
     else:
-        host = send.cpu()
-        got = torch.empty_like(host)
+        # gloo (tests, one-card rehearsals): staged through host memory -- pinned and cached when the planes live on a GPU
+        if send.is_cuda:
+            hk = ("host",) + tuple(send.shape) + (send.dtype,)
+            bufs = _A2A_SEND.get(hk)
+            if bufs is None:
+                bufs = _A2A_SEND[hk] = (torch.empty(send.shape, dtype=send.dtype, pin_memory=True), torch.empty(send.shape, dtype=send.dtype, pin_memory=True))
+            host, got = bufs
+            host.copy_(send)
+        else:
+            host, got = send, torch.empty_like(send)
         dist.all_to_all_single(got, host)
         recv = got.to(planes.device)
     return recv if hi - lo == mx else recv[..., : hi - lo].contiguous()

@@ -9,7 +9,7 @@ SRC=${SRC:-gemm}
 make -s -C vtc_amd/csrc -j8
 mkdir -p build/var_$name vtc_amd/lib/variants
 objs=""
-for f in gemm qkv_attn norm attention embed sweep towers prof train cam; do
+for f in gemm norm attention embed sweep towers prof train cam; do
   if [[ " $SRC " == *" $f "* ]]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -Wno-unused-variable "$@" -c vtc_amd/csrc/$f.hip -o build/var_$name/$f.o
     objs="$objs build/var_$name/$f.o"

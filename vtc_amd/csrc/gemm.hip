@@ -50,6 +50,10 @@
 #endif
 #include "gemm_stamps.h"
 
+#ifndef VTC_MFMA_PRIO
+#define VTC_MFMA_PRIO 3      // s_setprio of a wave inside its MFMA cluster.  Round 5 A/B (tools/gemm_ab.py, 6 rounds x 30 reps, bit-identical): 3 against
+                             // round 4's 1: c_proj +1.2 %, QKV +1.0 %, c_fc / out-proj / text shapes +0.2 ... +0.8 % (profiles/r05_experiments.txt 5)
+#endif
 #ifndef VTC_GEMM_DEEP_DEFAULT
 #define VTC_GEMM_DEEP_DEFAULT 1     // the 256 x 256 kernel's LDS-DMA pipeline: 1 = deep (round 4), 0 = one quarter in flight (rounds 1-3)
 #endif
@@ -1226,7 +1230,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
           __builtin_amdgcn_s_barrier();
           lgkm_wait_subtile(aS, wS);
           // (d) the MFMA cluster
-          __builtin_amdgcn_s_setprio(1);
+          __builtin_amdgcn_s_setprio(VTC_MFMA_PRIO);
   #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
   #pragma unroll
@@ -1315,7 +1319,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
           lgkm_wait_subtile(aS, wD[0]);
           VTC_PHASE_STAMP(1);
           // (d) the MFMA cluster
-          __builtin_amdgcn_s_setprio(1);
+          __builtin_amdgcn_s_setprio(VTC_MFMA_PRIO);
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
 #pragma unroll

@@ -257,6 +257,19 @@ int vtc_l2_sweep_shard_cols(const float *b_all, const float *a_local, int n_tota
 /* hits[j] += #{ i : (target_offset + i) in ids[i, :k_vals[j]] }   (hits: int64 device) */
 int vtc_recall_hits(const int64_t *ids, int n_queries, int depth, int64_t target_offset, const int *k_vals_host,
                     int nk, long long *hits, void *stream);
+/* R@K of BOTH directions of n PAIRED rows (a_i <-> b_i: RecallAtK.result(), model/metric.py:166-187; evaluation/eval.py:117-127) without the
+ * sorted neighbour lists (round 5).  The reference asks one thing of its search -- is the query's own index among the first k -- which is
+ * the RANK of one gallery row: #{ j : (|q - g_j|^2, j) < (|q - g_t|^2, t) } < k.  One prologue, ONE distance GEMM (the block-minima
+ * planes of vtc_l2_topk_bidir), ONE rank launch: entries whose key is more than the row's error bound away from the target's exact
+ * distance are counted or dropped unseen, the few in reach are settled in fp64.  The counters are those of vtc_l2_topk_bidir(depth =
+ * max k + 1, VTC_SWEEP_EXACT) followed by vtc_recall_hits_pair, exactly.  hits_*: nk device int64 each, ADDED to:
+ *   hits_b_from_a[j] += #{ i : a_i is among the k_j nearest a's of b_i }   = RecallAtK.compute(a, b) x n
+ *   hits_a_from_b[j] += #{ i : b_i is among the k_j nearest b's of a_i }   = RecallAtK.compute(b, a) x n
+ * n >= 1024, d % 64 == 0 (vtc_l2_recall_bidir_supported; else the two-call form); nk <= 4; k_vals on the host. */
+int vtc_l2_recall_bidir_supported(int n, int d);
+size_t vtc_l2_recall_bidir_workspace_bytes(int n, int d);
+int vtc_l2_recall_bidir(const float *a, const float *b, int n, int d, const int *k_vals_host, int nk, long long *hits_b_from_a,
+                        long long *hits_a_from_b, void *ws, size_t ws_bytes, void *stream);
 /* the same for the two directions of one evaluation (RecallAtK.result(), model/metric.py:166-187: compute(a, b) and compute(b, a),
  * same number of queries and the same targets) in ONE launch */
 int vtc_recall_hits_pair(const int64_t *ids_a, const int64_t *ids_b, int n_queries, int depth, int64_t target_offset,

@@ -416,7 +416,8 @@ def test_sharded_recall_world_1_equals_recallatk_compute_both(n):
     c_ab, c_ba = m.compute_both(ta, tb)
     assert r_ab == dict(c_ab) and r_ba == dict(c_ba)
     assert r_ab == dict(E.recall_at_k(a, b, [1, 5, 10], np.float64)) and r_ba == dict(E.recall_at_k(b, a, [1, 5, 10], np.float64))
-    assert ph["path"].startswith("one distance matrix" if n >= vdist.BIDIR_MIN_ROWS else "two searches")
+    assert ph["path"].startswith("one distance matrix" if n >= min(vdist.BIDIR_MIN_ROWS, vdist.RANK_MIN_ROWS) else "two searches")
+    assert vdist.RANK_MIN_ROWS == m.rank_min_rows
     assert vdist.BIDIR_MIN_ROWS == m.bidir_min_rows and vdist.BIDIR_MIN_ROWS_F32 == m.bidir_min_rows_f32
 
 
@@ -437,3 +438,76 @@ def test_exact_sweep_with_rows_whose_components_underflow_when_squared():
         assert np.array_equal(ids.cpu().numpy(), E.l2_topk(ga, qb, 11, np.float64)[0])
     i1, _, i2, _ = ops.l2_topk_bidir(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 11, precision=L.SWEEP_EXACT)
     assert np.array_equal(i1.cpu().numpy(), E.l2_topk(a, b, 11, np.float64)[0]) and np.array_equal(i2.cpu().numpy(), E.l2_topk(b, a, 11, np.float64)[0])
+
+
+def _hits_ref(a, b, ks):
+    n = a.shape[0]
+    return np.array([[round(r * n) for _, r in E.recall_at_k(a, b, ks, np.float64)], [round(r * n) for _, r in E.recall_at_k(b, a, ks, np.float64)]])
+
+
+@pytest.mark.parametrize("n,d,noise", [(1024, 64, 0.6), (2500, 512, 0.6), (4099, 512, 1.5), (3000, 128, 0.0), (2048, 768, 0.3)])
+def test_recall_bidir_rank_path_equals_the_fp64_oracle(n, d, noise):
+    """vtc_l2_recall_bidir (round 5): the hit counters of both directions straight from the distance GEMM's key planes -- the RANK of each
+    query's own gallery row, no sorted neighbour lists -- must be the fp64 oracle's and the two-step form's (vtc_l2_topk_bidir +
+    vtc_recall_hits_pair), for planted positives at several noise levels (noise 0: b == a, every rank 0 with exact ties), k sets incl. a
+    single k, and for UNRELATED sets (every target far from the top: the certain-miss shortcut)."""
+    from vtc_amd import _lib as L
+    from vtc_amd import ops
+    a, b = planted(n, d, seed=n, noise=noise) if noise > 0 else (planted(n, d, seed=n)[0],) * 2
+    ta, tb = torch.from_numpy(np.ascontiguousarray(a)).cuda(), torch.from_numpy(np.ascontiguousarray(b)).cuda()
+    for ks in ([1, 5, 10], [1], [3, 7, 20, 50]):
+        got = ops.recall_bidir(ta, tb, ks).cpu().numpy()
+        assert np.array_equal(got, _hits_ref(a, b, ks)), (n, d, noise, ks, got.tolist(), _hits_ref(a, b, ks).tolist())
+        i1, _, i2, _ = ops.l2_topk_bidir(ta, tb, min(max(ks) + 1, 64), precision=L.SWEEP_EXACT, return_dists=False)
+        two = ops.recall_hits_pair(i1, i2, [min(k, i1.shape[1]) for k in ks], 0, torch.zeros(2, len(ks), dtype=torch.int64, device="cuda")).cpu().numpy()
+        if max(ks) < 64:
+            assert np.array_equal(got, two)
+    rng = np.random.default_rng(n)
+    c = unit(rng.standard_normal((n, d))).astype(np.float32)            # unrelated to a: recall ~ k / n
+    got = ops.recall_bidir(ta, torch.from_numpy(c).cuda(), [1, 5, 10]).cpu().numpy()
+    assert np.array_equal(got, _hits_ref(a, c, [1, 5, 10]))
+
+
+def test_recall_bidir_rank_path_ties_duplicates_scales_and_the_adversarial_case():
+    """Exact duplicates in both sets (ties resolve to the lowest index: a duplicate BEFORE the target outranks it, one after does not), dense
+    near-duplicate clusters around targets (the lists overflow: fp64 fallback), un-normalised rows at scale 25 (eps scales with the norms),
+    and the bf16-midpoint adversary (rows whose rounding errors are the worst case: no entry may be dropped as certain that is not)."""
+    from oracle import sweep_planes as SP
+    from vtc_amd import ops
+    rng = np.random.default_rng(5)
+    n, d = 3000, 512
+    a, b = planted(n, d, seed=77, noise=0.4)
+    a[100:140] = a[99]                      # 40 exact duplicates of gallery row 99 ...
+    b[100:140] = b[99]                      # ... and of query 99
+    a[2000:2100] = a[1999] + (1e-7 * rng.standard_normal((100, d))).astype(np.float32)      # a dense cluster: fp64 decides, lists overflow
+    b[1999:2100] = a[1999]
+    for scale in (1.0, 25.0):
+        sa, sb = (a * np.float32(scale)).astype(np.float32), (b * np.float32(scale)).astype(np.float32)
+        got = ops.recall_bidir(torch.from_numpy(sa).cuda(), torch.from_numpy(sb).cuda(), [1, 5, 10]).cpu().numpy()
+        assert np.array_equal(got, _hits_ref(sa, sb, [1, 5, 10])), (scale, got.tolist(), _hits_ref(sa, sb, [1, 5, 10]).tolist())
+    g, q = SP.midpoint_case(d=512, depth=11)                  # gallery + one adversarial query whose true nearest row is gallery row 0
+    n2 = 1024
+    ga = np.concatenate([g, unit(rng.standard_normal((n2 - g.shape[0], 512))).astype(np.float32)]) if g.shape[0] < n2 else g[:n2]
+    qb = ga.copy()
+    qb[0] = q[0]                                              # pair 0 = the adversarial query against its true neighbour
+    got = ops.recall_bidir(torch.from_numpy(ga).cuda(), torch.from_numpy(qb).cuda(), [1, 5, 10]).cpu().numpy()
+    assert np.array_equal(got, _hits_ref(ga, qb, [1, 5, 10]))
+
+
+@pytest.mark.parametrize("n", [10000, 50000])
+def test_recall_bidir_rank_path_at_full_size_equals_the_two_step_form(n):
+    """BASELINE sizes: the counters of the rank path == those of vtc_l2_topk_bidir + vtc_recall_hits_pair (whose ids are held to the fp64
+    oracle elsewhere), through the drop-in metric and through sharded_recall(world = 1)."""
+    from vtc_amd import dist as vdist
+    from vtc_amd.host.metric import RecallAtK
+    a, b = planted(n, 512, seed=n + 9, noise=9.0)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    m = RecallAtK("videos", "titles", [1, 5, 10])
+    fast = m.compute_both(ta, tb)
+    m2 = RecallAtK("videos", "titles", [1, 5, 10])
+    m2.rank_path = False
+    assert fast == m2.compute_both(ta, tb)
+    r_ab, r_ba = vdist.sharded_recall(ta, tb, n, [1, 5, 10], 0, 1)
+    assert r_ab == dict(fast[0]) and r_ba == dict(fast[1])
+    print(f"[parity] rank path n={n}: R@1/5/10 {fast[0]} / {fast[1]}")
+    assert 0.02 < fast[0][0][1] < 0.9999         # the case is neither trivial nor hopeless

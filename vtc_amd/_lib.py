@@ -94,6 +94,9 @@ SIGNATURES = {
                                           C.c_size_t, vp]),
     "vtc_recall_hits": (C.c_int, [ip, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int), C.c_int, vp, vp]),
     "vtc_recall_hits_pair": (C.c_int, [ip, ip, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int), C.c_int, vp, vp, vp]),
+    "vtc_l2_recall_bidir_supported": (C.c_int, [C.c_int, C.c_int]),
+    "vtc_l2_recall_bidir_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "vtc_l2_recall_bidir": (C.c_int, [fp, fp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, ip, ip, vp, C.c_size_t, vp]),
     "vtc_gemm": (C.c_int, [vp, vp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "vtc_gemm_resid_layernorm_workspace_bytes": (C.c_size_t, [C.c_int]),
     "vtc_gemm_resid_layernorm_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

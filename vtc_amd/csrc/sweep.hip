@@ -122,8 +122,13 @@ __global__ __launch_bounds__(256) void sweep_prep_kernel(PrepSide A, PrepSide B,
   __syncthreads();
   if (threadIdx.x < 8) part[(size_t)blockIdx.x * 8 + threadIdx.x] = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
 }
-__global__ __launch_bounds__(256) void sweep_prep_max_kernel(const float *__restrict__ part, int nblocks, float *__restrict__ mxA, float *__restrict__ mxB) {
+__global__ __launch_bounds__(256) void sweep_prep_max_kernel(const float *__restrict__ part, int nblocks, float *__restrict__ mxA, float *__restrict__ mxB,
+                                                             int *zero_a, int *zero_b) {
   __shared__ float red[32][8];
+  if (threadIdx.x == 0) {          // (the recall-rank path's two fallback counters: saves a fill launch)
+    if (zero_a) *zero_a = 0;
+    if (zero_b) *zero_b = 0;
+  }
   const int k = threadIdx.x & 7, sl = threadIdx.x >> 3;
   float m = 0.f;
   for (int b = sl; b < nblocks; b += 32) m = fmaxf(m, part[(size_t)b * 8 + k]);
@@ -137,10 +142,10 @@ __global__ __launch_bounds__(256) void sweep_prep_max_kernel(const float *__rest
   }
 }
 static int prep_blocks(int rows) { return cdiv(rows, 4 * PREP_RPW); }
-static void launch_sweep_prep(const PrepSide &A, const PrepSide &B, int d, float *part, hipStream_t stream) {
+static void launch_sweep_prep(const PrepSide &A, const PrepSide &B, int d, float *part, hipStream_t stream, int *zero_a = nullptr, int *zero_b = nullptr) {
   const int nb = prep_blocks(A.n + B.n);
   hipLaunchKernelGGL(sweep_prep_kernel, dim3(nb), dim3(256), 0, stream, A, B, d, part);
-  hipLaunchKernelGGL(sweep_prep_max_kernel, dim3(1), dim3(256), 0, stream, part, nb, A.mx, B.mx);
+  hipLaunchKernelGGL(sweep_prep_max_kernel, dim3(1), dim3(256), 0, stream, part, nb, A.mx, B.mx, zero_a, zero_b);
 }
 
 // Wave-wide sorted best list, one entry per lane (lane i = i-th best), order = (distance, index).
@@ -1281,6 +1286,340 @@ Sweep2Ws plan2(char *ws, int ng, int nq, int d, bool bidir) {
   return s;
 }
 
+// ---- recall-only finish of the block-minima sweep (round 5) ----------------------------------------------------------------
+// The reference's RecallAtK.compute (model/metric.py:137-161) searches the max(k)+1 nearest gallery rows of every query and then asks
+// ONE thing of the sorted list: is the query's own row index among the first k.  That is the RANK of one gallery row,
+//     rank_i = #{ j : (|q_i - g_j|^2, j) < (|q_i - g_t|^2, t) },  t = the query's target,        hit at k  <=>  rank_i < k
+// (ties by lowest index, as everywhere in this file), and it does not need the sorted top list.  From the key planes of the distance
+// GEMM: with d_t the target's exact fp64 distance and eps the row's bound on |key distance - exact| (minsel_kernel's formula),
+//   key + eps < d_t   the entry is closer for certain         key - eps > d_t   farther for certain         else: fp64 decides;
+// a block whose FOURTH-smallest key is <= d_t + eps may hide unlisted entries in reach of d_t: all its entries go to fp64.
+// If the certain ones alone number >= max(k) the query misses at every k and nothing else is looked at -- the fate of most queries of
+// an untrained model -- and for a query whose target leads its list (a trained model) almost nothing is in reach: the fp64 re-rank of
+// ~20 candidate rows per query (the sweep's largest consumer of bytes) shrinks to the target row and a handful.  Same hits as
+// vtc_l2_topk_bidir + vtc_recall_hits_pair, bit for bit in the counters.
+struct RankArgs {
+  const unsigned *keys;        // [4][nblk][R]
+  int R, nblk, bw;             // owners (queries of this direction), blocks, entries per block (64 rows / RB columns)
+  const float *own, *other;    // fp32 rows: [R, d] owners, [ng, d] the other side
+  int ng, d;
+  const float *own_norm;
+  const float2 *own_st;
+  const float *other_max;
+  float kappa;
+  int kmax, nk, k[4];
+  unsigned long long *hits;    // [nk], added to
+  int *flags;                  // flags[0] = count, flags[1..] = rows left to recall_rank_finish_kernel: r (lists overflowed: brute force) or r | RK_HARD
+  int *work;                   // [R][RK_WORK] ints: a deferred row's (closer_safe, n_amb, n_ub, unsafe blocks[RK_UB], ambiguous entries[RK_AMB])
+  int *part;                   // [workgroups of recall_rank_kernel][4]: their hit counts, summed by recall_rank_finish_kernel (one atomic per k
+                               // instead of one per wave: 7 500 same-address atomics were 75 of the kernel's 125 us at 10k)
+  int nparts;
+};
+constexpr int RK_OW = 32, RK_CH = 64, RK_AMB = 64, RK_UB = 8;      // owners per workgroup, blocks per chunk, list capacities per owner
+constexpr int RK_WORK = 128, RK_HARD = 1 << 30, RK_INLINE = 16;      // ints per deferred row; flag bit; fp64 evaluations a wave does inline
+// fp64 |q - g|^2 for up to eight gallery rows at once (the arithmetic and order of wave_dist64: the same doubles whichever kernel forms them)
+__device__ __forceinline__ void wave_dist64_x8(const float *__restrict__ q, const float *__restrict__ gallery, const int (&jj)[8], int d, int lane,
+                                               double (&out)[8]) {
+  double sacc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 a = *reinterpret_cast<const float4 *>(q + c);
+    float4 b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) b[u] = *reinterpret_cast<const float4 *>(gallery + (size_t)(jj[u] < 0 ? 0 : jj[u]) * d + c);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double e0 = (double)a.x - (double)b[u].x, e1 = (double)a.y - (double)b[u].y, e2 = (double)a.z - (double)b[u].z,
+                   e3 = (double)a.w - (double)b[u].w;
+      sacc[u] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sacc[u] += __shfl_xor(sacc[u], o, 64);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) out[u] = sacc[u];
+}
+__global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, const RankArgs PB, int nblocks_a) {
+  const bool second = (int)blockIdx.x >= nblocks_a;
+  const RankArgs &P = second ? PB : PA;
+  const int bid = second ? (int)blockIdx.x - nblocks_a : (int)blockIdx.x;
+  const unsigned *__restrict__ keys = P.keys;
+  const int R = P.R, nblk = P.nblk, bw = P.bw, ng = P.ng, d = P.d, kmax = P.kmax;
+  __shared__ unsigned tl[4][RK_CH * (RK_OW + 1)];
+  __shared__ int amb[RK_OW][RK_AMB];
+  __shared__ int ublk[RK_OW][RK_UB];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  constexpr int OPW = RK_OW / 4;                     // owners per wave
+  const int r0 = bid * RK_OW;
+  const size_t plane = (size_t)nblk * R;
+  // ---- the targets' exact distances and the rows' thresholds (wave-uniform per owner) ----
+  double dt[OPW];
+  float lo[OPW], hi[OPW];
+  {
+    // the wave's eight (owner, target) pairs at once: all sixteen row pieces of a K slice are requested before the first is used and the
+    // eight xor butterflies interleave (one pair at a time this was eight dependent gather + butterfly latencies: 100 of the kernel's
+    // 123 us at 10k).  Per pair the arithmetic and order of wave_dist64 (target of owner r: gallery row r -- R == ng).
+#pragma unroll
+    for (int cc = 0; cc < OPW; ++cc) dt[cc] = 0.0;
+    for (int c = lane * 4; c < d; c += 256) {
+      float4 qa[OPW], gb[OPW];
+#pragma unroll
+      for (int cc = 0; cc < OPW; ++cc) {
+        const int r = min(r0 + OPW * w + cc, R - 1);
+        qa[cc] = *reinterpret_cast<const float4 *>(P.own + (size_t)r * d + c);
+        gb[cc] = *reinterpret_cast<const float4 *>(P.other + (size_t)min(r, ng - 1) * d + c);
+      }
+#pragma unroll
+      for (int cc = 0; cc < OPW; ++cc) {
+        const double e0 = (double)qa[cc].x - (double)gb[cc].x, e1 = (double)qa[cc].y - (double)gb[cc].y, e2 = (double)qa[cc].z - (double)gb[cc].z,
+                     e3 = (double)qa[cc].w - (double)gb[cc].w;
+        dt[cc] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int cc = 0; cc < OPW; ++cc) dt[cc] += __shfl_xor(dt[cc], o, 64);
+    }
+#pragma unroll
+    for (int cc = 0; cc < OPW; ++cc) {
+      const int r = min(r0 + OPW * w + cc, R - 1);
+      const float2 st = P.own_st[r];
+      const float eps = 1.001f * (2.0f * (st.x * P.other_max[2] + st.y * P.other_max[1] + st.y * P.other_max[2]) + P.kappa * (P.own_norm[r] + P.other_max[0]));
+      lo[cc] = __double2float_rd(dt[cc] - (double)eps);      // key <  lo  =>  key + eps < d_t
+      hi[cc] = __double2float_ru(dt[cc] + (double)eps);      // key >  hi  =>  key - eps > d_t
+    }
+  }
+  // per LANE (= block of the chunk) counters, reduced over the wave once behind the scan: a ballot + population count per (owner, plane,
+  // chunk) for each of them made the scan vector-ALU-bound (17 us per chunk of 64 blocks; 0.9 ms of the 50k sweep)
+  int ca_l[OPW], cs_l[OPW], n_amb[OPW], n_ub[OPW];
+#pragma unroll
+  for (int cc = 0; cc < OPW; ++cc) ca_l[cc] = cs_l[cc] = n_amb[cc] = n_ub[cc] = 0;
+  const int so = t % RK_OW, sb = t / RK_OW;          // scalar tile loads: this thread's owner and block slice (8 slices)
+  const bool vec = (R & 3) == 0;                      // 16-byte loads: four consecutive owners per thread, 8 threads per (plane, block) row
+  const int vo = 4 * (t & 7), vb = t >> 3;            // ... this thread's first owner and (block, plane) slice: 32 slices
+  for (int c0 = 0; c0 < nblk; c0 += RK_CH) {
+    if (vec) {
+      uint4 v[RK_CH * 4 / 32];
+#pragma unroll
+      for (int q = 0; q < RK_CH * 4 / 32; ++q) {     // (block, plane) pairs vb + 32 q of the chunk: plane = pair & 3, block = pair >> 2
+        const int pr = vb + 32 * q, pl = pr & 3, bl = pr >> 2, blk = c0 + bl;
+        const bool ok = blk < nblk && r0 + vo < R;
+        v[q] = ok ? *reinterpret_cast<const uint4 *>(keys + pl * plane + (size_t)blk * R + r0 + vo) : make_uint4(0x7F800000u, 0x7F800000u, 0x7F800000u, 0x7F800000u);
+      }
+#pragma unroll
+      for (int q = 0; q < RK_CH * 4 / 32; ++q) {
+        const int pr = vb + 32 * q, pl = pr & 3, bl = pr >> 2;
+        unsigned *dst = &tl[pl][bl * (RK_OW + 1) + vo];
+        dst[0] = v[q].x; dst[1] = v[q].y; dst[2] = v[q].z; dst[3] = v[q].w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < RK_CH / 8; ++q) {
+        const int bl = sb + 8 * q, blk = c0 + bl;
+        const bool ok = blk < nblk && r0 + so < R;
+        const size_t o = ok ? (size_t)blk * R + r0 + so : 0;
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) tl[pl][bl * (RK_OW + 1) + so] = ok ? keys[pl * plane + o] : 0x7F800000u;
+      }
+    }
+    __syncthreads();
+    const int blk = c0 + lane;
+    const int base = blk * bw;
+#pragma unroll
+    for (int cc = 0; cc < OPW; ++cc) {
+      const int o = OPW * w + cc, r = r0 + o;
+      const unsigned k3 = tl[3][lane * (RK_OW + 1) + o];
+      const bool unsafe = k3 != 0x7F800000u && __uint_as_float(k3 & ~127u) <= hi[cc];
+      unsigned kk[3];
+      bool am[3];
+      bool any_am = false;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        kk[pl] = tl[pl][lane * (RK_OW + 1) + o];
+        const float v = __uint_as_float(kk[pl] & ~127u);
+        const bool valid = kk[pl] != 0x7F800000u && base + (int)(kk[pl] & 127u) != r;      // (the target itself is not counted)
+        const bool dc = valid && v < lo[cc];
+        am[pl] = valid && !dc && !(v > hi[cc]) && !unsafe;                                  // (an unsafe block's entries all go to fp64 below)
+        any_am |= am[pl];
+        ca_l[cc] += dc ? 1 : 0;
+        cs_l[cc] += (dc && !unsafe) ? 1 : 0;
+      }
+      const unsigned long long um = __ballot(unsafe);
+      if (um) {                                                           // wave-uniform, rare
+        const int pos = n_ub[cc] + __popcll(um & ((1ull << lane) - 1ull));
+        if (unsafe && pos < RK_UB) ublk[o][pos] = blk;
+        n_ub[cc] += __popcll(um);
+      }
+      if (__ballot(any_am)) {                                             // wave-uniform, rare: entries within eps of the target's distance
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const unsigned long long mask = __ballot(am[pl]);
+          const int pos = n_amb[cc] + __popcll(mask & ((1ull << lane) - 1ull));
+          if (am[pl] && pos < RK_AMB) amb[o][pos] = base + (int)(kk[pl] & 127u);
+          n_amb[cc] += __popcll(mask);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  int closer_all[OPW], closer_safe[OPW];
+#pragma unroll
+  for (int cc = 0; cc < OPW; ++cc) {
+    int x = ca_l[cc], y = cs_l[cc];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); }
+    closer_all[cc] = x; closer_safe[cc] = y;
+  }
+  // ---- settle: certain misses, fp64 for what is in reach, the rest to the fallback ----
+  int hit_cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int cc = 0; cc < OPW; ++cc) {
+    const int o = OPW * w + cc, r = r0 + o;
+    if (r >= R) continue;                                                 // wave-uniform
+    if (closer_all[cc] >= kmax) continue;                                 // a miss at every k
+    if (n_amb[cc] > RK_AMB || n_ub[cc] > RK_UB) {
+      if (lane == 0) P.flags[1 + atomicAdd(P.flags, 1)] = r;
+      continue;
+    }
+    if (n_amb[cc] + n_ub[cc] * bw > RK_INLINE) {
+      // a row with much in reach of its target (the target sits inside the bulk of its row's distances, yet fewer than max(k) entries are
+      // closer for certain): its fp64 work -- every entry of its unsafe blocks -- is a long serial chain for ONE wave that has seven more
+      // owners to do (the stragglers were the whole kernel time: 127 us at 10k for 0.3 % of the rows).  Deferred with its lists:
+      // recall_rank_finish_kernel gives it a workgroup of its own.
+      int *wk = P.work + (size_t)r * RK_WORK;
+      if (lane == 0) { wk[0] = closer_safe[cc]; wk[1] = n_amb[cc]; wk[2] = n_ub[cc]; }
+      if (lane < n_ub[cc]) wk[3 + lane] = ublk[o][lane];
+      if (lane < n_amb[cc]) wk[3 + RK_UB + lane] = amb[o][lane];
+      if (lane == 0) P.flags[1 + atomicAdd(P.flags, 1)] = r | RK_HARD;
+      continue;
+    }
+    const float *q = P.own + (size_t)r * d;
+    int rank = closer_safe[cc];
+    auto count_group = [&](const int (&jj)[8]) {
+      double dd[8];
+      wave_dist64_x8(q, P.other, jj, d, lane, dd);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (jj[u] >= 0 && (dd[u] < dt[cc] || (dd[u] == dt[cc] && jj[u] < r))) ++rank;
+    };
+    for (int c0 = 0; c0 < n_amb[cc] && rank < kmax; c0 += 8) {
+      int jj[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) jj[u] = c0 + u < n_amb[cc] ? amb[o][c0 + u] : -1;
+      count_group(jj);
+    }
+    for (int ub = 0; ub < n_ub[cc] && rank < kmax; ++ub) {
+      const int base = ublk[o][ub] * bw;
+      for (int c0 = 0; c0 < bw && rank < kmax; c0 += 8) {
+        int jj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = base + c0 + u;
+          jj[u] = (c0 + u < bw && j < ng && j != r) ? j : -1;
+        }
+        count_group(jj);
+      }
+    }
+#pragma unroll
+    for (int qk = 0; qk < 4; ++qk)
+      if (qk < P.nk && rank < P.k[qk]) ++hit_cnt[qk];
+  }
+  __shared__ int hsum[4][4];
+  if (lane == 0) {
+#pragma unroll
+    for (int qk = 0; qk < 4; ++qk) hsum[w][qk] = hit_cnt[qk];
+  }
+  __syncthreads();
+  if (t < 4) P.part[(size_t)bid * 4 + t] = hsum[0][t] + hsum[1][t] + hsum[2][t] + hsum[3][t];
+}
+// The rows recall_rank_kernel left over, one workgroup per row: a DEFERRED row (r | RK_HARD) comes with its lists -- the four waves split its
+// fp64 evaluations; a row whose lists overflowed (dense near-ties around the target) gets its rank by fp64 brute force over the other side.
+__global__ __launch_bounds__(256) void recall_rank_finish_kernel(const RankArgs PA, const RankArgs PB, int nblocks_a) {
+  const bool second = (int)blockIdx.x >= nblocks_a;
+  const RankArgs &P = second ? PB : PA;
+  const int bid = second ? (int)blockIdx.x - nblocks_a : (int)blockIdx.x;
+  const int nbl = second ? (int)gridDim.x - nblocks_a : nblocks_a;
+  __shared__ int part[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (bid == 0) {            // this direction's first workgroup: the rank kernel's per-workgroup hit counts -> one atomic per k
+    int acc[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < P.nparts; i += 256) {
+      const int4 v = *reinterpret_cast<const int4 *>(P.part + (size_t)i * 4);
+      acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+    }
+    __shared__ int red[4][4];
+#pragma unroll
+    for (int qk = 0; qk < 4; ++qk) {
+      int x = acc[qk];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+      if (lane == 0) red[w][qk] = x;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < P.nk) {
+      const int x = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      if (x) atomicAdd(&P.hits[threadIdx.x], (unsigned long long)x);
+    }
+    __syncthreads();
+  }
+  const int n_flagged = P.flags[0];
+  for (int f = bid; f < n_flagged; f += nbl) {          // uniform for the workgroup; normally few trips
+    const int fr = P.flags[1 + f];
+    const bool hard = (fr & RK_HARD) != 0;
+    const int r = fr & ~RK_HARD;
+    const float *q = P.own + (size_t)r * P.d;
+    const double dt = wave_dist64(q, P.other + (size_t)r * P.d, P.d, lane);
+    int cnt = 0, base_rank = 0;
+    auto count_group = [&](const int (&jj)[8]) {
+      double dd[8];
+      wave_dist64_x8(q, P.other, jj, P.d, lane, dd);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (jj[u] >= 0 && (dd[u] < dt || (dd[u] == dt && jj[u] < r))) ++cnt;
+    };
+    if (hard) {
+      const int *wk = P.work + (size_t)r * RK_WORK;
+      base_rank = wk[0];
+      const int n_amb = wk[1], n_ub = wk[2];
+      const int n_eval = n_amb + n_ub * P.bw;           // evaluation e: e < n_amb -> ambiguous entry e; else entry (e - n_amb) % bw of unsafe block (e - n_amb) / bw
+      for (int e0 = 8 * w; e0 < n_eval; e0 += 32) {
+        int jj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u;
+          int j = -1;
+          if (e < n_amb) j = wk[3 + RK_UB + e];
+          else if (e < n_eval) {
+            const int x = e - n_amb, ub = x / P.bw;
+            j = wk[3 + ub] * P.bw + (x - ub * P.bw);
+            if (j >= P.ng || j == r) j = -1;
+          }
+          jj[u] = j;
+        }
+        count_group(jj);
+      }
+    } else {
+      for (int j0 = 8 * w; j0 < P.ng; j0 += 32) {
+        int jj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) jj[u] = (j0 + u < P.ng && j0 + u != r) ? j0 + u : -1;
+        count_group(jj);
+      }
+    }
+    if (lane == 0) part[w] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int rank = base_rank + part[0] + part[1] + part[2] + part[3];
+      for (int qk = 0; qk < P.nk; ++qk)
+        if (rank < P.k[qk]) atomicAdd(&P.hits[qk], 1ull);
+    }
+    __syncthreads();
+  }
+}
+
 // gallery a [na], queries b [nb]; ids_a2b != nullptr: also the transposed direction
 // colk_out != NULL (sharded sweep, rank-local rows): the column planes go to the caller's [4, nblk_r_pad, na] buffer and the
 // column direction is NOT finished here (vtc_l2_sweep_shard_cols does, after the exchange)
@@ -1337,6 +1676,43 @@ int exact2_impl(const float *a, const float *b, int na, int nb, int d, int depth
     hipLaunchKernelGGL(block_rescan_kernel, dim3(g1 + g2), dim3(256), 0, stream, q1, q2, g1);
   }
   VTC_LAUNCH_CHECK("l2_topk exact (both directions)");
+  return 0;
+}
+
+// R@K hit counters of BOTH directions of n paired rows (a_i <-> b_i) without the sorted lists: prologue, ONE distance GEMM, ONE
+// rank launch (+ the fallback launch, normally empty).  hits_b_from_a[j] += #{ i : rank of a_i among the a's for query b_i < k_j }
+// (= RecallAtK.compute(a, b)), hits_a_from_b the transposed direction (= compute(b, a)).
+int recall_bidir_impl(const float *a, const float *b, int n, int d, const int *k_vals, int nk, unsigned long long *hits_b_from_a,
+                      unsigned long long *hits_a_from_b, const Sweep2Ws &s, hipStream_t stream) {
+  {
+    ProfScope prof(VTC_PROF_TOPK, (double)2 * n * d * 6, stream);
+    const PrepSide A{b, s.qb, s.qn, s.qst, s.qmax, n}, B{a, s.gb, s.gn, s.gst, s.gmax, n};
+    launch_sweep_prep(A, B, d, s.pmax, stream, s.flags, s.flags2);       // ... and the two fallback counters zeroed
+  }
+  VTC_LAUNCH_CHECK("l2_recall prologue");
+  GemmEpi e;
+  e.mode = EPI_L2MIN; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
+  e.rowk = s.rowk; e.colk = s.colk; e.nblk_c = s.nblk_c; e.nblk_r = s.nblk_r; e.rb = s.rb;
+  if (int rc = launch_gemm(s.qb, s.gb, nullptr, nullptr, n, n, d, VTC_BF16, e, stream)) return rc;
+  const float kappa = exact2_kappa(d);
+  int kmax = 0;
+  static_assert(RK_WORK * sizeof(int) <= CD2 * sizeof(int64_t) && 3 + RK_UB + RK_AMB <= RK_WORK, "a deferred row's lists fit its candidate-list slot");
+  const int nwg = cdiv(n, RK_OW);            // (4 ints per workgroup in the cand_n arrays: n / 8 <= n)
+  RankArgs r1{s.rowk, n, s.nblk_c, 64, b, a, n, d, s.qn, s.qst, s.gmax, kappa, 0, nk, {0, 0, 0, 0}, hits_b_from_a, s.flags, (int *)s.cand, s.cand_n, nwg};
+  RankArgs r2{s.colk, n, s.nblk_r, s.rb, a, b, n, d, s.gn, s.gst, s.qmax, kappa, 0, nk, {0, 0, 0, 0}, hits_a_from_b, s.flags2, (int *)s.cand2, s.cand2_n, nwg};
+  for (int i = 0; i < nk; ++i) { r1.k[i] = r2.k[i] = k_vals[i]; kmax = std::max(kmax, k_vals[i]); }
+  r1.kmax = r2.kmax = kmax;
+  {
+    ProfScope prof(VTC_PROF_TOPK, (double)L2MIN_PLANES * ((double)s.nblk_c + s.nblk_r) * n * 4 + 4.0 * n * d * 4, stream);
+    const int nb = cdiv(n, RK_OW);
+    hipLaunchKernelGGL(recall_rank_kernel, dim3(2 * nb), dim3(256), 0, stream, r1, r2, nb);
+  }
+  {
+    ProfScope prof(VTC_PROF_TOPK, 0.0, stream);
+    const int g = std::min(n, 1024);
+    hipLaunchKernelGGL(recall_rank_finish_kernel, dim3(2 * g), dim3(256), 0, stream, r1, r2, g);
+  }
+  VTC_LAUNCH_CHECK("l2_recall_bidir");
   return 0;
 }
 }  // namespace
@@ -1604,6 +1980,19 @@ extern "C" int vtc_recall_hits_pair(const int64_t *ids_a, const int64_t *ids_b, 
   }
   VTC_LAUNCH_CHECK("recall_hits_pair");
   return 0;
+}
+
+extern "C" int vtc_l2_recall_bidir_supported(int n, int d) { return (n >= 1024 && d > 0 && d % 64 == 0) ? 1 : 0; }
+extern "C" size_t vtc_l2_recall_bidir_workspace_bytes(int n, int d) { return plan2(nullptr, n, n, d, true).total; }
+extern "C" int vtc_l2_recall_bidir(const float *a, const float *b, int n, int d, const int *k_vals, int nk, long long *hits_b_from_a,
+                                   long long *hits_a_from_b, void *ws, size_t ws_bytes, void *stream) {
+  VTC_CHECK(a && b && hits_b_from_a && hits_a_from_b && k_vals, "l2_recall_bidir: null argument");
+  VTC_CHECK(vtc_l2_recall_bidir_supported(n, d), "l2_recall_bidir: n=%d must be >= 1024 and d=%d a multiple of 64 (else: vtc_l2_topk + vtc_recall_hits)", n, d);
+  VTC_CHECK(nk >= 1 && nk <= 4, "l2_recall_bidir: nk=%d must be in [1,4]", nk);
+  for (int i = 0; i < nk; ++i) VTC_CHECK(k_vals[i] >= 1 && k_vals[i] <= n, "l2_recall_bidir: k=%d outside [1, n=%d]", k_vals[i], n);
+  Sweep2Ws s = plan2((char *)ws, n, n, d, true);
+  VTC_CHECK(ws && ws_bytes >= s.total, "l2_recall_bidir: workspace too small (%zu < %zu)", ws_bytes, s.total);
+  return recall_bidir_impl(a, b, n, d, k_vals, nk, (unsigned long long *)hits_b_from_a, (unsigned long long *)hits_a_from_b, s, (hipStream_t)stream);
 }
 
 extern "C" int vtc_similarity(const float *v, const float *t, int nv, int nt, int d, const float *logit_scale, float *sim,

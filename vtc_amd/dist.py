@@ -105,6 +105,8 @@ def all_gather_rows(x: torch.Tensor, n_total: int, rank: int, world: int) -> tor
     return torch.cat([out[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
 
 
+RANK_PATH = os.environ.get("VTC_SWEEP_RANK", "1") != "0"      # world 1, EXACT: hit counters without sorted lists (as host/metric.py RecallAtK.rank_path)
+RANK_MIN_ROWS = 1024
 BIDIR_MIN_ROWS = 5120       # as host/metric.py RecallAtK.bidir_min_rows (tools/bidir_threshold.py: EXACT 6k 0.49 vs 0.6+, 10k 0.64 vs 0.79 ms)
 BIDIR_MIN_ROWS_F32 = 3000
 
@@ -123,6 +125,8 @@ def sweep_path(n_total: int, precision: int, world: int, depth: int = 11) -> str
     if world > 1:
         return ("one [N/G, N] distance GEMM per rank, column block minima exchanged (all-to-all)"
                 if one_matrix_sharded(n_total, precision, world, depth) else "two searches per rank ([N/G, N] blocks)")
+    if precision == 3 and RANK_PATH and n_total >= RANK_MIN_ROWS:
+        return "one distance matrix, ranks of the paired rows (no sorted lists)"
     one = n_total >= (BIDIR_MIN_ROWS_F32 if precision == 0 else BIDIR_MIN_ROWS)
     return "one distance matrix, row + column top-k" if one else "two searches per rank ([N/G, N] blocks)"
 
@@ -239,6 +243,19 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
     ks = [min(int(k), depth) for k in k_vals]
     hits = torch.zeros(2, len(ks), dtype=torch.int64, device=feats_a_local.device)
     both = None
+    if (hip_sweep and world == 1 and precision == 3 and RANK_PATH and n_total >= RANK_MIN_ROWS and len(ks) <= 4
+            and feats_a_local.shape == feats_b_local.shape and feats_a_local.shape[1] % 64 == 0):
+        # one rank owns every pair: the hit counters come straight from the distance GEMM's key planes (vtc_l2_recall_bidir: the rank of
+        # each query's own gallery row; no sorted lists) -- what RecallAtK.compute_both does on one GPU
+        from . import ops
+        ops.recall_bidir(a_all, b_all, ks, ws=ws, hits=hits)
+        mark("bidir_gemm_rank")
+        hits = hits.cpu()
+        if marks:
+            for (_, e0), (name, e1) in zip(marks, marks[1:]):
+                phases[name + "_ms"] = round(phases.get(name + "_ms", 0.0) + e0.elapsed_time(e1), 4)
+            phases["path"] = sweep_path(n_total, precision, world, depth)
+        return ({k: hits[0, j].item() / n_total for j, k in enumerate(k_vals)}, {k: hits[1, j].item() / n_total for j, k in enumerate(k_vals)})
     if hip_sweep and world == 1 and n_total >= (BIDIR_MIN_ROWS_F32 if precision == 0 else BIDIR_MIN_ROWS):
         # one rank owns the whole matrix: both directions from one distance GEMM (vtc_l2_topk_bidir); with more
         # ranks each direction's [N/G, N] block is a different matrix and the two searches stay separate

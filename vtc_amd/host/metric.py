@@ -111,6 +111,10 @@ class RecallAtK(BaseMetric):
     #: and pays a list initialisation per segment; the GEMM it saves grows with N^2)
     bidir_min_rows = 5120          # tools/bidir_threshold.py: one matrix wins from ~5k rows (EXACT 10k: 0.64 vs 0.79 ms)
     bidir_min_rows_f32 = 3000      # SWEEP_F32: the fp32-MFMA GEMM it saves is the expensive part at every size
+    #: EXACT mode, paired rows: hit counters straight from the distance GEMM's key planes (the rank of each query's own gallery row),
+    #: no sorted neighbour lists (round 5; the library takes n >= 1024)
+    rank_path = True
+    rank_min_rows = 1024
 
     def _hits_to_recall(self, ids, num_samples):
         ks = [min(int(k), ids.shape[1]) for k in self.k_vals]
@@ -124,9 +128,19 @@ class RecallAtK(BaseMetric):
         """(compute(a, b), compute(b, a)) -- the two calls every caller of the reference makes back to back
         (metric.py:177-180, evaluation/eval.py:117-127, retrieval_evaluation.py:38-44)."""
         min_rows = self.bidir_min_rows_f32 if self.precision == L.SWEEP_F32 else self.bidir_min_rows
-        if features_a.shape[0] != features_b.shape[0] or features_a.shape[0] < min_rows:
+        if features_a.shape[0] != features_b.shape[0] or features_a.shape[0] < min(min_rows, self.rank_min_rows):
             return self.compute(features_a, features_b), self.compute(features_b, features_a)
         a, b, depth = self._prep(features_a, features_b)
+        ks = [int(k) for k in self.k_vals]
+        if (self.precision == L.SWEEP_EXACT and self.rank_path and a.shape[0] >= self.rank_min_rows and len(ks) <= 4
+                and max(ks) <= a.shape[0] and ops.recall_bidir_supported(a.shape[0], a.shape[1])):
+            # paired rows, parity mode: the reference asks only whether the query's own index is among the first k -- the RANK of one
+            # gallery row -- so the sorted lists are never built (vtc_l2_recall_bidir; the same counters as the two-step form below)
+            hits = ops.recall_bidir(a, b, ks, ws=self._workspace(L.lib().vtc_l2_recall_bidir_workspace_bytes(a.shape[0], a.shape[1]), a.device)).cpu().numpy()
+            n = a.shape[0]
+            return ([(k, float(h) / n) for k, h in zip(self.k_vals, hits[0])], [(k, float(h) / n) for k, h in zip(self.k_vals, hits[1])])
+        if features_a.shape[0] < min_rows:
+            return self.compute(features_a, features_b), self.compute(features_b, features_a)
         ids_b2a, _, ids_a2b, _ = ops.l2_topk_bidir(a, b, depth, precision=self.precision, return_dists=False, ws=self._workspace(
             L.lib().vtc_l2_topk_bidir_workspace_bytes(a.shape[0], b.shape[0], a.shape[1], self.precision, 0), a.device))
         return self._hits_to_recall(ids_b2a, a.shape[0]), self._hits_to_recall(ids_a2b, b.shape[0])

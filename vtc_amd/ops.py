@@ -315,6 +315,31 @@ def sweep_shard_cols(b_all: torch.Tensor, a_local: torch.Tensor, depth: int, pla
     return ids
 
 
+def recall_bidir_supported(n: int, d: int) -> bool:
+    return bool(L.lib().vtc_l2_recall_bidir_supported(int(n), int(d)))
+
+
+@on_device
+def recall_bidir(a: torch.Tensor, b: torch.Tensor, k_vals: Sequence[int], ws: Optional[torch.Tensor] = None,
+                 hits: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """R@K hit counters of both directions of n paired rows WITHOUT the sorted neighbour lists (vtc_l2_recall_bidir: one distance GEMM +
+    one rank launch): hits[0, j] += #{i : a_i among the k_j nearest a's of b_i} (= RecallAtK.compute(a, b) x n), hits[1, j] the transposed
+    direction (= compute(b, a) x n).  The same counters as l2_topk_bidir(depth = max k + 1, EXACT) + recall_hits_pair."""
+    a, b = _gpu(a, torch.float32, "a"), _gpu(b, torch.float32, "b")
+    n, d = a.shape
+    assert b.shape == (n, d) and 1 <= len(k_vals) <= 4
+    if hits is None:
+        hits = torch.zeros(2, len(k_vals), dtype=torch.int64, device=a.device)
+    assert hits.shape == (2, len(k_vals)) and hits.is_contiguous() and hits.dtype == torch.int64
+    need = L.lib().vtc_l2_recall_bidir_workspace_bytes(n, d)
+    if ws is None or ws.numel() < need or ws.device != a.device:
+        ws = workspace(need, a.device)
+    ks = (C.c_int * len(k_vals))(*[int(k) for k in k_vals])
+    L.check(L.lib().vtc_l2_recall_bidir(a.data_ptr(), b.data_ptr(), n, d, ks, len(k_vals), hits[0].data_ptr(), hits[1].data_ptr(),
+                                        ws.data_ptr(), ws.numel(), _stream()), "vtc_l2_recall_bidir")
+    return hits
+
+
 @on_device
 def recall_hits_pair(ids_a: torch.Tensor, ids_b: torch.Tensor, k_vals: Sequence[int], target_offset: int, hits: torch.Tensor) -> torch.Tensor:
     """hits[0] += hits of ids_a, hits[1] += hits of ids_b (both [n, depth], same targets): one launch for both directions."""

@@ -1613,8 +1613,9 @@ __global__ __launch_bounds__(256) void recall_rank_finish_kernel(const RankArgs 
     __syncthreads();
     if (threadIdx.x == 0) {
       const int rank = base_rank + part[0] + part[1] + part[2] + part[3];
-      for (int qk = 0; qk < P.nk; ++qk)
-        if (rank < P.k[qk]) atomicAdd(&P.hits[qk], 1ull);
+#pragma unroll
+      for (int qk = 0; qk < 4; ++qk)          // (constant indices: a run-time index into P.k[] sends the argument block to scratch)
+        if (qk < P.nk && rank < P.k[qk]) atomicAdd(&P.hits[qk], 1ull);
     }
     __syncthreads();
   }

@@ -270,6 +270,24 @@ int vtc_l2_recall_bidir_supported(int n, int d);
 size_t vtc_l2_recall_bidir_workspace_bytes(int n, int d);
 int vtc_l2_recall_bidir(const float *a, const float *b, int n, int d, const int *k_vals_host, int nk, long long *hits_b_from_a,
                         long long *hits_a_from_b, void *ws, size_t ws_bytes, void *stream);
+/* The sharded sweep (above) with the recall-only finish: rank r holds rows [row_base, row_base + n_local) of both sets and the gathered
+ * sets, runs ONE [n_local, n_total] distance GEMM and adds its PARTIAL counters (the host all-reduces them: model/metric.py:148-160 counted
+ * over this rank's queries):
+ *   vtc_l2_recall_shard_rows   hits_b_from_a[j] += #{ i local : a_(row_base + i) among the k_j nearest a's of b_(row_base + i) };
+ *                              col_planes [4, nblk_pad, n_total] as vtc_l2_sweep_shard_rows writes them
+ *   (host) all-to-all of the column planes, as above
+ *   vtc_l2_recall_shard_cols   planes [n_src, 4, nblk_pad, n_local]; src_bounds [n_src + 1] (device int32): source s ran rows
+ *                              [src_bounds[s], src_bounds[s + 1]);  hits_a_from_b[j] += #{ i local : b_(row_base + i) among the k_j nearest
+ *                              b's of a_(row_base + i) }
+ * Summed over the ranks: the counters of vtc_l2_recall_bidir on the gathered sets, exactly.  n_total >= 1024, d % 64 == 0, nk <= 4;
+ * workspace: vtc_l2_sweep_shard_workspace_bytes. */
+int vtc_l2_recall_shard_supported(int n_total, int n_local, int d);
+int vtc_l2_recall_shard_rows(const float *a_all, const float *b_local, int n_total, int n_local, int row_base, int d,
+                             const int *k_vals_host, int nk, long long *hits_b_from_a, unsigned *col_planes, int nblk_pad, void *ws,
+                             size_t ws_bytes, void *stream);
+int vtc_l2_recall_shard_cols(const float *b_all, const float *a_local, int n_total, int n_local, int row_base, int d,
+                             const int *k_vals_host, int nk, const unsigned *planes, int n_src, int nblk_pad, const int *src_bounds,
+                             long long *hits_a_from_b, void *ws, size_t ws_bytes, void *stream);
 /* the same for the two directions of one evaluation (RecallAtK.result(), model/metric.py:166-187: compute(a, b) and compute(b, a),
  * same number of queries and the same targets) in ONE launch */
 int vtc_recall_hits_pair(const int64_t *ids_a, const int64_t *ids_b, int n_queries, int depth, int64_t target_offset,

@@ -113,6 +113,66 @@ def test_one_matrix_sharded_sweep_exchange(world, n):
         assert brute < n // 2
 
 
+def _rank_ops():
+    """CPU stand-ins for ops.recall_shard_rows / ops.recall_shard_cols (the recall-only finish of the sharded sweep: hit counters, no ids):
+    the oracle's planes; the row direction counted from the oracle's fp64 ranks, the column direction FROM THE EXCHANGED PLANES."""
+    from oracle import sweep_planes as SP
+    stats = {}
+
+    def rows_fn(a_all, b_loc, base, ks, nbp, hits):
+        ids, planes = SP.shard_rows(a_all.numpy(), b_loc.numpy(), max(ks) + 1, nbp, RB)
+        tgt = np.arange(base, base + b_loc.shape[0])[:, None]
+        for j, k in enumerate(ks):
+            hits[j] += int((ids[:, :k] == tgt).any(axis=1).sum())
+        return torch.from_numpy(planes)
+
+    def cols_fn(b_all, a_loc, base, ks, planes, src_bounds, hits):
+        sb = src_bounds.numpy()
+        assert sb[-1] == b_all.shape[0] and len(sb) == planes.shape[0] + 1
+        ids = SP.shard_cols(b_all.numpy(), a_loc.numpy(), max(ks) + 1, planes.numpy(), sb[:-1].copy(), RB, stats)
+        tgt = np.arange(base, base + a_loc.shape[0])[:, None]
+        for j, k in enumerate(ks):
+            hits[j] += int((ids[:, :k] == tgt).any(axis=1).sum())
+    return (rows_fn, cols_fn, RB)
+
+
+def _worker_rank_sharded(rank, world, port, n, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from vtc_amd import dist as vdist
+    vdist.init_from_env(backend="gloo")
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((n, 32)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = a + 0.7 * rng.standard_normal((n, 32)).astype(np.float32)
+    b[: n // 2] /= np.linalg.norm(b[: n // 2], axis=1, keepdims=True)
+    lo, hi = vdist.shard_bounds(n, rank, world)
+    ph = {}
+    r_ab, r_ba = vdist.sharded_recall(torch.from_numpy(a[lo:hi]), torch.from_numpy(b[lo:hi]), n, [1, 5, 10], rank, world, rank_ops=_rank_ops(), phases=ph)
+    if rank == 0:
+        ref_ab = dict(E.recall_at_k(a, b, [1, 5, 10]))
+        ref_ba = dict(E.recall_at_k(b, a, [1, 5, 10]))
+        out.put((r_ab == ref_ab and r_ba == ref_ba, ph.get("path"), (r_ab, ref_ab, r_ba, ref_ba)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 400), (3, 601)])
+def test_rank_sharded_sweep_over_gloo(world, n):
+    """sharded_recall's recall-only branch for world > 1 (rows: counters with the GEMM; all-to-all of the column planes with the
+    [n_src + 1] source bounds; columns: counters from the exchanged planes; all-reduce of the 2 x nk counters) == the unsharded oracle."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rank_sharded, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok, path, detail = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok, detail
+    assert path == "injected rank ops"
+
+
 @pytest.mark.parametrize("n", [64, 101])          # even and ragged shards
 def test_sharded_recall_world2(n):
     ctx = mp.get_context("spawn")

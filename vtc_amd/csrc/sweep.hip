@@ -1299,8 +1299,11 @@ Sweep2Ws plan2(char *ws, int ng, int nq, int d, bool bidir) {
 // ~20 candidate rows per query (the sweep's largest consumer of bytes) shrinks to the target row and a handful.  Same hits as
 // vtc_l2_topk_bidir + vtc_recall_hits_pair, bit for bit in the counters.
 struct RankArgs {
-  const unsigned *keys;        // [4][nblk][R]
-  int R, nblk, bw;             // owners (queries of this direction), blocks, entries per block (64 rows / RB columns)
+  const unsigned *keys;        // [nsrc][4][nblk][R]
+  int R, nblk, bw;             // owners (queries of this direction), blocks PER SOURCE, entries per block (64 rows / RB columns)
+  int nsrc;                    // sources of key planes: 1, or (sharded sweep, column direction) the ranks that each ran a [rows of theirs, R] GEMM
+  const int *bounds;           // [nsrc + 1] (device): source s covers the other side's rows [bounds[s], bounds[s + 1]); NULL: one source, [0, ng)
+  int tgt_off;                 // owner r is paired with row r + tgt_off of the other side (sharded sweep: the rank's first row; else 0)
   const float *own, *other;    // fp32 rows: [R, d] owners, [ng, d] the other side
   int ng, d;
   const float *own_norm;
@@ -1310,7 +1313,7 @@ struct RankArgs {
   int kmax, nk, k[4];
   unsigned long long *hits;    // [nk], added to
   int *flags;                  // flags[0] = count, flags[1..] = rows left to recall_rank_finish_kernel: r (lists overflowed: brute force) or r | RK_HARD
-  int *work;                   // [R][RK_WORK] ints: a deferred row's (closer_safe, n_amb, n_ub, unsafe blocks[RK_UB], ambiguous entries[RK_AMB])
+  int *work;                   // [R][RK_WORK] ints: a deferred row's (closer_safe, n_amb, n_ub, unsafe blocks' first entry[RK_UB] and end[RK_UB], ambiguous entries[RK_AMB])
   int *part;                   // [workgroups of recall_rank_kernel][4]: their hit counts, summed by recall_rank_finish_kernel (one atomic per k
                                // instead of one per wave: 7 500 same-address atomics were 75 of the kernel's 125 us at 10k)
   int nparts;
@@ -1345,12 +1348,12 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
   const bool second = (int)blockIdx.x >= nblocks_a;
   const RankArgs &P = second ? PB : PA;
   const int bid = second ? (int)blockIdx.x - nblocks_a : (int)blockIdx.x;
-  const unsigned *__restrict__ keys = P.keys;
   const int R = P.R, nblk = P.nblk, bw = P.bw, ng = P.ng, d = P.d, kmax = P.kmax;
   __shared__ unsigned tl[4][RK_CH * (RK_OW + 1)];
   __shared__ int amb[RK_OW][RK_AMB];
-  __shared__ int ublk[RK_OW][RK_UB];
+  __shared__ int ublk[RK_OW][RK_UB], uend[RK_OW][RK_UB];       // unsafe blocks: first entry and end (the block's or its source's)
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int toff = P.tgt_off;
   constexpr int OPW = RK_OW / 4;                     // owners per wave
   const int r0 = bid * RK_OW;
   const size_t plane = (size_t)nblk * R;
@@ -1360,7 +1363,7 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
   {
     // the wave's eight (owner, target) pairs at once: all sixteen row pieces of a K slice are requested before the first is used and the
     // eight xor butterflies interleave (one pair at a time this was eight dependent gather + butterfly latencies: 100 of the kernel's
-    // 123 us at 10k).  Per pair the arithmetic and order of wave_dist64 (target of owner r: gallery row r -- R == ng).
+    // 123 us at 10k).  Per pair the arithmetic and order of wave_dist64 (target of owner r: row r + tgt_off of the other side).
 #pragma unroll
     for (int cc = 0; cc < OPW; ++cc) dt[cc] = 0.0;
     for (int c = lane * 4; c < d; c += 256) {
@@ -1369,7 +1372,7 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
       for (int cc = 0; cc < OPW; ++cc) {
         const int r = min(r0 + OPW * w + cc, R - 1);
         qa[cc] = *reinterpret_cast<const float4 *>(P.own + (size_t)r * d + c);
-        gb[cc] = *reinterpret_cast<const float4 *>(P.other + (size_t)min(r, ng - 1) * d + c);
+        gb[cc] = *reinterpret_cast<const float4 *>(P.other + (size_t)min(r + toff, ng - 1) * d + c);
       }
 #pragma unroll
       for (int cc = 0; cc < OPW; ++cc) {
@@ -1400,6 +1403,9 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
   const int so = t % RK_OW, sb = t / RK_OW;          // scalar tile loads: this thread's owner and block slice (8 slices)
   const bool vec = (R & 3) == 0;                      // 16-byte loads: four consecutive owners per thread, 8 threads per (plane, block) row
   const int vo = 4 * (t & 7), vb = t >> 3;            // ... this thread's first owner and (block, plane) slice: 32 slices
+  for (int src = 0; src < P.nsrc; ++src) {
+  const int sbeg = P.bounds ? P.bounds[src] : 0, send = P.bounds ? P.bounds[src + 1] : ng;
+  const unsigned *__restrict__ keys = P.keys + (size_t)src * 4 * plane;
   for (int c0 = 0; c0 < nblk; c0 += RK_CH) {
     if (vec) {
       uint4 v[RK_CH * 4 / 32];
@@ -1427,10 +1433,10 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
     }
     __syncthreads();
     const int blk = c0 + lane;
-    const int base = blk * bw;
+    const int base = sbeg + blk * bw;
 #pragma unroll
     for (int cc = 0; cc < OPW; ++cc) {
-      const int o = OPW * w + cc, r = r0 + o;
+      const int o = OPW * w + cc, tg = r0 + o + toff;
       const unsigned k3 = tl[3][lane * (RK_OW + 1) + o];
       const bool unsafe = k3 != 0x7F800000u && __uint_as_float(k3 & ~127u) <= hi[cc];
       unsigned kk[3];
@@ -1440,7 +1446,7 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
       for (int pl = 0; pl < 3; ++pl) {
         kk[pl] = tl[pl][lane * (RK_OW + 1) + o];
         const float v = __uint_as_float(kk[pl] & ~127u);
-        const bool valid = kk[pl] != 0x7F800000u && base + (int)(kk[pl] & 127u) != r;      // (the target itself is not counted)
+        const bool valid = kk[pl] != 0x7F800000u && base + (int)(kk[pl] & 127u) != tg;     // (the target itself is not counted)
         const bool dc = valid && v < lo[cc];
         am[pl] = valid && !dc && !(v > hi[cc]) && !unsafe;                                  // (an unsafe block's entries all go to fp64 below)
         any_am |= am[pl];
@@ -1450,7 +1456,7 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
       const unsigned long long um = __ballot(unsafe);
       if (um) {                                                           // wave-uniform, rare
         const int pos = n_ub[cc] + __popcll(um & ((1ull << lane) - 1ull));
-        if (unsafe && pos < RK_UB) ublk[o][pos] = blk;
+        if (unsafe && pos < RK_UB) { ublk[o][pos] = base; uend[o][pos] = min(base + bw, send); }
         n_ub[cc] += __popcll(um);
       }
       if (__ballot(any_am)) {                                             // wave-uniform, rare: entries within eps of the target's distance
@@ -1465,6 +1471,7 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
     }
     __syncthreads();
   }
+  }
   int closer_all[OPW], closer_safe[OPW];
 #pragma unroll
   for (int cc = 0; cc < OPW; ++cc) {
@@ -1477,7 +1484,7 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
   int hit_cnt[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int cc = 0; cc < OPW; ++cc) {
-    const int o = OPW * w + cc, r = r0 + o;
+    const int o = OPW * w + cc, r = r0 + o, tg = r + toff;
     if (r >= R) continue;                                                 // wave-uniform
     if (closer_all[cc] >= kmax) continue;                                 // a miss at every k
     if (n_amb[cc] > RK_AMB || n_ub[cc] > RK_UB) {
@@ -1491,8 +1498,8 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
       // recall_rank_finish_kernel gives it a workgroup of its own.
       int *wk = P.work + (size_t)r * RK_WORK;
       if (lane == 0) { wk[0] = closer_safe[cc]; wk[1] = n_amb[cc]; wk[2] = n_ub[cc]; }
-      if (lane < n_ub[cc]) wk[3 + lane] = ublk[o][lane];
-      if (lane < n_amb[cc]) wk[3 + RK_UB + lane] = amb[o][lane];
+      if (lane < n_ub[cc]) { wk[3 + lane] = ublk[o][lane]; wk[3 + RK_UB + lane] = uend[o][lane]; }
+      if (lane < n_amb[cc]) wk[3 + 2 * RK_UB + lane] = amb[o][lane];
       if (lane == 0) P.flags[1 + atomicAdd(P.flags, 1)] = r | RK_HARD;
       continue;
     }
@@ -1503,7 +1510,7 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
       wave_dist64_x8(q, P.other, jj, d, lane, dd);
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (jj[u] >= 0 && (dd[u] < dt[cc] || (dd[u] == dt[cc] && jj[u] < r))) ++rank;
+        if (jj[u] >= 0 && (dd[u] < dt[cc] || (dd[u] == dt[cc] && jj[u] < tg))) ++rank;
     };
     for (int c0 = 0; c0 < n_amb[cc] && rank < kmax; c0 += 8) {
       int jj[8];
@@ -1512,13 +1519,13 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
       count_group(jj);
     }
     for (int ub = 0; ub < n_ub[cc] && rank < kmax; ++ub) {
-      const int base = ublk[o][ub] * bw;
+      const int base = ublk[o][ub], end = uend[o][ub];
       for (int c0 = 0; c0 < bw && rank < kmax; c0 += 8) {
         int jj[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int j = base + c0 + u;
-          jj[u] = (c0 + u < bw && j < ng && j != r) ? j : -1;
+          jj[u] = (j < end && j != tg) ? j : -1;
         }
         count_group(jj);
       }
@@ -1569,16 +1576,16 @@ __global__ __launch_bounds__(256) void recall_rank_finish_kernel(const RankArgs 
   for (int f = bid; f < n_flagged; f += nbl) {          // uniform for the workgroup; normally few trips
     const int fr = P.flags[1 + f];
     const bool hard = (fr & RK_HARD) != 0;
-    const int r = fr & ~RK_HARD;
+    const int r = fr & ~RK_HARD, tg = r + P.tgt_off;
     const float *q = P.own + (size_t)r * P.d;
-    const double dt = wave_dist64(q, P.other + (size_t)r * P.d, P.d, lane);
+    const double dt = wave_dist64(q, P.other + (size_t)tg * P.d, P.d, lane);
     int cnt = 0, base_rank = 0;
     auto count_group = [&](const int (&jj)[8]) {
       double dd[8];
       wave_dist64_x8(q, P.other, jj, P.d, lane, dd);
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (jj[u] >= 0 && (dd[u] < dt || (dd[u] == dt && jj[u] < r))) ++cnt;
+        if (jj[u] >= 0 && (dd[u] < dt || (dd[u] == dt && jj[u] < tg))) ++cnt;
     };
     if (hard) {
       const int *wk = P.work + (size_t)r * RK_WORK;
@@ -1591,11 +1598,11 @@ __global__ __launch_bounds__(256) void recall_rank_finish_kernel(const RankArgs 
         for (int u = 0; u < 8; ++u) {
           const int e = e0 + u;
           int j = -1;
-          if (e < n_amb) j = wk[3 + RK_UB + e];
+          if (e < n_amb) j = wk[3 + 2 * RK_UB + e];
           else if (e < n_eval) {
             const int x = e - n_amb, ub = x / P.bw;
-            j = wk[3 + ub] * P.bw + (x - ub * P.bw);
-            if (j >= P.ng || j == r) j = -1;
+            j = wk[3 + ub] + (x - ub * P.bw);
+            if (j >= wk[3 + RK_UB + ub] || j == tg) j = -1;
           }
           jj[u] = j;
         }
@@ -1605,7 +1612,7 @@ __global__ __launch_bounds__(256) void recall_rank_finish_kernel(const RankArgs 
       for (int j0 = 8 * w; j0 < P.ng; j0 += 32) {
         int jj[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) jj[u] = (j0 + u < P.ng && j0 + u != r) ? j0 + u : -1;
+        for (int u = 0; u < 8; ++u) jj[u] = (j0 + u < P.ng && j0 + u != tg) ? j0 + u : -1;
         count_group(jj);
       }
     }
@@ -1697,10 +1704,10 @@ int recall_bidir_impl(const float *a, const float *b, int n, int d, const int *k
   if (int rc = launch_gemm(s.qb, s.gb, nullptr, nullptr, n, n, d, VTC_BF16, e, stream)) return rc;
   const float kappa = exact2_kappa(d);
   int kmax = 0;
-  static_assert(RK_WORK * sizeof(int) <= CD2 * sizeof(int64_t) && 3 + RK_UB + RK_AMB <= RK_WORK, "a deferred row's lists fit its candidate-list slot");
+  static_assert(RK_WORK * sizeof(int) <= CD2 * sizeof(int64_t) && 3 + 2 * RK_UB + RK_AMB <= RK_WORK, "a deferred row's lists fit its candidate-list slot");
   const int nwg = cdiv(n, RK_OW);            // (4 ints per workgroup in the cand_n arrays: n / 8 <= n)
-  RankArgs r1{s.rowk, n, s.nblk_c, 64, b, a, n, d, s.qn, s.qst, s.gmax, kappa, 0, nk, {0, 0, 0, 0}, hits_b_from_a, s.flags, (int *)s.cand, s.cand_n, nwg};
-  RankArgs r2{s.colk, n, s.nblk_r, s.rb, a, b, n, d, s.gn, s.gst, s.qmax, kappa, 0, nk, {0, 0, 0, 0}, hits_a_from_b, s.flags2, (int *)s.cand2, s.cand2_n, nwg};
+  RankArgs r1{s.rowk, n, s.nblk_c, 64, 1, nullptr, 0, b, a, n, d, s.qn, s.qst, s.gmax, kappa, 0, nk, {0, 0, 0, 0}, hits_b_from_a, s.flags, (int *)s.cand, s.cand_n, nwg};
+  RankArgs r2{s.colk, n, s.nblk_r, s.rb, 1, nullptr, 0, a, b, n, d, s.gn, s.gst, s.qmax, kappa, 0, nk, {0, 0, 0, 0}, hits_a_from_b, s.flags2, (int *)s.cand2, s.cand2_n, nwg};
   for (int i = 0; i < nk; ++i) { r1.k[i] = r2.k[i] = k_vals[i]; kmax = std::max(kmax, k_vals[i]); }
   r1.kmax = r2.kmax = kmax;
   {
@@ -1772,6 +1779,91 @@ extern "C" int vtc_l2_sweep_shard_cols(const float *b_all, const float *a_local,
   const Rescan rs{planes, n_local, n_src * nblk_pad, rb, nblk_pad, n_src, src_base, s.theta};
   return exact_finish(b_all, a_local, n_total, n_local, d, depth, CD2, s.cand, nullptr, s.qn, s.gn, s.gmax, s.flags, ids, dists, stream,
                       s.cand_n, &s.fb, &rs);
+}
+
+// ---- the same exchange with the recall-only finish (round 5): hit counters instead of sorted lists ---------------------------
+// One direction of recall_rank_kernel + recall_rank_finish_kernel (the second argument block is not used: every workgroup is "first").
+static void launch_rank_one(const RankArgs &r, hipStream_t stream) {
+  {
+    ProfScope prof(VTC_PROF_TOPK, (double)L2MIN_PLANES * r.nsrc * r.nblk * r.R * 4 + 2.0 * r.R * r.d * 4, stream);
+    const int nb = cdiv(r.R, RK_OW);
+    hipLaunchKernelGGL(recall_rank_kernel, dim3(nb), dim3(256), 0, stream, r, r, nb);
+  }
+  {
+    ProfScope prof(VTC_PROF_TOPK, 0.0, stream);
+    const int g = std::min(r.R, 1024);
+    hipLaunchKernelGGL(recall_rank_finish_kernel, dim3(g), dim3(256), 0, stream, r, r, g);
+  }
+}
+
+static int fill_k(RankArgs &r, const int *k_vals, int nk) {
+  r.nk = nk; r.kmax = 0;
+  for (int i = 0; i < 4; ++i) r.k[i] = 0;
+  for (int i = 0; i < nk; ++i) { r.k[i] = k_vals[i]; r.kmax = std::max(r.kmax, k_vals[i]); }
+  return r.kmax;
+}
+
+extern "C" int vtc_l2_recall_shard_supported(int n_total, int n_local, int d) {
+  return d > 0 && d % 64 == 0 && n_local >= 1 && n_local <= n_total && exact2_enabled(n_total, n_local, 1);
+}
+
+extern "C" int vtc_l2_recall_shard_rows(const float *a_all, const float *b_local, int n_total, int n_local, int row_base, int d,
+                                        const int *k_vals, int nk, long long *hits_b_from_a, unsigned *col_planes, int nblk_pad, void *ws,
+                                        size_t ws_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VTC_CHECK(a_all && b_local && k_vals && hits_b_from_a && col_planes && ws, "l2_recall_shard_rows: null argument");
+  VTC_CHECK(vtc_l2_recall_shard_supported(n_total, n_local, d), "l2_recall_shard_rows: unsupported shape (n_total=%d n_local=%d d=%d)", n_total, n_local, d);
+  VTC_CHECK(row_base >= 0 && row_base + n_local <= n_total, "l2_recall_shard_rows: rows [%d, %d) outside [0, %d)", row_base, row_base + n_local, n_total);
+  VTC_CHECK(nk >= 1 && nk <= 4, "l2_recall_shard_rows: nk=%d must be in 1..4", nk);
+  for (int i = 0; i < nk; ++i) VTC_CHECK(k_vals[i] >= 1 && k_vals[i] <= n_total, "l2_recall_shard_rows: k=%d must be in 1..%d", k_vals[i], n_total);
+  Sweep2Ws s = plan2((char *)ws, n_total, n_local, d, false);
+  VTC_CHECK(nblk_pad >= s.nblk_r, "l2_recall_shard_rows: nblk_pad=%d < %d row blocks", nblk_pad, s.nblk_r);
+  VTC_CHECK(ws_bytes >= vtc_l2_sweep_shard_workspace_bytes(n_total, n_local, d), "l2_recall_shard_rows: workspace too small");
+  {
+    ProfScope prof(VTC_PROF_TOPK, (double)(n_total + n_local) * d * 6, stream);
+    const PrepSide A{b_local, s.qb, s.qn, s.qst, s.qmax, n_local}, B{a_all, s.gb, s.gn, s.gst, s.gmax, n_total};
+    launch_sweep_prep(A, B, d, s.pmax, stream, s.flags, nullptr);
+  }
+  VTC_LAUNCH_CHECK("l2_recall_shard_rows prologue");
+  GemmEpi e;
+  e.mode = EPI_L2MIN; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
+  e.rowk = s.rowk; e.colk = col_planes; e.nblk_c = s.nblk_c; e.nblk_r = nblk_pad; e.rb = s.rb;
+  for (int pl = 0; pl < L2MIN_PLANES && nblk_pad > s.nblk_r; ++pl)     // blocks this rank has no rows for (shards differ by a row): +inf keys
+    (void)hipMemsetD32Async((hipDeviceptr_t)(col_planes + ((size_t)pl * nblk_pad + s.nblk_r) * n_total), 0x7F800000,
+                            (size_t)(nblk_pad - s.nblk_r) * n_total, stream);
+  if (int rc = launch_gemm(s.qb, s.gb, nullptr, nullptr, n_local, n_total, d, VTC_BF16, e, stream)) return rc;
+  RankArgs r{s.rowk, n_local, s.nblk_c, 64, 1, nullptr, row_base, b_local, a_all, n_total, d, s.qn, s.qst, s.gmax, exact2_kappa(d), 0, nk, {0, 0, 0, 0},
+             (unsigned long long *)hits_b_from_a, s.flags, (int *)s.cand, s.cand_n, cdiv(n_local, RK_OW)};
+  fill_k(r, k_vals, nk);
+  launch_rank_one(r, stream);
+  VTC_LAUNCH_CHECK("l2_recall_shard_rows");
+  return 0;
+}
+
+extern "C" int vtc_l2_recall_shard_cols(const float *b_all, const float *a_local, int n_total, int n_local, int row_base, int d,
+                                        const int *k_vals, int nk, const unsigned *planes, int n_src, int nblk_pad, const int *src_bounds,
+                                        long long *hits_a_from_b, void *ws, size_t ws_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VTC_CHECK(b_all && a_local && k_vals && planes && src_bounds && hits_a_from_b && ws, "l2_recall_shard_cols: null argument");
+  VTC_CHECK(vtc_l2_recall_shard_supported(n_total, n_local, d) && n_src >= 1 && nblk_pad >= 1,
+            "l2_recall_shard_cols: unsupported shape (n_total=%d n_local=%d d=%d n_src=%d)", n_total, n_local, d, n_src);
+  VTC_CHECK(row_base >= 0 && row_base + n_local <= n_total, "l2_recall_shard_cols: rows [%d, %d) outside [0, %d)", row_base, row_base + n_local, n_total);
+  VTC_CHECK(nk >= 1 && nk <= 4, "l2_recall_shard_cols: nk=%d must be in 1..4", nk);
+  for (int i = 0; i < nk; ++i) VTC_CHECK(k_vals[i] >= 1 && k_vals[i] <= n_total, "l2_recall_shard_cols: k=%d must be in 1..%d", k_vals[i], n_total);
+  VTC_CHECK(ws_bytes >= vtc_l2_sweep_shard_workspace_bytes(n_total, n_local, d), "l2_recall_shard_cols: workspace too small");
+  // owners = a_local (this rank's columns of every source's GEMM), the other side = b_all: the plan's areas fit as they are
+  Sweep2Ws s = plan2((char *)ws, n_total, n_local, d, false);
+  {   // statistics only (the operands were rounded by the ranks that ran the GEMMs -- with this same rounding)
+    ProfScope prof(VTC_PROF_TOPK, (double)(n_total + n_local) * d * 4, stream);
+    const PrepSide A{a_local, nullptr, s.qn, s.qst, s.qmax, n_local}, B{b_all, nullptr, s.gn, s.gst, s.gmax, n_total};
+    launch_sweep_prep(A, B, d, s.pmax, stream, s.flags, nullptr);
+  }
+  RankArgs r{planes, n_local, nblk_pad, vtc_l2_sweep_row_block(), n_src, src_bounds, row_base, a_local, b_all, n_total, d, s.qn, s.qst, s.gmax,
+             exact2_kappa(d), 0, nk, {0, 0, 0, 0}, (unsigned long long *)hits_a_from_b, s.flags, (int *)s.cand, s.cand_n, cdiv(n_local, RK_OW)};
+  fill_k(r, k_vals, nk);
+  launch_rank_one(r, stream);
+  VTC_LAUNCH_CHECK("l2_recall_shard_cols");
+  return 0;
 }
 
 // diagnostics (tests/probes/sweep_v2_debug.py; not part of the public header): the raw block-minima planes of one distance GEMM.

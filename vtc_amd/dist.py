@@ -121,7 +121,18 @@ def one_matrix_sharded(n_total: int, precision: int, world: int, depth: int) -> 
                for lo, hi in (shard_bounds(n_total, r, world) for r in range(world)))
 
 
-def sweep_path(n_total: int, precision: int, world: int, depth: int = 11) -> str:
+def rank_sharded(n_total: int, d: int, precision: int, world: int, nk: int = 3) -> bool:
+    """True when world > 1 ranks take the one-GEMM-per-rank path with the recall-only finish (hit counters from the ranks of the paired
+    rows: no sorted lists; VTC_SWEEP_RANK=0 or VTC_SWEEP_SHARD_TWO=1 turn it off)."""
+    if world <= 1 or precision != 3 or not RANK_PATH or nk > 4 or os.environ.get("VTC_SWEEP_SHARD_TWO") == "1":
+        return False
+    from . import ops
+    return all(ops.recall_shard_supported(n_total, hi - lo, d) for lo, hi in (shard_bounds(n_total, r, world) for r in range(world)))
+
+
+def sweep_path(n_total: int, precision: int, world: int, depth: int = 11, d: int = 512) -> str:
+    if world > 1 and rank_sharded(n_total, d, precision, world):
+        return "one [N/G, N] distance GEMM per rank, column block minima exchanged (all-to-all), ranks of the paired rows (no sorted lists)"
     if world > 1:
         return ("one [N/G, N] distance GEMM per rank, column block minima exchanged (all-to-all)"
                 if one_matrix_sharded(n_total, precision, world, depth) else "two searches per rank ([N/G, N] blocks)")
@@ -202,7 +213,8 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
                    precision: int = 3,    # _lib.SWEEP_EXACT
                    ws: Optional[torch.Tensor] = None,
                    shard_ops: Optional[tuple] = None,
-                   phases: Optional[dict] = None):
+                   phases: Optional[dict] = None,
+                   rank_ops: Optional[tuple] = None):
     """R@K both directions for row-sharded embeddings.
 
     Returns ({k: recall b_from_a-direction as RecallAtK.compute(a, b)}, {k: compute(b, a)}).
@@ -210,7 +222,8 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
     exercise the sharding logic under gloo.  ``ws``: a caller-owned uint8 workspace reused across calls (grown by the
     ops layer when too small).  ``shard_ops = (rows_fn, cols_fn, row_block)``: stand-ins for ops.sweep_shard_rows /
     ops.sweep_shard_cols (tests: the one-GEMM-per-rank exchange under gloo).  ``phases``: a dict that receives this rank's
-    GPU time per phase in ms (HIP events on the launch stream: allgather / rows_gemm_select / alltoall / cols_select /
+    ``rank_ops = (rows_fn, cols_fn, row_block)``: stand-ins for ops.recall_shard_rows / ops.recall_shard_cols (the same exchange with the
+    recall-only finish: hit counters, no ids).  GPU time per phase in ms (HIP events on the launch stream: allgather / rows_gemm_select / alltoall / cols_select /
     search_a / search_b / hits / allreduce) and the path taken -- what a scaling run is read from."""
     lo, hi = shard_bounds(n_total, rank, world)
     marks = []
@@ -263,6 +276,36 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
         i1, _, i2, _ = ops.l2_topk_bidir(a_all, b_all, depth, precision=precision, return_dists=False, ws=ws)
         both = (i1, i2)
         mark("bidir_gemm_select")
+    if (world > 1 and (rank_ops is not None or (hip_sweep and shard_ops is None and feats_a_local.shape[1] == feats_b_local.shape[1]
+                                                  and rank_sharded(n_total, feats_a_local.shape[1], precision, world, len(ks))))):
+        # one [N/G, N] GEMM per rank, recall-only finish: this rank's hit counters of the row direction come with the GEMM, the column
+        # block minima go to the column owners, whose rank launch counts the other direction
+        injected = rank_ops is not None
+        if rank_ops is None:
+            from . import ops
+            rank_ops = (lambda a_, b_, base, ks_, nbp, h: ops.recall_shard_rows(a_, b_, base, ks_, nbp, h, ws=ws),
+                        lambda b_, a_, base, ks_, pl, sb, h: ops.recall_shard_cols(b_, a_, base, ks_, pl, sb, h, ws=ws), ops.sweep_row_block())
+        rows_fn, cols_fn, rb = rank_ops
+        bounds = [shard_bounds(n_total, r, world) for r in range(world)]
+        nblk_pad = -(-max(h - l for l, h in bounds) // rb)
+        planes = rows_fn(a_all, feats_b_local, lo, ks, nblk_pad, hits[0])
+        mark("rows_gemm_rank")
+        recv = exchange_column_planes(planes, n_total, rank, world)
+        mark("alltoall")
+        src_bounds = torch.tensor([l for l, _ in bounds] + [n_total], dtype=torch.int32, device=planes.device)
+        cols_fn(b_all, feats_a_local, lo, ks, recv, src_bounds, hits[1])
+        mark("cols_rank")
+        dist.all_reduce(hits, op=dist.ReduceOp.SUM)
+        mark("allreduce")
+        hits = hits.cpu()
+        if marks:
+            for (_, e0), (name, e1) in zip(marks, marks[1:]):
+                phases[name + "_ms"] = round(phases.get(name + "_ms", 0.0) + e0.elapsed_time(e1), 4)
+        if phases is not None:
+            phases["path"] = sweep_path(n_total, precision, world, depth, feats_a_local.shape[1]) if not injected else "injected rank ops"
+            phases["exchange"] = (f"all_to_all{'' if A2A_MODE == 'list' else '_single'} (RCCL)" if dist.get_backend() == "nccl"
+                                  else f"all_to_all_single through host memory ({dist.get_backend()})")
+        return ({k: hits[0, j].item() / n_total for j, k in enumerate(k_vals)}, {k: hits[1, j].item() / n_total for j, k in enumerate(k_vals)})
     if both is None and world > 1 and (shard_ops is not None or (hip_sweep and one_matrix_sharded(n_total, precision, world, depth))):
         # one [N/G, N] GEMM per rank: rows finished locally, column block minima to the column owners
         if shard_ops is None:

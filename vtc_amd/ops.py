@@ -340,6 +340,52 @@ def recall_bidir(a: torch.Tensor, b: torch.Tensor, k_vals: Sequence[int], ws: Op
     return hits
 
 
+def recall_shard_supported(n_total: int, n_local: int, d: int) -> bool:
+    return bool(L.lib().vtc_l2_recall_shard_supported(int(n_total), int(n_local), int(d)))
+
+
+@on_device
+def recall_shard_rows(a_all: torch.Tensor, b_local: torch.Tensor, row_base: int, k_vals: Sequence[int], nblk_pad: int, hits: torch.Tensor,
+                      ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Rank-local half of the sharded sweep with the recall-only finish (vtc_l2_recall_shard_rows): hits [nk] int64 += this rank's
+    counters of RecallAtK.compute(a, b); returns col_planes [4, nblk_pad, n_total] (int32 tensor) for the exchange."""
+    a_all, b_local = _gpu(a_all, torch.float32, "a_all"), _gpu(b_local, torch.float32, "b_local")
+    n, d = a_all.shape
+    nl = b_local.shape[0]
+    assert hits.shape == (len(k_vals),) and hits.dtype == torch.int64 and hits.is_contiguous() and hits.device == a_all.device
+    need = L.lib().vtc_l2_sweep_shard_workspace_bytes(n, nl, d)
+    if ws is None or ws.numel() < need or ws.device != a_all.device:
+        ws = workspace(need, a_all.device)
+    planes = torch.empty(4, nblk_pad, n, dtype=torch.int32, device=a_all.device)
+    ks = (C.c_int * len(k_vals))(*[int(k) for k in k_vals])
+    L.check(L.lib().vtc_l2_recall_shard_rows(a_all.data_ptr(), b_local.data_ptr(), n, nl, int(row_base), d, ks, len(k_vals), hits.data_ptr(),
+                                             planes.data_ptr(), nblk_pad, ws.data_ptr(), ws.numel(), _stream()), "vtc_l2_recall_shard_rows")
+    return planes
+
+
+@on_device
+def recall_shard_cols(b_all: torch.Tensor, a_local: torch.Tensor, row_base: int, k_vals: Sequence[int], planes: torch.Tensor,
+                      src_bounds: torch.Tensor, hits: torch.Tensor, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Second half, after the exchange: planes [n_src, 4, nblk_pad, n_local] int32, src_bounds [n_src + 1] int32 (device); hits [nk] int64
+    += this rank's counters of RecallAtK.compute(b, a)."""
+    b_all, a_local = _gpu(b_all, torch.float32, "b_all"), _gpu(a_local, torch.float32, "a_local")
+    planes, src_bounds = _gpu(planes, torch.int32, "planes"), _gpu(src_bounds, torch.int32, "src_bounds")
+    n, d = b_all.shape
+    nl = a_local.shape[0]
+    n_src, four, nblk_pad, nl2 = planes.shape
+    if four != 4 or nl2 != nl or src_bounds.numel() != n_src + 1:
+        raise ValueError(f"recall_shard_cols: planes {tuple(planes.shape)} / src_bounds {tuple(src_bounds.shape)} do not match n_local={nl}")
+    assert hits.shape == (len(k_vals),) and hits.dtype == torch.int64 and hits.is_contiguous() and hits.device == b_all.device
+    need = L.lib().vtc_l2_sweep_shard_workspace_bytes(n, nl, d)
+    if ws is None or ws.numel() < need or ws.device != b_all.device:
+        ws = workspace(need, b_all.device)
+    ks = (C.c_int * len(k_vals))(*[int(k) for k in k_vals])
+    L.check(L.lib().vtc_l2_recall_shard_cols(b_all.data_ptr(), a_local.data_ptr(), n, nl, int(row_base), d, ks, len(k_vals), planes.data_ptr(),
+                                             n_src, nblk_pad, src_bounds.data_ptr(), hits.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+            "vtc_l2_recall_shard_cols")
+    return hits
+
+
 @on_device
 def recall_hits_pair(ids_a: torch.Tensor, ids_b: torch.Tensor, k_vals: Sequence[int], target_offset: int, hits: torch.Tensor) -> torch.Tensor:
     """hits[0] += hits of ids_a, hits[1] += hits of ids_b (both [n, depth], same targets): one launch for both directions."""

@@ -29,6 +29,8 @@ struct P {
   unsigned short *hi, *lo;
   int M, W, MT, NT;
   int gap_ticks;      // s_memrealtime ticks (100 MHz) spent per tile before its update: the K loop's stand-in
+  int prefetch;       // 1: at the START of the gap every wave touches one dword per 128-byte line of the (hi, lo) rows it is about to update
+                      // (4 loads per wave: lane = row), so that the lines are on their way to L2 / Infinity Cache while the "K loop" runs
 };
 
 template <int PAT, int ST, int XD>
@@ -61,9 +63,23 @@ __global__ __launch_bounds__(512, 2) void resid_kernel(P p) {
       const int gsz = min(SUPER, p.MT - sr * SUPER);
       const int nt = rem / gsz;
       const int m0 = (sr * SUPER + (rem - nt * gsz)) * 256, n0 = nt * 256;
+      unsigned pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0;
+      if (p.prefetch) {
+        const int wr = wave >> 2, wc = wave & 3;
+        const size_t o = (size_t)(m0 + wr * 128 + lane) * p.W + n0 + wc * 64;
+        const unsigned short *a0 = p.hi + o, *a1 = p.hi + o + (size_t)64 * p.W, *a2 = p.lo + o, *a3 = p.lo + o + (size_t)64 * p.W;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pf0) : "v"(a0) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pf1) : "v"(a1) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pf2) : "v"(a2) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pf3) : "v"(a3) : "memory");
+      }
       if (p.gap_ticks > 0) {
         const long long t_end = (long long)__builtin_amdgcn_s_memrealtime() + p.gap_ticks;
         while ((long long)__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(4);
+      }
+      if (p.prefetch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));
       }
       if constexpr (PAT == 0) {
         // wave = rows wr*128.., columns wc*64..; pass i = 16 rows; k = 4 row groups of 4 rows; 8 B per lane
@@ -159,14 +175,15 @@ static double run(F launch) {
 
 #define RUN(PAT, ST, XD, gap, label)                                                                                              \
   do {                                                                                                                            \
-    p.gap_ticks = gap;                                                                                                            \
+    p.gap_ticks = gap; p.prefetch = PFV;                                                                                          \
     const double t = run([&] { hipLaunchKernelGGL((resid_kernel<PAT, ST, XD>), dim3(cus), dim3(512), 0, 0, p); });                 \
-    printf("P%d %-44s st=%d depth=%d gap=%4.1f us : %7.1f us  %5.2f TB/s   (per tile round %.1f us)\n", PAT, label, ST, XD, gap * 0.01, t * 1e6,            \
+    printf("P%d %-44s st=%d depth=%d pf=%d gap=%4.1f us : %7.1f us  %5.2f TB/s   (per tile round %.1f us)\n", PAT, label, ST, XD, PFV, gap * 0.01, t * 1e6,            \
            moved / t / 1e12, t * 1e6 / rounds);                                                                                   \
     fflush(stdout);                                                                                                               \
   } while (0)
 
 int main() {
+  int PFV = 0;
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
   const int cus = prop.multiProcessorCount;
@@ -195,7 +212,11 @@ int main() {
   RUN(2, 1, 3, 0, "16 B/lane, 2 rows x 512 B");
   RUN(2, 2, 3, 0, "16 B/lane, 2 rows x 512 B");
   // with the K loop's stand-in: ~21 us per tile (the out-proj's 12 K-tiles), ~10 us, ~40 us
-  for (int gap : {1000, 2100, 4000}) {
+  for (int gap : {1000, 1700, 2100, 4000}) {
+    PFV = 1;
+    RUN(0, 0, 2, gap, "epilogue shape, lines touched at gap start");
+    RUN(0, 0, 3, gap, "epilogue shape, lines touched at gap start");
+    PFV = 0;
     RUN(0, 0, 2, gap, "epilogue shape (8 B/lane, 4 rows x 128 B)");
     RUN(1, 0, 2, gap, "16 B/lane, 8 rows x 128 B");
     RUN(2, 0, 3, gap, "16 B/lane, 2 rows x 512 B");

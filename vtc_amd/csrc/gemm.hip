@@ -846,9 +846,33 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(GemmParams p) {
     }
     return false;
   };
-  stage_ahead(0, 0);
-  if (NSTAGE == 3 && stage_ahead(0, 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // `ahead` = slabs in flight or landed BEHIND the one being multiplied (<= NSTAGE - 1).  A wait that must be sure of the next slab may
+  // leave the ahead - 1 slabs issued after it in flight (vmcnt is in order): NSTAGE - 2 slabs of LDS-DMA cover the L2 / HBM round trip
+  // of these launches, whose time is one tile's serial K loop (2 - 5 stages; the 64 x 64 configuration runs 3).
+  auto wait_all_but = [&](int slabs) {       // uniform; slabs <= NSTAGE - 2
+    if constexpr (NSTAGE >= 3) {
+      if (slabs >= 1) {
+        if constexpr (NSTAGE >= 4) {
+          if (slabs >= 2) {
+            if constexpr (NSTAGE >= 5) {
+              if (slabs >= 3) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * G) : "memory"); return; }
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+            return;
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        return;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  static_assert(NSTAGE >= 2 && NSTAGE <= 5 && 3 * G <= 63, "stages / counted waits");
+  int ahead = -1;
+#pragma unroll
+  for (int d = 0; d < NSTAGE - 1; ++d)
+    if (stage_ahead(0, d)) ++ahead;
+  wait_all_but(ahead);                       // slab 0 has landed
   __syncthreads();
 
   while (true) {
@@ -900,9 +924,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(GemmParams p) {
           for (int j = 0; j < TN; ++j) Mma<T>::run(wf[j], aO, acc[i + 1][j]);
         }
       }
-      // the next slab must have landed; with 3 stages the slab issued in this step may stay in flight
-      if (NSTAGE == 3 && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (issued) ++ahead;
+      wait_all_but(ahead - 1);               // the next slab has landed; the slabs issued after it may stay in flight
+      --ahead;
       __syncthreads();
       cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
@@ -1397,6 +1421,7 @@ int run(GemmParams p, hipStream_t stream) {
   p.MT = cdiv(p.M, BM); p.NT = cdiv(p.N, BN);
   const int ntiles = p.MT * p.NT;
   const size_t shmem = (size_t)NSTAGE * (BM + BN) * ROWB;
+  if (p.K / Mma<T>::KPR < NSTAGE - 1) { vtc_set_error("gemm: K=%d is too short for %d stages", p.K, NSTAGE); return 1; }
   const int wg_per_cu = shmem > 80 * 1024 ? 1 : 2;
   const int grid = min(ntiles, num_cus() * wg_per_cu);
   static PerDeviceOnce attr;
@@ -1459,9 +1484,15 @@ int run_cfg(const GemmParams &p, hipStream_t stream) {
   // on the chip -- these launches are bounded by one tile's serial K loop, not by throughput
   const long ts128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
 #ifndef VTC_SMALL_NSTAGE
-#define VTC_SMALL_NSTAGE 3      // LDS stages of the 64 x 64 configuration: two K-steps of LDS-DMA in flight (these launches are one tile's serial K loop: B = 1 forward 2.36 -> 1.98 ms; 2 = round 2)
+#define VTC_SMALL_NSTAGE 3      // LDS stages of the 64 x 64 configuration: two K-steps of LDS-DMA in flight (these launches are one tile's serial K loop: B = 1 forward 2.36 -> 1.98 ms from 2 to 3 stages in round 2; 5 stages, round 5: no further gain -- 1.83 against 1.78 - 1.80 ms, profiles/r05_experiments.txt 8)
 #endif
-  if ((ts128 * 2 <= num_cus() && g_force_tile == 0) || g_force_tile == 5) return run<T, MODE, OutT, 2, 1, 2, 4, VTC_SMALL_NSTAGE>(p, stream);
+  if ((ts128 * 2 <= num_cus() && g_force_tile == 0) || g_force_tile == 5) {
+    // the slabs staged ahead may reach into the NEXT tile but not beyond it: a K loop of ksteps slabs carries at most ksteps + 1 stages
+    const int ksteps = p.K / Mma<T>::KPR;
+    if (ksteps >= VTC_SMALL_NSTAGE - 1) return run<T, MODE, OutT, 2, 1, 2, 4, VTC_SMALL_NSTAGE>(p, stream);
+    if (ksteps >= 2) return run<T, MODE, OutT, 2, 1, 2, 4, 3>(p, stream);
+    return run<T, MODE, OutT, 2, 1, 2, 4, 2>(p, stream);
+  }
   return run<T, MODE, OutT, 2, 2, 4, 4, 2>(p, stream);
 }
 

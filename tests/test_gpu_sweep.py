@@ -574,3 +574,63 @@ def test_rank_sharded_sweep_at_50k_equals_the_single_gpu_counters():
     one = ops.recall_bidir(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), [1, 5, 10]).cpu().numpy()
     assert np.array_equal(got, one), (got.tolist(), one.tolist())
     assert 0.02 * 50000 < got[0][0] < 0.9999 * 50000
+
+
+def test_rank_path_random_shapes_single_and_sharded():
+    """Seeded random (n, d, k set, world): odd row counts (scalar plane loads), k up to 200 (beyond the 64 of the sorted-list form), duplicates,
+    un-normalised rows -- vtc_l2_recall_bidir and the summed counters of the sharded form both equal the fp64 oracle's."""
+    from vtc_amd import ops
+    rng = np.random.default_rng(4242)
+    for case in range(8):
+        n = int(rng.integers(1024, 7000))
+        d = int(rng.choice([64, 128, 512, 768]))
+        world = int(rng.integers(2, 7))
+        ks = sorted(int(k) for k in rng.choice([1, 2, 3, 5, 10, 17, 64, 65, 200], size=int(rng.integers(1, 5)), replace=False))
+        a, b = planted(n, d, seed=3000 + case, noise=float(rng.choice([0.3, 0.8, 2.0, 6.0])))
+        if case % 3 == 1:
+            a[n // 3:n // 3 + 30] = a[5]                    # duplicates of an early row: ties broken by the lowest index
+        if case % 3 == 2:
+            sc = rng.uniform(0.5, 20.0, (n, 1)).astype(np.float32)
+            a, b = (a * sc).astype(np.float32), (b * sc).astype(np.float32)
+        ref = _hits_ref(a, b, ks)
+        one = ops.recall_bidir(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), ks).cpu().numpy()
+        assert np.array_equal(one, ref), (case, n, d, ks, one.tolist(), ref.tolist())
+        got = _play_rank_sharded(a, b, world, ks)
+        assert np.array_equal(got, ref), (case, n, d, world, ks, got.tolist(), ref.tolist())
+
+
+def test_recall_entry_points_refuse_what_they_do_not_cover():
+    """include/vtc_hip.h: n >= 1024, d % 64 == 0, 1 <= nk <= 4, 1 <= k <= n, rows inside the gathered set -- refused with a message, nothing launched."""
+    import ctypes as C
+    from vtc_amd import _lib as L
+    lib = L.lib()
+    assert lib.vtc_l2_recall_bidir_supported(1023, 512) == 0 and lib.vtc_l2_recall_bidir_supported(1024, 500) == 0
+    assert lib.vtc_l2_recall_bidir_supported(1024, 512) == 1
+    assert lib.vtc_l2_recall_shard_supported(4096, 512, 512) == 1 and lib.vtc_l2_recall_shard_supported(4096, 0, 512) == 0
+    assert lib.vtc_l2_recall_shard_supported(1000, 500, 512) == 0 and lib.vtc_l2_recall_shard_supported(4096, 512, 96) == 0
+    n, d = 2048, 64
+    a = torch.randn(n, d, device="cuda")
+    b = torch.randn(n, d, device="cuda")
+    hits = torch.zeros(2, 4, dtype=torch.int64, device="cuda")
+    ws = torch.empty(int(lib.vtc_l2_recall_bidir_workspace_bytes(n, d)), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+
+    def call(ks, nk=None, ws_bytes=None):
+        arr = (C.c_int * max(1, len(ks)))(*ks)
+        return lib.vtc_l2_recall_bidir(a.data_ptr(), b.data_ptr(), n, d, arr, len(ks) if nk is None else nk, hits[0].data_ptr(), hits[1].data_ptr(),
+                                       ws.data_ptr(), ws.numel() if ws_bytes is None else ws_bytes, s)
+    assert call([1, 5, 10]) == 0
+    for bad in (dict(ks=[0]), dict(ks=[n + 1]), dict(ks=[1, 2, 3, 4, 5]), dict(ks=[1], nk=0), dict(ks=[1], ws_bytes=1024)):
+        assert call(**bad) != 0, bad
+        assert lib.vtc_last_error(), bad
+    torch.cuda.synchronize()
+    planes = torch.empty(4, 2, n, dtype=torch.int32, device="cuda")
+    ws2 = torch.empty(int(lib.vtc_l2_sweep_shard_workspace_bytes(n, 256, d)), dtype=torch.uint8, device="cuda")
+    arr = (C.c_int * 1)(1)
+    rc = lib.vtc_l2_recall_shard_rows(a.data_ptr(), b[:256].contiguous().data_ptr(), n, 256, n - 100, d, arr, 1, hits[0].data_ptr(), planes.data_ptr(), 2,
+                                      ws2.data_ptr(), ws2.numel(), s)
+    assert rc != 0 and b"outside" in lib.vtc_last_error()
+    rc = lib.vtc_l2_recall_shard_rows(a.data_ptr(), b[:256].contiguous().data_ptr(), n, 256, 0, d, arr, 1, hits[0].data_ptr(), planes.data_ptr(), 1,
+                                      ws2.data_ptr(), ws2.numel(), s)
+    assert rc != 0 and b"nblk_pad" in lib.vtc_last_error()
+    torch.cuda.synchronize()

@@ -417,7 +417,8 @@ def test_sharded_recall_world_1_equals_recallatk_compute_both(n):
     c_ab, c_ba = m.compute_both(ta, tb)
     assert r_ab == dict(c_ab) and r_ba == dict(c_ba)
     assert r_ab == dict(E.recall_at_k(a, b, [1, 5, 10], np.float64)) and r_ba == dict(E.recall_at_k(b, a, [1, 5, 10], np.float64))
-    assert ph["path"].startswith("one distance matrix" if n >= min(vdist.BIDIR_MIN_ROWS, vdist.RANK_MIN_ROWS) else "two searches")
+    one_matrix_from = min(vdist.BIDIR_MIN_ROWS, vdist.RANK_MIN_ROWS) if vdist.RANK_PATH else vdist.BIDIR_MIN_ROWS       # (VTC_SWEEP_RANK=0: sorted lists)
+    assert ph["path"].startswith("one distance matrix" if n >= one_matrix_from else "two searches")
     assert vdist.RANK_MIN_ROWS == m.rank_min_rows
     assert vdist.BIDIR_MIN_ROWS == m.bidir_min_rows and vdist.BIDIR_MIN_ROWS_F32 == m.bidir_min_rows_f32
 

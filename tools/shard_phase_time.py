@@ -49,15 +49,17 @@ def main():
         hits = torch.zeros(2, 3, dtype=torch.int64, device="cuda")
         planes = [ops.recall_shard_rows(ta, tb[l:h].contiguous(), l, ks, nbp, hits[0], ws=ws) for l, h in bounds]
         recv = torch.stack([pl[:, :, lo:hi] for pl in planes]).contiguous()
+        planes4 = [ops.sweep_shard_rows(ta, tb[l:h].contiguous(), depth, nbp, ws=ws)[1] for l, h in bounds]      # the sorted-list form's four planes
+        recv4 = torch.stack([pl[:, :, lo:hi] for pl in planes4]).contiguous()
         sb = torch.tensor([l for l, _ in bounds], dtype=torch.int32, device="cuda")
         sbn = torch.tensor([l for l, _ in bounds] + [n], dtype=torch.int32, device="cuda")
         out = {
             "rows_gemm_select (sorted lists)": timed(lambda: ops.sweep_shard_rows(ta, bl, depth, nbp, ws=ws)),
-            "cols_select (sorted lists)": timed(lambda: ops.sweep_shard_cols(tb, al, depth, recv, sb, ws=ws)),
+            "cols_select (sorted lists)": timed(lambda: ops.sweep_shard_cols(tb, al, depth, recv4, sb, ws=ws)),
             "rows_gemm_rank (recall only)": timed(lambda: ops.recall_shard_rows(ta, bl, lo, ks, nbp, hits[0], ws=ws)),
             "cols_rank (recall only)": timed(lambda: ops.recall_shard_cols(tb, al, lo, ks, recv, sbn, hits[1], ws=ws)),
         }
-        print(f"N={n} G={G} (rank 0: {hi - lo} rows; planes to exchange {4 * nbp * n * 4 / 1e6:.2f} MB per rank): "
+        print(f"N={n} G={G} (rank 0: {hi - lo} rows; planes to exchange {planes[0].shape[0] * nbp * n * 4 / 1e6:.2f} MB per rank (recall only; sorted lists: {4 * nbp * n * 4 / 1e6:.2f})): "
               + "; ".join(f"{k} {v:.3f} ms" for k, v in out.items()), flush=True)
 
 

@@ -126,27 +126,39 @@ __device__ __forceinline__ unsigned xor16_of(unsigned x, bool odd_row) {
   const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);     // r[0]: odd 16-lane rows <- the even row below;  r[1]: even rows <- the odd row above
   return odd_row ? r[0] : r[1];
 }
-// Sorted quadruple of the four smallest keys seen.
-struct Min4 {
-  unsigned a, b, c, d;
-  __device__ __forceinline__ void init() { a = b = c = d = VTC_L2MIN_INF; }
-  __device__ __forceinline__ void insert(unsigned k) {       // 4 VALU: a, b, c shift up around k; d = fourth smallest of {a, b, c, d, k}
-    d = umed3(c, d, k);          // k <= c: c;  c < k < d: k;  k >= d: d   (round 4: was min(d, max(c, k)))
-    c = umed3(b, c, k);
-    b = umed3(a, b, k);
-    a = min(a, k);
+// The NPL smallest keys seen, sorted (NPL = 4: three keys + the fourth as a bound; NPL = 2, round 5: the smallest + the second as a bound --
+// half the vector instructions per value and half the plane bytes, for the recall-only sweep at small k, whose rank kernel sends a block
+// to fp64 whenever its bound is in reach of the target's distance).
+template <int NPL>
+struct MinK {
+  static_assert(NPL == 2 || NPL == 4, "two or four planes");
+  unsigned v[NPL];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) v[q] = VTC_L2MIN_INF;
   }
-  // the four smallest of two sorted quadruples, sorted: reversed elementwise min (a bitonic sequence), then two exchange stages
-  __device__ __forceinline__ void merge(unsigned oa, unsigned ob, unsigned oc, unsigned od) {
-    const unsigned x0 = min(a, od), x1 = min(b, oc), x2 = min(c, ob), x3 = min(d, oa);
-    const unsigned y0 = min(x0, x2), y2 = max(x0, x2), y1 = min(x1, x3), y3 = max(x1, x3);
-    a = min(y0, y1); b = max(y0, y1); c = min(y2, y3); d = max(y2, y3);
+  __device__ __forceinline__ void insert(unsigned k) {       // NPL VALU: the slots shift up around k; v[NPL - 1] = NPL-th smallest of the old slots and k
+#pragma unroll
+    for (int q = NPL - 1; q >= 1; --q) v[q] = umed3(v[q - 1], v[q], k);       // k <= v[q-1]: v[q-1];  between: k;  k >= v[q]: v[q]   (round 4: was min / max pairs)
+    v[0] = min(v[0], k);
+  }
+  // the NPL smallest of two sorted tuples, sorted: reversed elementwise min (a bitonic sequence), then the exchange stages
+  __device__ __forceinline__ void merge(const unsigned (&o)[NPL]) {
+    if constexpr (NPL == 4) {
+      const unsigned x0 = min(v[0], o[3]), x1 = min(v[1], o[2]), x2 = min(v[2], o[1]), x3 = min(v[3], o[0]);
+      const unsigned y0 = min(x0, x2), y2 = max(x0, x2), y1 = min(x1, x3), y3 = max(x1, x3);
+      v[0] = min(y0, y1); v[1] = max(y0, y1); v[2] = min(y2, y3); v[3] = max(y2, y3);
+    } else {
+      const unsigned x0 = min(v[0], o[1]), x1 = min(v[1], o[0]);
+      v[0] = min(x0, x1); v[1] = max(x0, x1);
+    }
   }
 };
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int NPL>
 __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmParams &p, int m0, int n0) {
   static_assert(TN == 4, "a wave's columns are one 64-column block");
+  using Min4 = MinK<NPL>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int g = lane >> 4, l15 = lane & 15;
@@ -209,13 +221,21 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
     // the row's 64 columns of this wave sit in the four lanes l15 + 16 g: merge (xor 16, xor 32)
     {
       const bool odd = (g & 1) != 0, up = g >= 2;
-      row.merge(xor16_of(row.a, odd), xor16_of(row.b, odd), xor16_of(row.c, odd), xor16_of(row.d, odd));
-      row.merge(xor32_of(row.a, up), xor32_of(row.b, up), xor32_of(row.c, up), xor32_of(row.d, up));
+      unsigned o[NPL];
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) o[q] = xor16_of(row.v[q], odd);
+      row.merge(o);
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) o[q] = xor32_of(row.v[q], up);
+      row.merge(o);
     }
     // lane g stores plane g (keys 1-3, bound): 16 consecutive rows each (64-byte segments).  A wave whose 64 columns lie
     // wholly past N owns no block (its slot would be the next plane's block 0).
-    if (mv && nbase < p.N) {
-      p.epi.rowk[(size_t)g * rstride + (size_t)cblk * p.M + m] = g == 0 ? row.a : (g == 1 ? row.b : (g == 2 ? row.c : row.d));
+    if (mv && nbase < p.N && g < NPL) {
+      unsigned mine = row.v[0];
+#pragma unroll
+      for (int q = 1; q < NPL; ++q) mine = g == q ? row.v[q] : mine;
+      p.epi.rowk[(size_t)g * rstride + (size_t)cblk * p.M + m] = mine;
     }
   }
   if (cols_too) {
@@ -236,9 +256,13 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
     // one step on a pair of slots: `up` lanes keep `hi` and send `lo`, the others keep `lo` and send `hi`
     auto step = [&](const Min4 &lo, const Min4 &hi, bool up, auto fetch) __attribute__((always_inline)) -> Min4 {
       Min4 k;
-      k.a = up ? hi.a : lo.a; k.b = up ? hi.b : lo.b; k.c = up ? hi.c : lo.c; k.d = up ? hi.d : lo.d;
-      const unsigned sa = up ? lo.a : hi.a, sb = up ? lo.b : hi.b, sc = up ? lo.c : hi.c, sd = up ? lo.d : hi.d;
-      k.merge(fetch(sa), fetch(sb), fetch(sc), fetch(sd));
+      unsigned got[NPL];
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) {
+        k.v[q] = up ? hi.v[q] : lo.v[q];
+        got[q] = fetch(up ? lo.v[q] : hi.v[q]);
+      }
+      k.merge(got);
       return k;
     };
     const bool b0 = (l15 & 1) != 0, b1 = (l15 & 2) != 0, b2 = (l15 & 4) != 0, b3 = (l15 & 8) != 0;
@@ -254,13 +278,11 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
 #undef VTC_DPPU
     const int cj = (b0 ? 2 : 0) + (b1 ? 1 : 0), ce = (b3 ? 2 : 0) + (b2 ? 1 : 0);
     const int n = nbase + 16 * cj + 4 * g + ce;
-    // every lane stores the four planes of its own column: a wave covers its 64 columns, 256 contiguous bytes per plane
+    // every lane stores the planes of its own column: a wave covers its 64 columns, 256 contiguous bytes per plane
     if (n < p.N && mbase < p.M) {
       unsigned *dst = p.epi.colk + (size_t)rblk * p.N + n;
-      dst[0] = fin.a;
-      dst[cstride] = fin.b;
-      dst[2 * cstride] = fin.c;
-      dst[3 * cstride] = fin.d;
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) dst[q * cstride] = fin.v[q];
     }
   }
 }
@@ -271,7 +293,7 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
 template <typename T, int MODE_T, typename OutT, int WM, int WN, int TM, int TN, int SCRATCH_PER_WAVE, bool REJOIN = false>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmParams &p, int m0, int n0, unsigned scratch_off) {
   // EPI_*_FOLD = the base epilogue + the folded LayerNorm, compiled apart so that the plain kernels keep their registers
-  constexpr bool FOLD = MODE_T >= EPI_FOLD_BASE;
+  constexpr bool FOLD = MODE_T >= EPI_FOLD_BASE && MODE_T <= EPI_RESID_FOLD_C;
   constexpr bool CENTER = MODE_T == EPI_RESID_FOLD_C;
   constexpr int MODE = CENTER ? VTC_EPI_RESID : (FOLD ? MODE_T - EPI_FOLD_BASE : MODE_T);
   auto rejoin = [&]() __attribute__((always_inline)) {
@@ -279,9 +301,9 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       if ((int)(threadIdx.x >> 6) / WN == 0) __builtin_amdgcn_s_barrier();
     }
   };
-  if constexpr (MODE == EPI_L2MIN) {
+  if constexpr (MODE == EPI_L2MIN || MODE == EPI_L2MIN2) {
     rejoin();
-    if constexpr (TN == 4) l2min_epilogue<WM, WN, TM, TN>(acc, p, m0, n0);
+    if constexpr (TN == 4) l2min_epilogue<WM, WN, TM, TN, l2min_planes(MODE)>(acc, p, m0, n0);
     return;
   }
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1360,7 +1382,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
       rd_step = -rd_step;
     }
     };
-    if constexpr (MODE != EPI_L2MIN && MODE != EPI_PATCH && MODE != EPI_RESID_LN) {   // (those three keep one copy: register budgets)
+    if constexpr (MODE != EPI_L2MIN && MODE != EPI_L2MIN2 && MODE != EPI_PATCH && MODE != EPI_RESID_LN) {   // (those keep one copy: register budgets)
       const bool this_in = m0 + BM <= p.M && n0 + BN <= p.N, next_in = !has_next || (m0n + BM <= p.M && n0n + BN <= p.N);
       if (this_in && next_in) kloop(std::true_type{});
       else kloop(std::false_type{});
@@ -1383,7 +1405,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
     }
     VTC_STAMP_TILE_END(!has_next);   // epilogue issue
     if (!has_next) break;
-    relax_first = MODE != EPI_L2MIN && MODE != EPI_RESID_LN && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 3) == 0);   // the tile just stored took a fast path
+    relax_first = MODE != EPI_L2MIN && MODE != EPI_L2MIN2 && MODE != EPI_RESID_LN && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 3) == 0);   // the tile just stored took a fast path
     __builtin_amdgcn_s_barrier();          // the transposition area is the next K-tile's DMA target
     VTC_STAMP(3);       // post-epilogue barrier
     li += nb_x; m0 = m0n; n0 = n0n;
@@ -1451,7 +1473,7 @@ template <int MODE, typename OutT, typename T>
 int run_phased(const GemmParams &p, hipStream_t stream) {
   // the deep pipeline needs two K-tiles per tile; the fused-LayerNorm tail and the sweep's block-minima epilogue stay on the
   // round-3 loop (register budgets: EPI_L2MIN with the deep loop spills 18 registers and measures the same, r04_experiments.txt 7)
-  if constexpr (MODE != EPI_RESID_LN && MODE != EPI_L2MIN) {
+  if constexpr (MODE != EPI_RESID_LN && MODE != EPI_L2MIN && MODE != EPI_L2MIN2) {
     if (p.K >= 128) {
       if (g_deep >= 1) return run_phased_d<MODE, OutT, T, 1>(p, stream);
     }
@@ -1502,6 +1524,10 @@ int run_l2min(const GemmParams &p, hipStream_t stream) {
   // (round 5: a third form -- two 4-wave workgroups per CU on 128 x 256 tiles, K = 32 slabs, so that one's epilogue runs under the
   //  other's K loop -- was built, passes the sweep tests and measures 5.2 ms against 4.6 at 50k: tools/probes/gemm_l2min2.hip,
   //  profiles/r05_experiments.txt 3)
+  if (p.epi.mode == EPI_L2MIN2) {
+    if (p.epi.rb == 128) return run_phased<EPI_L2MIN2, float, bf16_t>(p, stream);
+    return run<bf16_t, EPI_L2MIN2, float, 2, 2, 4, 4, 2>(p, stream);
+  }
   if (p.epi.rb == 128) return run_phased<EPI_L2MIN, float, bf16_t>(p, stream);
   return run<bf16_t, EPI_L2MIN, float, 2, 2, 4, 4, 2>(p, stream);
 }
@@ -1537,6 +1563,7 @@ int dispatch(GemmParams p, hipStream_t stream) {
     case EPI_L2DIST: return run_cfg<T, EPI_L2DIST, float>(p, stream);
     case EPI_SCALE: return run_cfg<T, EPI_SCALE, float>(p, stream);
     case EPI_L2MIN:
+    case EPI_L2MIN2:
       if constexpr (sizeof(T) == 2 && !std::is_same<T, f16_t>::value) return run_l2min(p, stream);
       break;
     case EPI_RESID_LN:

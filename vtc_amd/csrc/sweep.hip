@@ -1298,8 +1298,16 @@ Sweep2Ws plan2(char *ws, int ng, int nq, int d, bool bidir) {
 // an untrained model -- and for a query whose target leads its list (a trained model) almost nothing is in reach: the fp64 re-rank of
 // ~20 candidate rows per query (the sweep's largest consumer of bytes) shrinks to the target row and a handful.  Same hits as
 // vtc_l2_topk_bidir + vtc_recall_hits_pair, bit for bit in the counters.
+// Planes the recall-only sweep asks of the distance GEMM: for max(k) <= 16 the block's smallest key + the second as a bound (EPI_L2MIN2: half
+// the epilogue's insert instructions and half the plane bytes; a block with two entries in reach of a target goes to fp64, which for a target
+// with r closer entries happens about r^2 / (2 x blocks) of the time), else three keys + bound.  VTC_SWEEP_PLANES=4 keeps four planes.
+static int recall_planes(int kmax) {
+  static const int force = [] { const char *e = getenv("VTC_SWEEP_PLANES"); return e ? atoi(e) : 0; }();
+  if (force == 2 || force == 4) return force;
+  return kmax <= 16 ? 2 : L2MIN_PLANES;
+}
 struct RankArgs {
-  const unsigned *keys;        // [nsrc][4][nblk][R]
+  const unsigned *keys;        // [nsrc][NPL][nblk][R], NPL = 4 (EPI_L2MIN: three keys + bound) or 2 (EPI_L2MIN2: one key + bound) -- the kernel's template argument
   int R, nblk, bw;             // owners (queries of this direction), blocks PER SOURCE, entries per block (64 rows / RB columns)
   int nsrc;                    // sources of key planes: 1, or (sharded sweep, column direction) the ranks that each ran a [rows of theirs, R] GEMM
   const int *bounds;           // [nsrc + 1] (device): source s covers the other side's rows [bounds[s], bounds[s + 1]); NULL: one source, [0, ng)
@@ -1344,12 +1352,13 @@ __device__ __forceinline__ void wave_dist64_x8(const float *__restrict__ q, cons
 #pragma unroll
   for (int u = 0; u < 8; ++u) out[u] = sacc[u];
 }
+template <int NPL>
 __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, const RankArgs PB, int nblocks_a) {
   const bool second = (int)blockIdx.x >= nblocks_a;
   const RankArgs &P = second ? PB : PA;
   const int bid = second ? (int)blockIdx.x - nblocks_a : (int)blockIdx.x;
   const int R = P.R, nblk = P.nblk, bw = P.bw, ng = P.ng, d = P.d, kmax = P.kmax;
-  __shared__ unsigned tl[4][RK_CH * (RK_OW + 1)];
+  __shared__ unsigned tl[NPL][RK_CH * (RK_OW + 1)];
   __shared__ int amb[RK_OW][RK_AMB];
   __shared__ int ublk[RK_OW][RK_UB], uend[RK_OW][RK_UB];       // unsafe blocks: first entry and end (the block's or its source's)
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -1405,19 +1414,19 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
   const int vo = 4 * (t & 7), vb = t >> 3;            // ... this thread's first owner and (block, plane) slice: 32 slices
   for (int src = 0; src < P.nsrc; ++src) {
   const int sbeg = P.bounds ? P.bounds[src] : 0, send = P.bounds ? P.bounds[src + 1] : ng;
-  const unsigned *__restrict__ keys = P.keys + (size_t)src * 4 * plane;
+  const unsigned *__restrict__ keys = P.keys + (size_t)src * NPL * plane;
   for (int c0 = 0; c0 < nblk; c0 += RK_CH) {
     if (vec) {
-      uint4 v[RK_CH * 4 / 32];
+      uint4 v[RK_CH * NPL / 32];
 #pragma unroll
-      for (int q = 0; q < RK_CH * 4 / 32; ++q) {     // (block, plane) pairs vb + 32 q of the chunk: plane = pair & 3, block = pair >> 2
-        const int pr = vb + 32 * q, pl = pr & 3, bl = pr >> 2, blk = c0 + bl;
+      for (int q = 0; q < RK_CH * NPL / 32; ++q) {     // (block, plane) pairs vb + 32 q of the chunk: plane = pair % NPL, block = pair / NPL
+        const int pr = vb + 32 * q, pl = pr & (NPL - 1), bl = pr / NPL, blk = c0 + bl;
         const bool ok = blk < nblk && r0 + vo < R;
         v[q] = ok ? *reinterpret_cast<const uint4 *>(keys + pl * plane + (size_t)blk * R + r0 + vo) : make_uint4(0x7F800000u, 0x7F800000u, 0x7F800000u, 0x7F800000u);
       }
 #pragma unroll
-      for (int q = 0; q < RK_CH * 4 / 32; ++q) {
-        const int pr = vb + 32 * q, pl = pr & 3, bl = pr >> 2;
+      for (int q = 0; q < RK_CH * NPL / 32; ++q) {
+        const int pr = vb + 32 * q, pl = pr & (NPL - 1), bl = pr / NPL;
         unsigned *dst = &tl[pl][bl * (RK_OW + 1) + vo];
         dst[0] = v[q].x; dst[1] = v[q].y; dst[2] = v[q].z; dst[3] = v[q].w;
       }
@@ -1428,7 +1437,7 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
         const bool ok = blk < nblk && r0 + so < R;
         const size_t o = ok ? (size_t)blk * R + r0 + so : 0;
 #pragma unroll
-        for (int pl = 0; pl < 4; ++pl) tl[pl][bl * (RK_OW + 1) + so] = ok ? keys[pl * plane + o] : 0x7F800000u;
+        for (int pl = 0; pl < NPL; ++pl) tl[pl][bl * (RK_OW + 1) + so] = ok ? keys[pl * plane + o] : 0x7F800000u;
       }
     }
     __syncthreads();
@@ -1437,13 +1446,13 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
 #pragma unroll
     for (int cc = 0; cc < OPW; ++cc) {
       const int o = OPW * w + cc, tg = r0 + o + toff;
-      const unsigned k3 = tl[3][lane * (RK_OW + 1) + o];
+      const unsigned k3 = tl[NPL - 1][lane * (RK_OW + 1) + o];            // the block's bound: its NPL-th smallest key
       const bool unsafe = k3 != 0x7F800000u && __uint_as_float(k3 & ~127u) <= hi[cc];
-      unsigned kk[3];
-      bool am[3];
+      unsigned kk[NPL - 1];
+      bool am[NPL - 1];
       bool any_am = false;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < NPL - 1; ++pl) {
         kk[pl] = tl[pl][lane * (RK_OW + 1) + o];
         const float v = __uint_as_float(kk[pl] & ~127u);
         const bool valid = kk[pl] != 0x7F800000u && base + (int)(kk[pl] & 127u) != tg;     // (the target itself is not counted)
@@ -1461,7 +1470,7 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
       }
       if (__ballot(any_am)) {                                             // wave-uniform, rare: entries within eps of the target's distance
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL - 1; ++pl) {
           const unsigned long long mask = __ballot(am[pl]);
           const int pos = n_amb[cc] + __popcll(mask & ((1ull << lane) - 1ull));
           if (am[pl] && pos < RK_AMB) amb[o][pos] = base + (int)(kk[pl] & 127u);
@@ -1698,12 +1707,15 @@ int recall_bidir_impl(const float *a, const float *b, int n, int d, const int *k
     launch_sweep_prep(A, B, d, s.pmax, stream, s.flags, s.flags2);       // ... and the two fallback counters zeroed
   }
   VTC_LAUNCH_CHECK("l2_recall prologue");
+  int kmax = 0;
+  for (int i = 0; i < nk; ++i) kmax = std::max(kmax, k_vals[i]);
+  const int npl = recall_planes(kmax);
   GemmEpi e;
-  e.mode = EPI_L2MIN; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
+  e.mode = npl == 2 ? EPI_L2MIN2 : EPI_L2MIN; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
   e.rowk = s.rowk; e.colk = s.colk; e.nblk_c = s.nblk_c; e.nblk_r = s.nblk_r; e.rb = s.rb;
   if (int rc = launch_gemm(s.qb, s.gb, nullptr, nullptr, n, n, d, VTC_BF16, e, stream)) return rc;
   const float kappa = exact2_kappa(d);
-  int kmax = 0;
+  kmax = 0;
   static_assert(RK_WORK * sizeof(int) <= CD2 * sizeof(int64_t) && 3 + 2 * RK_UB + RK_AMB <= RK_WORK, "a deferred row's lists fit its candidate-list slot");
   const int nwg = cdiv(n, RK_OW);            // (4 ints per workgroup in the cand_n arrays: n / 8 <= n)
   RankArgs r1{s.rowk, n, s.nblk_c, 64, 1, nullptr, 0, b, a, n, d, s.qn, s.qst, s.gmax, kappa, 0, nk, {0, 0, 0, 0}, hits_b_from_a, s.flags, (int *)s.cand, s.cand_n, nwg};
@@ -1711,9 +1723,10 @@ int recall_bidir_impl(const float *a, const float *b, int n, int d, const int *k
   for (int i = 0; i < nk; ++i) { r1.k[i] = r2.k[i] = k_vals[i]; kmax = std::max(kmax, k_vals[i]); }
   r1.kmax = r2.kmax = kmax;
   {
-    ProfScope prof(VTC_PROF_TOPK, (double)L2MIN_PLANES * ((double)s.nblk_c + s.nblk_r) * n * 4 + 4.0 * n * d * 4, stream);
+    ProfScope prof(VTC_PROF_TOPK, (double)npl * ((double)s.nblk_c + s.nblk_r) * n * 4 + 4.0 * n * d * 4, stream);
     const int nb = cdiv(n, RK_OW);
-    hipLaunchKernelGGL(recall_rank_kernel, dim3(2 * nb), dim3(256), 0, stream, r1, r2, nb);
+    if (npl == 2) hipLaunchKernelGGL(recall_rank_kernel<2>, dim3(2 * nb), dim3(256), 0, stream, r1, r2, nb);
+    else hipLaunchKernelGGL(recall_rank_kernel<4>, dim3(2 * nb), dim3(256), 0, stream, r1, r2, nb);
   }
   {
     ProfScope prof(VTC_PROF_TOPK, 0.0, stream);
@@ -1783,11 +1796,12 @@ extern "C" int vtc_l2_sweep_shard_cols(const float *b_all, const float *a_local,
 
 // ---- the same exchange with the recall-only finish (round 5): hit counters instead of sorted lists ---------------------------
 // One direction of recall_rank_kernel + recall_rank_finish_kernel (the second argument block is not used: every workgroup is "first").
-static void launch_rank_one(const RankArgs &r, hipStream_t stream) {
+static void launch_rank_one(const RankArgs &r, int npl, hipStream_t stream) {
   {
-    ProfScope prof(VTC_PROF_TOPK, (double)L2MIN_PLANES * r.nsrc * r.nblk * r.R * 4 + 2.0 * r.R * r.d * 4, stream);
+    ProfScope prof(VTC_PROF_TOPK, (double)npl * r.nsrc * r.nblk * r.R * 4 + 2.0 * r.R * r.d * 4, stream);
     const int nb = cdiv(r.R, RK_OW);
-    hipLaunchKernelGGL(recall_rank_kernel, dim3(nb), dim3(256), 0, stream, r, r, nb);
+    if (npl == 2) hipLaunchKernelGGL(recall_rank_kernel<2>, dim3(nb), dim3(256), 0, stream, r, r, nb);
+    else hipLaunchKernelGGL(recall_rank_kernel<4>, dim3(nb), dim3(256), 0, stream, r, r, nb);
   }
   {
     ProfScope prof(VTC_PROF_TOPK, 0.0, stream);
@@ -1801,6 +1815,12 @@ static int fill_k(RankArgs &r, const int *k_vals, int nk) {
   for (int i = 0; i < 4; ++i) r.k[i] = 0;
   for (int i = 0; i < nk; ++i) { r.k[i] = k_vals[i]; r.kmax = std::max(r.kmax, k_vals[i]); }
   return r.kmax;
+}
+
+extern "C" int vtc_l2_recall_planes(const int *k_vals, int nk) {
+  int kmax = 0;
+  for (int i = 0; k_vals && i < nk; ++i) kmax = std::max(kmax, k_vals[i]);
+  return recall_planes(kmax);
 }
 
 extern "C" int vtc_l2_recall_shard_supported(int n_total, int n_local, int d) {
@@ -1825,17 +1845,20 @@ extern "C" int vtc_l2_recall_shard_rows(const float *a_all, const float *b_local
     launch_sweep_prep(A, B, d, s.pmax, stream, s.flags, nullptr);
   }
   VTC_LAUNCH_CHECK("l2_recall_shard_rows prologue");
+  int kmax = 0;
+  for (int i = 0; i < nk; ++i) kmax = std::max(kmax, k_vals[i]);
+  const int npl = recall_planes(kmax);
   GemmEpi e;
-  e.mode = EPI_L2MIN; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
+  e.mode = npl == 2 ? EPI_L2MIN2 : EPI_L2MIN; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
   e.rowk = s.rowk; e.colk = col_planes; e.nblk_c = s.nblk_c; e.nblk_r = nblk_pad; e.rb = s.rb;
-  for (int pl = 0; pl < L2MIN_PLANES && nblk_pad > s.nblk_r; ++pl)     // blocks this rank has no rows for (shards differ by a row): +inf keys
+  for (int pl = 0; pl < npl && nblk_pad > s.nblk_r; ++pl)     // blocks this rank has no rows for (shards differ by a row): +inf keys
     (void)hipMemsetD32Async((hipDeviceptr_t)(col_planes + ((size_t)pl * nblk_pad + s.nblk_r) * n_total), 0x7F800000,
                             (size_t)(nblk_pad - s.nblk_r) * n_total, stream);
   if (int rc = launch_gemm(s.qb, s.gb, nullptr, nullptr, n_local, n_total, d, VTC_BF16, e, stream)) return rc;
   RankArgs r{s.rowk, n_local, s.nblk_c, 64, 1, nullptr, row_base, b_local, a_all, n_total, d, s.qn, s.qst, s.gmax, exact2_kappa(d), 0, nk, {0, 0, 0, 0},
              (unsigned long long *)hits_b_from_a, s.flags, (int *)s.cand, s.cand_n, cdiv(n_local, RK_OW)};
   fill_k(r, k_vals, nk);
-  launch_rank_one(r, stream);
+  launch_rank_one(r, npl, stream);
   VTC_LAUNCH_CHECK("l2_recall_shard_rows");
   return 0;
 }
@@ -1858,10 +1881,13 @@ extern "C" int vtc_l2_recall_shard_cols(const float *b_all, const float *a_local
     const PrepSide A{a_local, nullptr, s.qn, s.qst, s.qmax, n_local}, B{b_all, nullptr, s.gn, s.gst, s.gmax, n_total};
     launch_sweep_prep(A, B, d, s.pmax, stream, s.flags, nullptr);
   }
+  int kmax_ = 0;
+  for (int i = 0; i < nk; ++i) kmax_ = std::max(kmax_, k_vals[i]);
+  const int npl = recall_planes(kmax_);
   RankArgs r{planes, n_local, nblk_pad, vtc_l2_sweep_row_block(), n_src, src_bounds, row_base, a_local, b_all, n_total, d, s.qn, s.qst, s.gmax,
              exact2_kappa(d), 0, nk, {0, 0, 0, 0}, (unsigned long long *)hits_a_from_b, s.flags, (int *)s.cand, s.cand_n, cdiv(n_local, RK_OW)};
   fill_k(r, k_vals, nk);
-  launch_rank_one(r, stream);
+  launch_rank_one(r, npl, stream);
   VTC_LAUNCH_CHECK("l2_recall_shard_cols");
   return 0;
 }

@@ -138,9 +138,15 @@ struct MinK {
     for (int q = 0; q < NPL; ++q) v[q] = VTC_L2MIN_INF;
   }
   __device__ __forceinline__ void insert(unsigned k) {       // NPL VALU: the slots shift up around k; v[NPL - 1] = NPL-th smallest of the old slots and k
+    // slot q = med3(slot q-1, slot q, k): k <= v[q-1]: v[q-1];  between: k;  k >= v[q]: v[q]   (round 4: was min / max pairs).  ONE asm block, every slot
+    // updated in place from the top down: left to hipcc the smallest slot's min was scheduled first into a temporary and copied back -- a v_mov per insert
+    if constexpr (NPL == 2) {
+      asm("v_med3_u32 %1, %0, %1, %2\n\tv_min_u32 %0, %0, %2" : "+v"(v[0]), "+v"(v[1]) : "v"(k));
+    } else {     // (four slots as one asm block: 7 spilled registers in the phased kernel -- the compiler's own schedule stays)
 #pragma unroll
-    for (int q = NPL - 1; q >= 1; --q) v[q] = umed3(v[q - 1], v[q], k);       // k <= v[q-1]: v[q-1];  between: k;  k >= v[q]: v[q]   (round 4: was min / max pairs)
-    v[0] = min(v[0], k);
+      for (int q = NPL - 1; q >= 1; --q) v[q] = umed3(v[q - 1], v[q], k);
+      v[0] = min(v[0], k);
+    }
   }
   // the NPL smallest of two sorted tuples, sorted: reversed elementwise min (a bitonic sequence), then the exchange stages
   __device__ __forceinline__ void merge(const unsigned (&o)[NPL]) {
@@ -154,6 +160,30 @@ struct MinK {
     }
   }
 };
+
+// EPI_L2MIN2: the accumulators START at -(|q_m|^2 + |g_n|^2) / 2 (this lane's rows and columns in the MFMA layout), so that the K loop leaves
+// q.g - (|q|^2 + |g|^2) / 2 = -d / 2 in them and the epilogue takes its keys straight from the accumulator bits -- |acc| with the index in the low
+// mantissa bits, one v_bfi per key, where the four-plane form spends fma + add + max per value first.  |.| instead of the clamp at zero: a distance
+// that rounding made negative by x <= eps reads x instead of 0, still within eps of the exact one.  The keys are HALF distances (recall_rank_kernel<2>
+// halves its thresholds).  The next tile's norms are requested before a tile's epilogue and land under it.
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void l2min2_half_norms(const GemmParams &p, int m0, int n0, float (&hr)[TM], float (&hc)[TN][4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave / WN, wc = wave % WN, g = lane >> 4, l15 = lane & 15;
+  const int mbase = m0 + wr * TM * 16, nbase = n0 + wc * TN * 16;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mbase + 16 * i + l15;
+    hr[i] = m < p.M ? -0.5f * p.epi.rown[m] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = nbase + 16 * j + 4 * g + e;
+      hc[j][e] = n < p.N ? -0.5f * p.epi.coln[n] : 0.f;
+    }
+}
 
 template <int WM, int WN, int TM, int TN, int NPL>
 __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmParams &p, int m0, int n0) {
@@ -174,7 +204,7 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
     for (int e = 0; e < 4; ++e) {
       const int n = nbase + 16 * j + 4 * g + e;
       const bool v = n < p.N;
-      cn[j][e] = v ? p.epi.coln[n] : 0.f;
+      if constexpr (NPL != 2) cn[j][e] = v ? p.epi.coln[n] : 0.f;       // (two planes: the norms went into the accumulators before the K loop)
       cvalid |= (unsigned)v << (4 * j + e);
     }
   Min4 col[TN][4];
@@ -192,15 +222,20 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
     constexpr bool INTERIOR = decltype(interior_c)::value;
     const int m = mbase + 16 * i + l15;
     const bool mv = INTERIOR || m < p.M;
-    const float rn = mv ? p.epi.rown[m] : 0.f;
+    float rn = 0.f;
+    if constexpr (NPL != 2) rn = mv ? p.epi.rown[m] : 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         // a distance that rounding made negative (a query against itself: |q|^2 in fp32 minus |bf16(q)|^2) clamps to zero --
         // as a signed-integer max, which needs no canonicalisation; its key then sorts first, as it must
-        const unsigned bits = (unsigned)max(__float_as_int((rn - 2.0f * acc[i][j][e]) + cn[j][e]), 0);
-        unsigned kr = key_bfi(127u, (unsigned)(16 * j + 4 * g + e), bits), kc = key_bfi(127u, (unsigned)(16 * i + l15), bits);
+        // (two planes: the accumulator holds -d / 2; the key's mask drops the sign with the index bits)
+        unsigned bits;
+        if constexpr (NPL == 2) bits = __float_as_uint(acc[i][j][e]);
+        else bits = (unsigned)max(__float_as_int((rn - 2.0f * acc[i][j][e]) + cn[j][e]), 0);
+        constexpr unsigned KMASK = NPL == 2 ? 0x8000007Fu : 127u;
+        unsigned kr = key_bfi(KMASK, (unsigned)(16 * j + 4 * g + e), bits), kc = key_bfi(KMASK, (unsigned)(16 * i + l15), bits);
         if constexpr (!INTERIOR) {
           const bool v = mv && ((cvalid >> (4 * j + e)) & 1);
           kr = v ? kr : VTC_L2MIN_INF;
@@ -897,13 +932,18 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(GemmParams p) {
   wait_all_but(ahead);                       // slab 0 has landed
   __syncthreads();
 
+  [[maybe_unused]] float hr[TM], hc[TN][4];       // EPI_L2MIN2: -(norms) / 2 of the tile about to start (l2min2_half_norms)
+  if constexpr (MODE == EPI_L2MIN2 && TN == 4) l2min2_half_norms<WM, WN, TM, TN>(p, m0, n0, hr, hc);
   while (true) {
 
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (MODE == EPI_L2MIN2 && TN == 4) acc[i][j] = (f32x4){hr[i] + hc[j][0], hr[i] + hc[j][1], hr[i] + hc[j][2], hr[i] + hc[j][3]};
+        else acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
 
     for (int t = 0; t < ksteps; ++t) {
       // Stagger (MI355X_MICROARCH "two waves per SIMD", item 9): the two waves that share a SIMD run the
@@ -953,6 +993,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(GemmParams p) {
       cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
 
+    if constexpr (MODE == EPI_L2MIN2 && TN == 4) {
+      if (has_next) l2min2_half_norms<WM, WN, TM, TN>(p, m0n, n0n, hr, hc);
+    }
     tile_epilogue<T, MODE, OutT, WM, WN, TM, TN, STAGE / NW>(acc, p, m0, n0, ((cur + NSTAGE - 1) % NSTAGE) * STAGE);
     if (has_next) __syncthreads();         // the transposition area becomes the next K-step's staging buffer
 
@@ -1222,6 +1265,21 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
   u32x4 aS[4][2], wS[2][2];     // register subtile: 4 activation x 2 weight fragments x 2 K halves
   [[maybe_unused]] u32x4 wD[1][2][2];   // the deep loop's weight fragments
   bool relax_first = false;     // the previous tile's epilogue issued exactly NST stores last (see the phase-end wait)
+  // EPI_L2MIN2: -(norms) / 2 of a tile's 256 rows and 256 columns travel through 2 KiB of LDS behind the two stages -- one value per thread,
+  // requested before the previous tile's epilogue and written behind it (held in registers across the epilogue, 24 per lane, they cost 4 spills)
+  [[maybe_unused]] float *nrm = reinterpret_cast<float *>(lds + 2 * STAGE);
+  [[maybe_unused]] auto fetch_norm = [&](int tm0, int tn0) -> float {
+    if (tid < 256) {
+      const int m = tm0 + tid;
+      return m < p.M ? -0.5f * p.epi.rown[m] : 0.f;
+    }
+    const int n = tn0 + tid - 256;
+    return n < p.N ? -0.5f * p.epi.coln[n] : 0.f;
+  };
+  if constexpr (MODE == EPI_L2MIN2) {
+    nrm[tid] = fetch_norm(m0, n0);
+    __syncthreads();
+  }
   VTC_STAMP_INIT();
   while (true) {
     // PING-PONG: waves 4-7 (the SIMD partners of waves 0-3) run one barrier behind, so that on every SIMD one
@@ -1232,7 +1290,15 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (MODE == EPI_L2MIN2) {     // (l2min2_half_norms' layout: row 16 i + (lane & 15) of the wave's 128, columns 16 j + 4 g .. + 3 of its 64)
+          const float hr = nrm[wr * 128 + 16 * i + (lane & 15)];
+          const float4 hc = *reinterpret_cast<const float4 *>(nrm + 256 + wc * 64 + 16 * j + 4 * g);
+          acc[i][j] = (f32x4){hr + hc.x, hr + hc.y, hr + hc.z, hr + hc.w};
+        } else {
+          acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
 
     // The K loop exists twice: ALL_FAST = every quarter it stages (this tile's and, at its end, the next tile's first K-tile) lies
     // inside the operands, so the per-quarter "interior?" test, its two branches (one of them taken) and the clamped slow path are not
@@ -1393,6 +1459,10 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
     VTC_STAMP(1);       // (the re-join wait is inside the epilogue now: waves 0-3 wait for waves 4-7's last MFMA cluster AFTER requesting the
                         //  tile's bias / statistics / first residual rows)
 
+    [[maybe_unused]] float nrm_next = 0.f;
+    if constexpr (MODE == EPI_L2MIN2) {
+      if (has_next) nrm_next = fetch_norm(m0n, n0n);      // requested here, written to LDS behind the epilogue
+    }
     tile_epilogue<T, MODE, OutT, WM, WN, TM, TN, STAGE / NW, true>(acc, p, m0, n0, (cur ^ 1) * STAGE);
     if constexpr (MODE == EPI_RESID_LN) {
       int *ticket = reinterpret_cast<int *>(lds + 2 * STAGE);       // one word behind the two stages (run_phased asks for it)
@@ -1406,6 +1476,10 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
     VTC_STAMP_TILE_END(!has_next);   // epilogue issue
     if (!has_next) break;
     relax_first = MODE != EPI_L2MIN && MODE != EPI_L2MIN2 && MODE != EPI_RESID_LN && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 3) == 0);   // the tile just stored took a fast path
+    if constexpr (MODE == EPI_L2MIN2) {    // (every wave read this tile's norms before its K loop: long before any wave gets here)
+      nrm[tid] = nrm_next;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();          // the transposition area is the next K-tile's DMA target
     VTC_STAMP(3);       // post-epilogue barrier
     li += nb_x; m0 = m0n; n0 = n0n;
@@ -1459,7 +1533,7 @@ template <int MODE, typename OutT, typename T, int DEEP>
 int run_phased_d(GemmParams p, hipStream_t stream) {
   p.MT = cdiv(p.M, 256); p.NT = cdiv(p.N, 256);
   const int ntiles = p.MT * p.NT;
-  const size_t shmem = (size_t)2 * 512 * ROWB + (MODE == EPI_RESID_LN ? 16 : 0);   // 128 KiB: one workgroup per CU (+ the ticket word)
+  const size_t shmem = (size_t)2 * 512 * ROWB + (MODE == EPI_RESID_LN ? 16 : 0) + (MODE == EPI_L2MIN2 ? 2048 : 0);   // 128 KiB: one workgroup per CU (+ the ticket word / the tile's half norms)
   const int grid = min(ntiles, num_cus());
   static PerDeviceOnce attr;
   if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&gemm_phased_kernel<MODE, OutT, T, DEEP>), (int)shmem, "gemm_phased")) return 1;

@@ -1400,8 +1400,10 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
       const int r = min(r0 + OPW * w + cc, R - 1);
       const float2 st = P.own_st[r];
       const float eps = 1.001f * (2.0f * (st.x * P.other_max[2] + st.y * P.other_max[1] + st.y * P.other_max[2]) + P.kappa * (P.own_norm[r] + P.other_max[0]));
-      lo[cc] = __double2float_rd(dt[cc] - (double)eps);      // key <  lo  =>  key + eps < d_t
-      hi[cc] = __double2float_ru(dt[cc] + (double)eps);      // key >  hi  =>  key - eps > d_t
+      // (two planes: the keys are HALF distances -- gemm.hip, EPI_L2MIN2 -- and so are the thresholds; halving is exact)
+      constexpr double KS = NPL == 2 ? 0.5 : 1.0;
+      lo[cc] = __double2float_rd(KS * (dt[cc] - (double)eps));      // key <  lo  =>  key + eps < d_t
+      hi[cc] = __double2float_ru(KS * (dt[cc] + (double)eps));      // key >  hi  =>  key - eps > d_t
     }
   }
   // per LANE (= block of the chunk) counters, reduced over the wave once behind the scan: a ballot + population count per (owner, plane,

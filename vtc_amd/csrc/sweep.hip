@@ -1450,6 +1450,9 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
       const int o = OPW * w + cc, tg = r0 + o + toff;
       const unsigned k3 = tl[NPL - 1][lane * (RK_OW + 1) + o];            // the block's bound: its NPL-th smallest key
       const bool unsafe = k3 != 0x7F800000u && __uint_as_float(k3 & ~127u) <= hi[cc];
+      // the bound is an entry too (the block's NPL-th smallest): closer for certain, it raises the LOWER bound on the rank that ends a query as a
+      // miss without any fp64 (with two planes a query whose few closer entries share blocks would otherwise go to fp64 for a rank >= max k)
+      ca_l[cc] += (unsafe && __uint_as_float(k3 & ~127u) < lo[cc] && base + (int)(k3 & 127u) != tg) ? 1 : 0;
       unsigned kk[NPL - 1];
       bool am[NPL - 1];
       bool any_am = false;

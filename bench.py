@@ -106,7 +106,7 @@ def records_to_regions(recs):
 
 GEMM_MODE_NAMES = {0: "store", 1: "QuickGELU", 2: "residual (fp32 stream)", 3: "patch embed", 4: "L2 distance", 5: "scaled similarity",
                    6: "L2 block minima", 7: "residual + LayerNorm tail", 8: "store, folded LayerNorm", 9: "QuickGELU, folded LayerNorm",
-                   10: "residual on the (hi, lo) stream", 11: "residual on the (hi, lo) stream, re-centring", 12: "L2 block minima, two planes"}
+                   10: "residual on the (hi, lo) stream", 11: "residual on the (hi, lo) stream, re-centring", 12: "L2 block minima, two planes", 13: "L2 block minima, three planes"}
 
 
 def dominant_gemm(recs, cls, n_steps, peak):

@@ -274,8 +274,9 @@ int vtc_l2_recall_bidir(const float *a, const float *b, int n, int d, const int 
  * sets, runs ONE [n_local, n_total] distance GEMM and adds its PARTIAL counters (the host all-reduces them: model/metric.py:148-160 counted
  * over this rank's queries):
  *   vtc_l2_recall_shard_rows   hits_b_from_a[j] += #{ i local : a_(row_base + i) among the k_j nearest a's of b_(row_base + i) };
- *                              col_planes [P, nblk_pad, n_total] in vtc_l2_sweep_shard_rows' layout, P = vtc_l2_recall_planes(k_vals, nk):
- *                              2 for max k <= 16 (per column and block the smallest key + the second as a bound), else 4
+ *                              col_planes [P, nblk_pad, n_total] in vtc_l2_sweep_shard_rows' layout, P = vtc_l2_recall_planes(k_vals, nk, n_total):
+ *                              for max k <= 16 two planes (per column and block the smallest key + the second as a bound; n_total >= 16 384)
+ *                              or three (two keys + bound), else four
  *   (host) all-to-all of the column planes, as above
  *   vtc_l2_recall_shard_cols   planes [n_src, P, nblk_pad, n_local]; src_bounds [n_src + 1] (device int32): source s ran rows
  *                              [src_bounds[s], src_bounds[s + 1]);  hits_a_from_b[j] += #{ i local : b_(row_base + i) among the k_j nearest
@@ -283,7 +284,7 @@ int vtc_l2_recall_bidir(const float *a, const float *b, int n, int d, const int 
  * Summed over the ranks: the counters of vtc_l2_recall_bidir on the gathered sets, exactly.  n_total >= 1024, d % 64 == 0, nk <= 4;
  * workspace: vtc_l2_sweep_shard_workspace_bytes. */
 int vtc_l2_recall_shard_supported(int n_total, int n_local, int d);
-int vtc_l2_recall_planes(const int *k_vals_host, int nk);
+int vtc_l2_recall_planes(const int *k_vals_host, int nk, int n_total);
 int vtc_l2_recall_shard_rows(const float *a_all, const float *b_local, int n_total, int n_local, int row_base, int d,
                              const int *k_vals_host, int nk, long long *hits_b_from_a, unsigned *col_planes, int nblk_pad, void *ws,
                              size_t ws_bytes, void *stream);

@@ -32,7 +32,7 @@ def test_tower_gemm_instantiations_compile_without_spills(tmp_path):
     wanted = [f"gemm_phased_kernelILi{mode}E{types}Li1EEE" for mode, types in
               ((8, "tt"), (9, "tt"), (10, "ft"), (11, "ft"), (8, "5f16_tS1_"), (9, "5f16_tS1_"), (10, "f5f16_t"), (11, "f5f16_t"))]
     # the sweep's distance GEMM: block-minima epilogues with four planes (mode 6) and two (mode 12, round 5), round-3 K loop (`Li0E`)
-    wanted += ["gemm_phased_kernelILi6EftLi0EEE", "gemm_phased_kernelILi12EftLi0EEE"]
+    wanted += ["gemm_phased_kernelILi6EftLi0EEE", "gemm_phased_kernelILi12EftLi0EEE", "gemm_phased_kernelILi13EftLi0EEE"]
     for w in wanted:
         hits = [k for k in meta if w in k]
         assert len(hits) == 1, (w, hits)

@@ -22,7 +22,7 @@ for r in sorted(ours, key=lambda r: -int(r["TotalDurationNs"])):
     if t / tot < 0.002:
         continue
     n = short(r["Name"])
-    if n.startswith(("gemm_phased_kernel<6,", "gemm_kernel<bf16, 6,", "gemm_phased_kernel<12,", "gemm_kernel<bf16, 12,")):     # EPI_L2MIN / EPI_L2MIN2
+    if n.startswith(("gemm_phased_kernel<6,", "gemm_kernel<bf16, 6,", "gemm_phased_kernel<12,", "gemm_kernel<bf16, 12,", "gemm_phased_kernel<13,", "gemm_kernel<bf16, 13,")):     # EPI_L2MIN / EPI_L2MIN2
         gemm_ns += t
     lines.append(f"| `{n}` | {int(r['Calls']) / sweeps:.2f} | {float(r['AverageNs']) / 1e3:.2f} | {t / 1e6 / sweeps:.4f} | {100.0 * t / tot:.1f} |")
 flop = 2.0 * N * N * 512

@@ -98,7 +98,7 @@ SIGNATURES = {
     "vtc_l2_recall_bidir_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "vtc_l2_recall_bidir": (C.c_int, [fp, fp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, ip, ip, vp, C.c_size_t, vp]),
     "vtc_l2_recall_shard_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "vtc_l2_recall_planes": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "vtc_l2_recall_planes": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int]),
     "vtc_l2_recall_shard_rows": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, ip, vp, C.c_int, vp, C.c_size_t, vp]),
     "vtc_l2_recall_shard_cols": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, vp, C.c_int, C.c_int, vp, ip, vp,
                                            C.c_size_t, vp]),

@@ -231,9 +231,12 @@ enum { EPI_PATCH = 3, EPI_L2DIST = 4, EPI_SCALE = 5, EPI_L2MIN = 6, EPI_RESID_LN
        // modes 0 / 1 / 2 with the folded LayerNorm (fold_* fields), as instantiations of their own: chosen by launch_gemm
        EPI_FOLD_BASE = 8, EPI_STORE_FOLD = 8, EPI_GELU_FOLD = 9, EPI_RESID_FOLD = 10,
        EPI_RESID_FOLD_C = 11 /* ... that also re-centres the stream (fold_stat given) */,
-       EPI_L2MIN2 = 12 /* EPI_L2MIN with TWO planes per block (the smallest key + the second as a bound): the recall-only sweep at small k */ };
-#define L2MIN_PLANES 4            // planes of EPI_L2MIN (three keys + bound); EPI_L2MIN2 writes the first two plane slots of the same layout
-constexpr int l2min_planes(int mode) { return mode == EPI_L2MIN2 ? 2 : L2MIN_PLANES; }
+       EPI_L2MIN2 = 12 /* EPI_L2MIN with TWO planes per block (the smallest key + the second as a bound): the recall-only sweep at small k */,
+       EPI_L2MIN3 = 13 /* ... rows two planes, columns THREE (two keys + bound): small galleries, whose few, long column blocks make two planes' fp64 fallback frequent */ };
+#define L2MIN_PLANES 4            // planes of EPI_L2MIN (three keys + bound); EPI_L2MIN2 / 3 write the first two / three plane slots of the same layout
+constexpr int l2min_row_planes(int mode) { return (mode == EPI_L2MIN2 || mode == EPI_L2MIN3) ? 2 : L2MIN_PLANES; }     // per (row, block of 64 columns)
+constexpr int l2min_col_planes(int mode) { return mode == EPI_L2MIN2 ? 2 : (mode == EPI_L2MIN3 ? 3 : L2MIN_PLANES); }  // per (column, block of RB rows)
+constexpr bool l2min_half_keys(int mode) { return mode == EPI_L2MIN2 || mode == EPI_L2MIN3; }     // keys = half distances from pre-loaded accumulators (gemm.hip)
 
 int launch_gemm(const void *A, const void *W, const float *bias, void *out, int M, int N, int K, int dtype,
                 const GemmEpi &epi, hipStream_t stream);

@@ -131,7 +131,7 @@ __device__ __forceinline__ unsigned xor16_of(unsigned x, bool odd_row) {
 // to fp64 whenever its bound is in reach of the target's distance).
 template <int NPL>
 struct MinK {
-  static_assert(NPL == 2 || NPL == 4, "two or four planes");
+  static_assert(NPL == 2 || NPL == 3 || NPL == 4, "two, three or four planes");
   unsigned v[NPL];
   __device__ __forceinline__ void init() {
 #pragma unroll
@@ -142,6 +142,8 @@ struct MinK {
     // updated in place from the top down: left to hipcc the smallest slot's min was scheduled first into a temporary and copied back -- a v_mov per insert
     if constexpr (NPL == 2) {
       asm("v_med3_u32 %1, %0, %1, %2\n\tv_min_u32 %0, %0, %2" : "+v"(v[0]), "+v"(v[1]) : "v"(k));
+    } else if constexpr (NPL == 3) {
+      asm("v_med3_u32 %2, %1, %2, %3\n\tv_med3_u32 %1, %0, %1, %3\n\tv_min_u32 %0, %0, %3" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]) : "v"(k));
     } else {     // (four slots as one asm block: 7 spilled registers in the phased kernel -- the compiler's own schedule stays)
 #pragma unroll
       for (int q = NPL - 1; q >= 1; --q) v[q] = umed3(v[q - 1], v[q], k);
@@ -154,6 +156,11 @@ struct MinK {
       const unsigned x0 = min(v[0], o[3]), x1 = min(v[1], o[2]), x2 = min(v[2], o[1]), x3 = min(v[3], o[0]);
       const unsigned y0 = min(x0, x2), y2 = max(x0, x2), y1 = min(x1, x3), y3 = max(x1, x3);
       v[0] = min(y0, y1); v[1] = max(y0, y1); v[2] = min(y2, y3); v[3] = max(y2, y3);
+    } else if constexpr (NPL == 3) {     // the three smallest of the six = the elementwise min against the reversed partner; sorted by min3 / med3 / max3
+      const unsigned x0 = min(v[0], o[2]), x1 = min(v[1], o[1]), x2 = min(v[2], o[0]);
+      asm("v_min3_u32 %0, %1, %2, %3" : "=v"(v[0]) : "v"(x0), "v"(x1), "v"(x2));
+      asm("v_max3_u32 %0, %1, %2, %3" : "=v"(v[2]) : "v"(x0), "v"(x1), "v"(x2));
+      v[1] = umed3(x0, x1, x2);
     } else {
       const unsigned x0 = min(v[0], o[1]), x1 = min(v[1], o[0]);
       v[0] = min(x0, x1); v[1] = max(x0, x1);
@@ -185,10 +192,12 @@ __device__ __forceinline__ void l2min2_half_norms(const GemmParams &p, int m0, i
     }
 }
 
-template <int WM, int WN, int TM, int TN, int NPL>
+template <int WM, int WN, int TM, int TN, int NPLR, int NPL>      // NPLR / NPL: planes of the row / column direction
 __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmParams &p, int m0, int n0) {
   static_assert(TN == 4, "a wave's columns are one 64-column block");
+  static_assert((NPLR == 4) == (NPL == 4), "full-distance keys go with four planes in both directions");
   using Min4 = MinK<NPL>;
+  using MinR = MinK<NPLR>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int g = lane >> 4, l15 = lane & 15;
@@ -204,7 +213,7 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
     for (int e = 0; e < 4; ++e) {
       const int n = nbase + 16 * j + 4 * g + e;
       const bool v = n < p.N;
-      if constexpr (NPL != 2) cn[j][e] = v ? p.epi.coln[n] : 0.f;       // (two planes: the norms went into the accumulators before the K loop)
+      if constexpr (NPL == 4) cn[j][e] = v ? p.epi.coln[n] : 0.f;       // (two / three planes: the norms went into the accumulators before the K loop)
       cvalid |= (unsigned)v << (4 * j + e);
     }
   Min4 col[TN][4];
@@ -218,12 +227,12 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
   //  and the validity bit per value that edge waves need: ~350 of ~3 750 vector instructions per wave and tile)
   // (`cols_too` stays a RUN-TIME test inside the pass -- a not-taken scalar branch per value: made a compile-time choice (per tile, or
   //  per fragment row) the pass becomes straight-line code and hipcc spills 68-380 registers; round 5, profiles/r05_experiments.txt 3)
-  auto row_pass = [&](int i, auto interior_c, Min4 &row) __attribute__((always_inline)) {
+  auto row_pass = [&](int i, auto interior_c, MinR &row) __attribute__((always_inline)) {
     constexpr bool INTERIOR = decltype(interior_c)::value;
     const int m = mbase + 16 * i + l15;
     const bool mv = INTERIOR || m < p.M;
     float rn = 0.f;
-    if constexpr (NPL != 2) rn = mv ? p.epi.rown[m] : 0.f;
+    if constexpr (NPL == 4) rn = mv ? p.epi.rown[m] : 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -232,9 +241,9 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
         // as a signed-integer max, which needs no canonicalisation; its key then sorts first, as it must
         // (two planes: the accumulator holds -d / 2; the key's mask drops the sign with the index bits)
         unsigned bits;
-        if constexpr (NPL == 2) bits = __float_as_uint(acc[i][j][e]);
+        if constexpr (NPL != 4) bits = __float_as_uint(acc[i][j][e]);
         else bits = (unsigned)max(__float_as_int((rn - 2.0f * acc[i][j][e]) + cn[j][e]), 0);
-        constexpr unsigned KMASK = NPL == 2 ? 0x8000007Fu : 127u;
+        constexpr unsigned KMASK = NPL != 4 ? 0x8000007Fu : 127u;
         unsigned kr = key_bfi(KMASK, (unsigned)(16 * j + 4 * g + e), bits), kc = key_bfi(KMASK, (unsigned)(16 * i + l15), bits);
         if constexpr (!INTERIOR) {
           const bool v = mv && ((cvalid >> (4 * j + e)) & 1);
@@ -249,27 +258,27 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
   for (int i = 0; i < TM; ++i) {
     const int m = mbase + 16 * i + l15;
     const bool mv = m < p.M;
-    Min4 row;
+    MinR row;
     row.init();
     if (interior) row_pass(i, std::true_type{}, row);
     else row_pass(i, std::false_type{}, row);
     // the row's 64 columns of this wave sit in the four lanes l15 + 16 g: merge (xor 16, xor 32)
     {
       const bool odd = (g & 1) != 0, up = g >= 2;
-      unsigned o[NPL];
+      unsigned o[NPLR];
 #pragma unroll
-      for (int q = 0; q < NPL; ++q) o[q] = xor16_of(row.v[q], odd);
+      for (int q = 0; q < NPLR; ++q) o[q] = xor16_of(row.v[q], odd);
       row.merge(o);
 #pragma unroll
-      for (int q = 0; q < NPL; ++q) o[q] = xor32_of(row.v[q], up);
+      for (int q = 0; q < NPLR; ++q) o[q] = xor32_of(row.v[q], up);
       row.merge(o);
     }
     // lane g stores plane g (keys 1-3, bound): 16 consecutive rows each (64-byte segments).  A wave whose 64 columns lie
     // wholly past N owns no block (its slot would be the next plane's block 0).
-    if (mv && nbase < p.N && g < NPL) {
+    if (mv && nbase < p.N && g < NPLR) {
       unsigned mine = row.v[0];
 #pragma unroll
-      for (int q = 1; q < NPL; ++q) mine = g == q ? row.v[q] : mine;
+      for (int q = 1; q < NPLR; ++q) mine = g == q ? row.v[q] : mine;
       p.epi.rowk[(size_t)g * rstride + (size_t)cblk * p.M + m] = mine;
     }
   }
@@ -336,9 +345,9 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[TM][TN], const GemmPa
       if ((int)(threadIdx.x >> 6) / WN == 0) __builtin_amdgcn_s_barrier();
     }
   };
-  if constexpr (MODE == EPI_L2MIN || MODE == EPI_L2MIN2) {
+  if constexpr (MODE == EPI_L2MIN || l2min_half_keys(MODE)) {
     rejoin();
-    if constexpr (TN == 4) l2min_epilogue<WM, WN, TM, TN, l2min_planes(MODE)>(acc, p, m0, n0);
+    if constexpr (TN == 4) l2min_epilogue<WM, WN, TM, TN, l2min_row_planes(MODE), l2min_col_planes(MODE)>(acc, p, m0, n0);
     return;
   }
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -933,7 +942,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(GemmParams p) {
   __syncthreads();
 
   [[maybe_unused]] float hr[TM], hc[TN][4];       // EPI_L2MIN2: -(norms) / 2 of the tile about to start (l2min2_half_norms)
-  if constexpr (MODE == EPI_L2MIN2 && TN == 4) l2min2_half_norms<WM, WN, TM, TN>(p, m0, n0, hr, hc);
+  if constexpr (l2min_half_keys(MODE) && TN == 4) l2min2_half_norms<WM, WN, TM, TN>(p, m0, n0, hr, hc);
   while (true) {
 
     f32x4 acc[TM][TN];
@@ -941,7 +950,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(GemmParams p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if constexpr (MODE == EPI_L2MIN2 && TN == 4) acc[i][j] = (f32x4){hr[i] + hc[j][0], hr[i] + hc[j][1], hr[i] + hc[j][2], hr[i] + hc[j][3]};
+        if constexpr (l2min_half_keys(MODE) && TN == 4) acc[i][j] = (f32x4){hr[i] + hc[j][0], hr[i] + hc[j][1], hr[i] + hc[j][2], hr[i] + hc[j][3]};
         else acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
 
@@ -993,7 +1002,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(GemmParams p) {
       cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     }
 
-    if constexpr (MODE == EPI_L2MIN2 && TN == 4) {
+    if constexpr (l2min_half_keys(MODE) && TN == 4) {
       if (has_next) l2min2_half_norms<WM, WN, TM, TN>(p, m0n, n0n, hr, hc);
     }
     tile_epilogue<T, MODE, OutT, WM, WN, TM, TN, STAGE / NW>(acc, p, m0, n0, ((cur + NSTAGE - 1) % NSTAGE) * STAGE);
@@ -1276,7 +1285,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
     const int n = tn0 + tid - 256;
     return n < p.N ? -0.5f * p.epi.coln[n] : 0.f;
   };
-  if constexpr (MODE == EPI_L2MIN2) {
+  if constexpr (l2min_half_keys(MODE)) {
     nrm[tid] = fetch_norm(m0, n0);
     __syncthreads();
   }
@@ -1291,7 +1300,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if constexpr (MODE == EPI_L2MIN2) {     // (l2min2_half_norms' layout: row 16 i + (lane & 15) of the wave's 128, columns 16 j + 4 g .. + 3 of its 64)
+        if constexpr (l2min_half_keys(MODE)) {     // (l2min2_half_norms' layout: row 16 i + (lane & 15) of the wave's 128, columns 16 j + 4 g .. + 3 of its 64)
           const float hr = nrm[wr * 128 + 16 * i + (lane & 15)];
           const float4 hc = *reinterpret_cast<const float4 *>(nrm + 256 + wc * 64 + 16 * j + 4 * g);
           acc[i][j] = (f32x4){hr + hc.x, hr + hc.y, hr + hc.z, hr + hc.w};
@@ -1448,7 +1457,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
       rd_step = -rd_step;
     }
     };
-    if constexpr (MODE != EPI_L2MIN && MODE != EPI_L2MIN2 && MODE != EPI_PATCH && MODE != EPI_RESID_LN) {   // (those keep one copy: register budgets)
+    if constexpr (MODE != EPI_L2MIN && !l2min_half_keys(MODE) && MODE != EPI_PATCH && MODE != EPI_RESID_LN) {   // (those keep one copy: register budgets)
       const bool this_in = m0 + BM <= p.M && n0 + BN <= p.N, next_in = !has_next || (m0n + BM <= p.M && n0n + BN <= p.N);
       if (this_in && next_in) kloop(std::true_type{});
       else kloop(std::false_type{});
@@ -1460,7 +1469,7 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
                         //  tile's bias / statistics / first residual rows)
 
     [[maybe_unused]] float nrm_next = 0.f;
-    if constexpr (MODE == EPI_L2MIN2) {
+    if constexpr (l2min_half_keys(MODE)) {
       if (has_next) nrm_next = fetch_norm(m0n, n0n);      // requested here, written to LDS behind the epilogue
     }
     tile_epilogue<T, MODE, OutT, WM, WN, TM, TN, STAGE / NW, true>(acc, p, m0, n0, (cur ^ 1) * STAGE);
@@ -1475,8 +1484,8 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(GemmParams p) {
     }
     VTC_STAMP_TILE_END(!has_next);   // epilogue issue
     if (!has_next) break;
-    relax_first = MODE != EPI_L2MIN && MODE != EPI_L2MIN2 && MODE != EPI_RESID_LN && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 3) == 0);   // the tile just stored took a fast path
-    if constexpr (MODE == EPI_L2MIN2) {    // (every wave read this tile's norms before its K loop: long before any wave gets here)
+    relax_first = MODE != EPI_L2MIN && !l2min_half_keys(MODE) && MODE != EPI_RESID_LN && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 3) == 0);   // the tile just stored took a fast path
+    if constexpr (l2min_half_keys(MODE)) {    // (every wave read this tile's norms before its K loop: long before any wave gets here)
       nrm[tid] = nrm_next;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -1533,7 +1542,7 @@ template <int MODE, typename OutT, typename T, int DEEP>
 int run_phased_d(GemmParams p, hipStream_t stream) {
   p.MT = cdiv(p.M, 256); p.NT = cdiv(p.N, 256);
   const int ntiles = p.MT * p.NT;
-  const size_t shmem = (size_t)2 * 512 * ROWB + (MODE == EPI_RESID_LN ? 16 : 0) + (MODE == EPI_L2MIN2 ? 2048 : 0);   // 128 KiB: one workgroup per CU (+ the ticket word / the tile's half norms)
+  const size_t shmem = (size_t)2 * 512 * ROWB + (MODE == EPI_RESID_LN ? 16 : 0) + (l2min_half_keys(MODE) ? 2048 : 0);   // 128 KiB: one workgroup per CU (+ the ticket word / the tile's half norms)
   const int grid = min(ntiles, num_cus());
   static PerDeviceOnce attr;
   if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&gemm_phased_kernel<MODE, OutT, T, DEEP>), (int)shmem, "gemm_phased")) return 1;
@@ -1547,7 +1556,7 @@ template <int MODE, typename OutT, typename T>
 int run_phased(const GemmParams &p, hipStream_t stream) {
   // the deep pipeline needs two K-tiles per tile; the fused-LayerNorm tail and the sweep's block-minima epilogue stay on the
   // round-3 loop (register budgets: EPI_L2MIN with the deep loop spills 18 registers and measures the same, r04_experiments.txt 7)
-  if constexpr (MODE != EPI_RESID_LN && MODE != EPI_L2MIN && MODE != EPI_L2MIN2) {
+  if constexpr (MODE != EPI_RESID_LN && MODE != EPI_L2MIN && !l2min_half_keys(MODE)) {
     if (p.K >= 128) {
       if (g_deep >= 1) return run_phased_d<MODE, OutT, T, 1>(p, stream);
     }
@@ -1602,6 +1611,10 @@ int run_l2min(const GemmParams &p, hipStream_t stream) {
     if (p.epi.rb == 128) return run_phased<EPI_L2MIN2, float, bf16_t>(p, stream);
     return run<bf16_t, EPI_L2MIN2, float, 2, 2, 4, 4, 2>(p, stream);
   }
+  if (p.epi.mode == EPI_L2MIN3) {
+    if (p.epi.rb == 128) return run_phased<EPI_L2MIN3, float, bf16_t>(p, stream);
+    return run<bf16_t, EPI_L2MIN3, float, 2, 2, 4, 4, 2>(p, stream);
+  }
   if (p.epi.rb == 128) return run_phased<EPI_L2MIN, float, bf16_t>(p, stream);
   return run<bf16_t, EPI_L2MIN, float, 2, 2, 4, 4, 2>(p, stream);
 }
@@ -1638,6 +1651,7 @@ int dispatch(GemmParams p, hipStream_t stream) {
     case EPI_SCALE: return run_cfg<T, EPI_SCALE, float>(p, stream);
     case EPI_L2MIN:
     case EPI_L2MIN2:
+    case EPI_L2MIN3:
       if constexpr (sizeof(T) == 2 && !std::is_same<T, f16_t>::value) return run_l2min(p, stream);
       break;
     case EPI_RESID_LN:

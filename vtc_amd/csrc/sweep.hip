@@ -1298,13 +1298,19 @@ Sweep2Ws plan2(char *ws, int ng, int nq, int d, bool bidir) {
 // an untrained model -- and for a query whose target leads its list (a trained model) almost nothing is in reach: the fp64 re-rank of
 // ~20 candidate rows per query (the sweep's largest consumer of bytes) shrinks to the target row and a handful.  Same hits as
 // vtc_l2_topk_bidir + vtc_recall_hits_pair, bit for bit in the counters.
-// Planes the recall-only sweep asks of the distance GEMM: for max(k) <= 16 the block's smallest key + the second as a bound (EPI_L2MIN2: half
-// the epilogue's insert instructions and half the plane bytes; a block with two entries in reach of a target goes to fp64, which for a target
-// with r closer entries happens about r^2 / (2 x blocks) of the time), else three keys + bound.  VTC_SWEEP_PLANES=4 keeps four planes.
-static int recall_planes(int kmax) {
+// What the recall-only sweep asks of the distance GEMM (gemm.hip, l2min_epilogue).  max(k) <= 16 and many blocks per row (>= 16 384 rows): the
+// block's smallest key + the second as a bound in both directions (EPI_L2MIN2: 6 vector instructions per value, half the plane bytes) -- a block
+// with two entries in reach of a target goes to fp64 whole, which for a target with r closer entries happens about r^2 / (2 x blocks) of the time:
+// rare at 50k (782 / 391 blocks).  At 10k (157 / 79 blocks) it is not, and the COLUMN direction -- blocks of 128 rows: twice as likely and twice
+// as dear as the rows' blocks of 64 -- made the finish kernel 93 us of a 0.3 ms sweep on low-recall data: there the columns keep two keys + bound
+// (EPI_L2MIN3: rows two planes, columns three; 7 per value).  max(k) > 16: three keys + bound in both.  VTC_SWEEP_PLANES=2|3|4 forces a form.
+static int recall_mode(int kmax, int n_total) {
   static const int force = [] { const char *e = getenv("VTC_SWEEP_PLANES"); return e ? atoi(e) : 0; }();
-  if (force == 2 || force == 4) return force;
-  return kmax <= 16 ? 2 : L2MIN_PLANES;
+  if (force == 2) return EPI_L2MIN2;
+  if (force == 3) return EPI_L2MIN3;
+  if (force == 4) return EPI_L2MIN;
+  if (kmax > 16) return EPI_L2MIN;
+  return n_total < 16384 ? EPI_L2MIN3 : EPI_L2MIN2;
 }
 struct RankArgs {
   const unsigned *keys;        // [nsrc][NPL][nblk][R], NPL = 4 (EPI_L2MIN: three keys + bound) or 2 (EPI_L2MIN2: one key + bound) -- the kernel's template argument
@@ -1352,15 +1358,21 @@ __device__ __forceinline__ void wave_dist64_x8(const float *__restrict__ q, cons
 #pragma unroll
   for (int u = 0; u < 8; ++u) out[u] = sacc[u];
 }
+constexpr int RK_TLS = RK_CH * (RK_OW + 1);           // words of one plane's tile in LDS
+struct RankShared {
+  unsigned tl[L2MIN_PLANES * RK_TLS];
+  int amb[RK_OW][RK_AMB];
+  int ublk[RK_OW][RK_UB], uend[RK_OW][RK_UB];       // unsafe blocks: first entry and end (the block's or its source's)
+  int hsum[4][4];
+};
+// one direction's workgroup; NPL = planes of ITS key layout (the two directions of one sweep may differ: gemm.hip, EPI_L2MIN3)
 template <int NPL>
-__global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, const RankArgs PB, int nblocks_a) {
-  const bool second = (int)blockIdx.x >= nblocks_a;
-  const RankArgs &P = second ? PB : PA;
-  const int bid = second ? (int)blockIdx.x - nblocks_a : (int)blockIdx.x;
+__device__ __forceinline__ void recall_rank_body(const RankArgs &P, int bid, RankShared &sh) {
   const int R = P.R, nblk = P.nblk, bw = P.bw, ng = P.ng, d = P.d, kmax = P.kmax;
-  __shared__ unsigned tl[NPL][RK_CH * (RK_OW + 1)];
-  __shared__ int amb[RK_OW][RK_AMB];
-  __shared__ int ublk[RK_OW][RK_UB], uend[RK_OW][RK_UB];       // unsafe blocks: first entry and end (the block's or its source's)
+  unsigned *tl = sh.tl;
+  auto &amb = sh.amb;
+  auto &ublk = sh.ublk;
+  auto &uend = sh.uend;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int toff = P.tgt_off;
   constexpr int OPW = RK_OW / 4;                     // owners per wave
@@ -1400,8 +1412,8 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
       const int r = min(r0 + OPW * w + cc, R - 1);
       const float2 st = P.own_st[r];
       const float eps = 1.001f * (2.0f * (st.x * P.other_max[2] + st.y * P.other_max[1] + st.y * P.other_max[2]) + P.kappa * (P.own_norm[r] + P.other_max[0]));
-      // (two planes: the keys are HALF distances -- gemm.hip, EPI_L2MIN2 -- and so are the thresholds; halving is exact)
-      constexpr double KS = NPL == 2 ? 0.5 : 1.0;
+      // (two / three planes: the keys are HALF distances -- gemm.hip, EPI_L2MIN2 -- and so are the thresholds; halving is exact)
+      constexpr double KS = NPL != 4 ? 0.5 : 1.0;
       lo[cc] = __double2float_rd(KS * (dt[cc] - (double)eps));      // key <  lo  =>  key + eps < d_t
       hi[cc] = __double2float_ru(KS * (dt[cc] + (double)eps));      // key >  hi  =>  key - eps > d_t
     }
@@ -1422,14 +1434,14 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
       uint4 v[RK_CH * NPL / 32];
 #pragma unroll
       for (int q = 0; q < RK_CH * NPL / 32; ++q) {     // (block, plane) pairs vb + 32 q of the chunk: plane = pair % NPL, block = pair / NPL
-        const int pr = vb + 32 * q, pl = pr & (NPL - 1), bl = pr / NPL, blk = c0 + bl;
+        const int pr = vb + 32 * q, pl = pr % NPL, bl = pr / NPL, blk = c0 + bl;
         const bool ok = blk < nblk && r0 + vo < R;
         v[q] = ok ? *reinterpret_cast<const uint4 *>(keys + pl * plane + (size_t)blk * R + r0 + vo) : make_uint4(0x7F800000u, 0x7F800000u, 0x7F800000u, 0x7F800000u);
       }
 #pragma unroll
       for (int q = 0; q < RK_CH * NPL / 32; ++q) {
-        const int pr = vb + 32 * q, pl = pr & (NPL - 1), bl = pr / NPL;
-        unsigned *dst = &tl[pl][bl * (RK_OW + 1) + vo];
+        const int pr = vb + 32 * q, pl = pr % NPL, bl = pr / NPL;
+        unsigned *dst = &tl[(pl) * RK_TLS + bl * (RK_OW + 1) + vo];
         dst[0] = v[q].x; dst[1] = v[q].y; dst[2] = v[q].z; dst[3] = v[q].w;
       }
     } else {
@@ -1439,7 +1451,7 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
         const bool ok = blk < nblk && r0 + so < R;
         const size_t o = ok ? (size_t)blk * R + r0 + so : 0;
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) tl[pl][bl * (RK_OW + 1) + so] = ok ? keys[pl * plane + o] : 0x7F800000u;
+        for (int pl = 0; pl < NPL; ++pl) tl[(pl) * RK_TLS + bl * (RK_OW + 1) + so] = ok ? keys[pl * plane + o] : 0x7F800000u;
       }
     }
     __syncthreads();
@@ -1448,7 +1460,7 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
 #pragma unroll
     for (int cc = 0; cc < OPW; ++cc) {
       const int o = OPW * w + cc, tg = r0 + o + toff;
-      const unsigned k3 = tl[NPL - 1][lane * (RK_OW + 1) + o];            // the block's bound: its NPL-th smallest key
+      const unsigned k3 = tl[(NPL - 1) * RK_TLS + lane * (RK_OW + 1) + o];            // the block's bound: its NPL-th smallest key
       const bool unsafe = k3 != 0x7F800000u && __uint_as_float(k3 & ~127u) <= hi[cc];
       // the bound is an entry too (the block's NPL-th smallest): closer for certain, it raises the LOWER bound on the rank that ends a query as a
       // miss without any fp64 (with two planes a query whose few closer entries share blocks would otherwise go to fp64 for a rank >= max k)
@@ -1458,7 +1470,7 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
       bool any_am = false;
 #pragma unroll
       for (int pl = 0; pl < NPL - 1; ++pl) {
-        kk[pl] = tl[pl][lane * (RK_OW + 1) + o];
+        kk[pl] = tl[(pl) * RK_TLS + lane * (RK_OW + 1) + o];
         const float v = __uint_as_float(kk[pl] & ~127u);
         const bool valid = kk[pl] != 0x7F800000u && base + (int)(kk[pl] & 127u) != tg;     // (the target itself is not counted)
         const bool dc = valid && v < lo[cc];
@@ -1548,13 +1560,19 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
     for (int qk = 0; qk < 4; ++qk)
       if (qk < P.nk && rank < P.k[qk]) ++hit_cnt[qk];
   }
-  __shared__ int hsum[4][4];
+  auto &hsum = sh.hsum;
   if (lane == 0) {
 #pragma unroll
     for (int qk = 0; qk < 4; ++qk) hsum[w][qk] = hit_cnt[qk];
   }
   __syncthreads();
   if (t < 4) P.part[(size_t)bid * 4 + t] = hsum[0][t] + hsum[1][t] + hsum[2][t] + hsum[3][t];
+}
+template <int NPLA, int NPLB>
+__global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, const RankArgs PB, int nblocks_a) {
+  __shared__ RankShared sh;
+  if ((int)blockIdx.x < nblocks_a) recall_rank_body<NPLA>(PA, (int)blockIdx.x, sh);
+  else recall_rank_body<NPLB>(PB, (int)blockIdx.x - nblocks_a, sh);
 }
 // The rows recall_rank_kernel left over, one workgroup per row: a DEFERRED row (r | RK_HARD) comes with its lists -- the four waves split its
 // fp64 evaluations; a row whose lists overflowed (dense near-ties around the target) gets its rank by fp64 brute force over the other side.
@@ -1714,9 +1732,9 @@ int recall_bidir_impl(const float *a, const float *b, int n, int d, const int *k
   VTC_LAUNCH_CHECK("l2_recall prologue");
   int kmax = 0;
   for (int i = 0; i < nk; ++i) kmax = std::max(kmax, k_vals[i]);
-  const int npl = recall_planes(kmax);
+  const int mode = recall_mode(kmax, n);
   GemmEpi e;
-  e.mode = npl == 2 ? EPI_L2MIN2 : EPI_L2MIN; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
+  e.mode = mode; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
   e.rowk = s.rowk; e.colk = s.colk; e.nblk_c = s.nblk_c; e.nblk_r = s.nblk_r; e.rb = s.rb;
   if (int rc = launch_gemm(s.qb, s.gb, nullptr, nullptr, n, n, d, VTC_BF16, e, stream)) return rc;
   const float kappa = exact2_kappa(d);
@@ -1728,10 +1746,11 @@ int recall_bidir_impl(const float *a, const float *b, int n, int d, const int *k
   for (int i = 0; i < nk; ++i) { r1.k[i] = r2.k[i] = k_vals[i]; kmax = std::max(kmax, k_vals[i]); }
   r1.kmax = r2.kmax = kmax;
   {
-    ProfScope prof(VTC_PROF_TOPK, (double)npl * ((double)s.nblk_c + s.nblk_r) * n * 4 + 4.0 * n * d * 4, stream);
+    ProfScope prof(VTC_PROF_TOPK, ((double)l2min_row_planes(mode) * s.nblk_c + (double)l2min_col_planes(mode) * s.nblk_r) * n * 4 + 4.0 * n * d * 4, stream);
     const int nb = cdiv(n, RK_OW);
-    if (npl == 2) hipLaunchKernelGGL(recall_rank_kernel<2>, dim3(2 * nb), dim3(256), 0, stream, r1, r2, nb);
-    else hipLaunchKernelGGL(recall_rank_kernel<4>, dim3(2 * nb), dim3(256), 0, stream, r1, r2, nb);
+    if (mode == EPI_L2MIN2) hipLaunchKernelGGL((recall_rank_kernel<2, 2>), dim3(2 * nb), dim3(256), 0, stream, r1, r2, nb);
+    else if (mode == EPI_L2MIN3) hipLaunchKernelGGL((recall_rank_kernel<2, 3>), dim3(2 * nb), dim3(256), 0, stream, r1, r2, nb);
+    else hipLaunchKernelGGL((recall_rank_kernel<4, 4>), dim3(2 * nb), dim3(256), 0, stream, r1, r2, nb);
   }
   {
     ProfScope prof(VTC_PROF_TOPK, 0.0, stream);
@@ -1805,8 +1824,9 @@ static void launch_rank_one(const RankArgs &r, int npl, hipStream_t stream) {
   {
     ProfScope prof(VTC_PROF_TOPK, (double)npl * r.nsrc * r.nblk * r.R * 4 + 2.0 * r.R * r.d * 4, stream);
     const int nb = cdiv(r.R, RK_OW);
-    if (npl == 2) hipLaunchKernelGGL(recall_rank_kernel<2>, dim3(nb), dim3(256), 0, stream, r, r, nb);
-    else hipLaunchKernelGGL(recall_rank_kernel<4>, dim3(nb), dim3(256), 0, stream, r, r, nb);
+    if (npl == 2) hipLaunchKernelGGL((recall_rank_kernel<2, 2>), dim3(nb), dim3(256), 0, stream, r, r, nb);
+    else if (npl == 3) hipLaunchKernelGGL((recall_rank_kernel<3, 3>), dim3(nb), dim3(256), 0, stream, r, r, nb);
+    else hipLaunchKernelGGL((recall_rank_kernel<4, 4>), dim3(nb), dim3(256), 0, stream, r, r, nb);
   }
   {
     ProfScope prof(VTC_PROF_TOPK, 0.0, stream);
@@ -1822,10 +1842,10 @@ static int fill_k(RankArgs &r, const int *k_vals, int nk) {
   return r.kmax;
 }
 
-extern "C" int vtc_l2_recall_planes(const int *k_vals, int nk) {
+extern "C" int vtc_l2_recall_planes(const int *k_vals, int nk, int n_total) {
   int kmax = 0;
   for (int i = 0; k_vals && i < nk; ++i) kmax = std::max(kmax, k_vals[i]);
-  return recall_planes(kmax);
+  return l2min_col_planes(recall_mode(kmax, n_total));       // (the planes that travel: the column direction's)
 }
 
 extern "C" int vtc_l2_recall_shard_supported(int n_total, int n_local, int d) {
@@ -1852,9 +1872,9 @@ extern "C" int vtc_l2_recall_shard_rows(const float *a_all, const float *b_local
   VTC_LAUNCH_CHECK("l2_recall_shard_rows prologue");
   int kmax = 0;
   for (int i = 0; i < nk; ++i) kmax = std::max(kmax, k_vals[i]);
-  const int npl = recall_planes(kmax);
+  const int mode = recall_mode(kmax, n_total), npl = l2min_col_planes(mode);
   GemmEpi e;
-  e.mode = npl == 2 ? EPI_L2MIN2 : EPI_L2MIN; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
+  e.mode = mode; e.out_dtype = VTC_F32; e.rown = s.qn; e.coln = s.gn;
   e.rowk = s.rowk; e.colk = col_planes; e.nblk_c = s.nblk_c; e.nblk_r = nblk_pad; e.rb = s.rb;
   for (int pl = 0; pl < npl && nblk_pad > s.nblk_r; ++pl)     // blocks this rank has no rows for (shards differ by a row): +inf keys
     (void)hipMemsetD32Async((hipDeviceptr_t)(col_planes + ((size_t)pl * nblk_pad + s.nblk_r) * n_total), 0x7F800000,
@@ -1863,7 +1883,7 @@ extern "C" int vtc_l2_recall_shard_rows(const float *a_all, const float *b_local
   RankArgs r{s.rowk, n_local, s.nblk_c, 64, 1, nullptr, row_base, b_local, a_all, n_total, d, s.qn, s.qst, s.gmax, exact2_kappa(d), 0, nk, {0, 0, 0, 0},
              (unsigned long long *)hits_b_from_a, s.flags, (int *)s.cand, s.cand_n, cdiv(n_local, RK_OW)};
   fill_k(r, k_vals, nk);
-  launch_rank_one(r, npl, stream);
+  launch_rank_one(r, l2min_row_planes(mode), stream);
   VTC_LAUNCH_CHECK("l2_recall_shard_rows");
   return 0;
 }
@@ -1888,7 +1908,7 @@ extern "C" int vtc_l2_recall_shard_cols(const float *b_all, const float *a_local
   }
   int kmax_ = 0;
   for (int i = 0; i < nk; ++i) kmax_ = std::max(kmax_, k_vals[i]);
-  const int npl = recall_planes(kmax_);
+  const int npl = l2min_col_planes(recall_mode(kmax_, n_total));
   RankArgs r{planes, n_local, nblk_pad, vtc_l2_sweep_row_block(), n_src, src_bounds, row_base, a_local, b_all, n_total, d, s.qn, s.qst, s.gmax,
              exact2_kappa(d), 0, nk, {0, 0, 0, 0}, (unsigned long long *)hits_a_from_b, s.flags, (int *)s.cand, s.cand_n, cdiv(n_local, RK_OW)};
   fill_k(r, k_vals, nk);

@@ -357,7 +357,7 @@ def recall_shard_rows(a_all: torch.Tensor, b_local: torch.Tensor, row_base: int,
     if ws is None or ws.numel() < need or ws.device != a_all.device:
         ws = workspace(need, a_all.device)
     ks = (C.c_int * len(k_vals))(*[int(k) for k in k_vals])
-    planes = torch.empty(L.lib().vtc_l2_recall_planes(ks, len(k_vals)), nblk_pad, n, dtype=torch.int32, device=a_all.device)
+    planes = torch.empty(L.lib().vtc_l2_recall_planes(ks, len(k_vals), n), nblk_pad, n, dtype=torch.int32, device=a_all.device)
     L.check(L.lib().vtc_l2_recall_shard_rows(a_all.data_ptr(), b_local.data_ptr(), n, nl, int(row_base), d, ks, len(k_vals), hits.data_ptr(),
                                              planes.data_ptr(), nblk_pad, ws.data_ptr(), ws.numel(), _stream()), "vtc_l2_recall_shard_rows")
     return planes
@@ -374,7 +374,7 @@ def recall_shard_cols(b_all: torch.Tensor, a_local: torch.Tensor, row_base: int,
     nl = a_local.shape[0]
     n_src, npl, nblk_pad, nl2 = planes.shape
     ks = (C.c_int * len(k_vals))(*[int(k) for k in k_vals])
-    if npl != L.lib().vtc_l2_recall_planes(ks, len(k_vals)) or nl2 != nl or src_bounds.numel() != n_src + 1:
+    if npl != L.lib().vtc_l2_recall_planes(ks, len(k_vals), n) or nl2 != nl or src_bounds.numel() != n_src + 1:
         raise ValueError(f"recall_shard_cols: planes {tuple(planes.shape)} / src_bounds {tuple(src_bounds.shape)} do not match n_local={nl}, "
                          f"k_vals={list(k_vals)}")
     assert hits.shape == (len(k_vals),) and hits.dtype == torch.int64 and hits.is_contiguous() and hits.device == b_all.device

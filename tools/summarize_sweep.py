@@ -27,9 +27,9 @@ for r in sorted(ours, key=lambda r: -int(r["TotalDurationNs"])):
     lines.append(f"| `{n}` | {int(r['Calls']) / sweeps:.2f} | {float(r['AverageNs']) / 1e3:.2f} | {t / 1e6 / sweeps:.4f} | {100.0 * t / tot:.1f} |")
 flop = 2.0 * N * N * 512
 g = gemm_ns / 1e9 / sweeps
-lines += ["", f"* distance GEMM (`EPI_L2MIN` = 6: three keys + bound per block, `EPI_L2MIN2` = 12: one key + bound -- R@K at max k <= 16; 2 N^2 512 = {flop / 1e12:.3f} TFLOP, never writes the matrix): {g * 1e3:.3f} ms = "
+lines += ["", f"* distance GEMM (`EPI_L2MIN` = 6: three keys + bound per block, `EPI_L2MIN2` = 12: one key + bound, `EPI_L2MIN3` = 13: rows one key + bound, columns two keys + bound (below 16 384 rows) -- R@K at max k <= 16; 2 N^2 512 = {flop / 1e12:.3f} TFLOP, never writes the matrix): {g * 1e3:.3f} ms = "
           f"**{flop / g / 1e12:.0f} TFLOP/s = {flop / g / 2.5e15:.3f} of the 2.5 PFLOP/s dense bf16 peak** -- the binding resource "
-          "(bound: mfma + valu: K = 512 is 8 K-tiles per 256 x 256 tile, then the block-minima epilogue's VALU work: 13 vector instructions per value with four planes, 6 with two (keys straight from accumulators that start at -(norms)/2))",
+          "(bound: mfma + valu: K = 512 is 8 K-tiles per 256 x 256 tile, then the block-minima epilogue's VALU work: 13 vector instructions per value with four planes, 6 / 7 in modes 12 / 13 (keys straight from accumulators that start at -(norms)/2))",
           f"* whole sweep: {flop / 1e12:.3f} TFLOP / {tot / 1e6 / sweeps:.3f} ms of kernels = {flop / (tot / 1e9 / sweeps) / 1e12:.0f} TFLOP/s = "
           f"{flop / (tot / 1e9 / sweeps) / 2.5e15:.3f} of the bf16 MFMA peak.  (Rounds 1-4 also printed 2 x 8 N^2 bytes / time / 8 TB/s here -- the "
           "bytes of a materialised fp32 matrix, which this sweep never writes; the counter-measured bytes are in profiles/r05_sweep_traffic.md.)"]

@@ -1574,22 +1574,23 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, con
   if ((int)blockIdx.x < nblocks_a) recall_rank_body<NPLA>(PA, (int)blockIdx.x, sh);
   else recall_rank_body<NPLB>(PB, (int)blockIdx.x - nblocks_a, sh);
 }
-// The rows recall_rank_kernel left over, one workgroup per row: a DEFERRED row (r | RK_HARD) comes with its lists -- the four waves split its
+// The rows recall_rank_kernel left over, one workgroup per row: a DEFERRED row (r | RK_HARD) comes with its lists -- the waves split its
 // fp64 evaluations; a row whose lists overflowed (dense near-ties around the target) gets its rank by fp64 brute force over the other side.
-__global__ __launch_bounds__(256) void recall_rank_finish_kernel(const RankArgs PA, const RankArgs PB, int nblocks_a) {
+constexpr int RK_FW = 8;        // waves of a finish workgroup: a deferred row is 64 - 128 fp64 distances of 2 KB rows, latency-bound -- eight at once per wave
+__global__ __launch_bounds__(64 * RK_FW) void recall_rank_finish_kernel(const RankArgs PA, const RankArgs PB, int nblocks_a) {
   const bool second = (int)blockIdx.x >= nblocks_a;
   const RankArgs &P = second ? PB : PA;
   const int bid = second ? (int)blockIdx.x - nblocks_a : (int)blockIdx.x;
   const int nbl = second ? (int)gridDim.x - nblocks_a : nblocks_a;
-  __shared__ int part[4];
+  __shared__ int part[RK_FW];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (bid == 0) {            // this direction's first workgroup: the rank kernel's per-workgroup hit counts -> one atomic per k
     int acc[4] = {0, 0, 0, 0};
-    for (int i = threadIdx.x; i < P.nparts; i += 256) {
+    for (int i = threadIdx.x; i < P.nparts; i += 64 * RK_FW) {
       const int4 v = *reinterpret_cast<const int4 *>(P.part + (size_t)i * 4);
       acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
     }
-    __shared__ int red[4][4];
+    __shared__ int red[RK_FW][4];
 #pragma unroll
     for (int qk = 0; qk < 4; ++qk) {
       int x = acc[qk];
@@ -1599,7 +1600,9 @@ __global__ __launch_bounds__(256) void recall_rank_finish_kernel(const RankArgs 
     }
     __syncthreads();
     if ((int)threadIdx.x < P.nk) {
-      const int x = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      int x = 0;
+#pragma unroll
+      for (int ww = 0; ww < RK_FW; ++ww) x += red[ww][threadIdx.x];
       if (x) atomicAdd(&P.hits[threadIdx.x], (unsigned long long)x);
     }
     __syncthreads();
@@ -1624,7 +1627,7 @@ __global__ __launch_bounds__(256) void recall_rank_finish_kernel(const RankArgs 
       base_rank = wk[0];
       const int n_amb = wk[1], n_ub = wk[2];
       const int n_eval = n_amb + n_ub * P.bw;           // evaluation e: e < n_amb -> ambiguous entry e; else entry (e - n_amb) % bw of unsafe block (e - n_amb) / bw
-      for (int e0 = 8 * w; e0 < n_eval; e0 += 32) {
+      for (int e0 = 8 * w; e0 < n_eval; e0 += 8 * RK_FW) {
         int jj[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -1641,7 +1644,7 @@ __global__ __launch_bounds__(256) void recall_rank_finish_kernel(const RankArgs 
         count_group(jj);
       }
     } else {
-      for (int j0 = 8 * w; j0 < P.ng; j0 += 32) {
+      for (int j0 = 8 * w; j0 < P.ng; j0 += 8 * RK_FW) {
         int jj[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) jj[u] = (j0 + u < P.ng && j0 + u != tg) ? j0 + u : -1;
@@ -1651,7 +1654,9 @@ __global__ __launch_bounds__(256) void recall_rank_finish_kernel(const RankArgs 
     if (lane == 0) part[w] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int rank = base_rank + part[0] + part[1] + part[2] + part[3];
+      int rank = base_rank;
+#pragma unroll
+      for (int ww = 0; ww < RK_FW; ++ww) rank += part[ww];
 #pragma unroll
       for (int qk = 0; qk < 4; ++qk)          // (constant indices: a run-time index into P.k[] sends the argument block to scratch)
         if (qk < P.nk && rank < P.k[qk]) atomicAdd(&P.hits[qk], 1ull);
@@ -1755,7 +1760,7 @@ int recall_bidir_impl(const float *a, const float *b, int n, int d, const int *k
   {
     ProfScope prof(VTC_PROF_TOPK, 0.0, stream);
     const int g = std::min(n, 1024);
-    hipLaunchKernelGGL(recall_rank_finish_kernel, dim3(2 * g), dim3(256), 0, stream, r1, r2, g);
+    hipLaunchKernelGGL(recall_rank_finish_kernel, dim3(2 * g), dim3(64 * RK_FW), 0, stream, r1, r2, g);
   }
   VTC_LAUNCH_CHECK("l2_recall_bidir");
   return 0;
@@ -1831,7 +1836,7 @@ static void launch_rank_one(const RankArgs &r, int npl, hipStream_t stream) {
   {
     ProfScope prof(VTC_PROF_TOPK, 0.0, stream);
     const int g = std::min(r.R, 1024);
-    hipLaunchKernelGGL(recall_rank_finish_kernel, dim3(g), dim3(256), 0, stream, r, r, g);
+    hipLaunchKernelGGL(recall_rank_finish_kernel, dim3(g), dim3(64 * RK_FW), 0, stream, r, r, g);
   }
 }
 

@@ -198,7 +198,11 @@ __device__ __forceinline__ void l2min_epilogue(f32x4 (&acc)[TM][TN], const GemmP
   static_assert((NPLR == 4) == (NPL == 4), "full-distance keys go with four planes in both directions");
   using Min4 = MinK<NPL>;
   using MinR = MinK<NPLR>;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the thread index made opaque once per tile, as in tile_epilogue: the sixteen key indices, the plane addresses and the lane's row /
+  //  column offsets are then formed per tile instead of being hoisted out of the tile loop and held across the K loop)
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int lane = tid_ & 63, wave = tid_ >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int g = lane >> 4, l15 = lane & 15;
   const int nbase = n0 + wc * 64, mbase = m0 + wr * TM * 16;
@@ -1556,6 +1560,7 @@ template <int MODE, typename OutT, typename T>
 int run_phased(const GemmParams &p, hipStream_t stream) {
   // the deep pipeline needs two K-tiles per tile; the fused-LayerNorm tail and the sweep's block-minima epilogue stay on the
   // round-3 loop (register budgets: EPI_L2MIN with the deep loop spills 18 registers and measures the same, r04_experiments.txt 7)
+  // (round 5: with the epilogue's thread index opaque the two-plane form fits the deep loop without spills -- 2.94 - 2.96 against 2.89 - 2.93 ms at 50k: no gain)
   if constexpr (MODE != EPI_RESID_LN && MODE != EPI_L2MIN && !l2min_half_keys(MODE)) {
     if (p.K >= 128) {
       if (g_deep >= 1) return run_phased_d<MODE, OutT, T, 1>(p, stream);

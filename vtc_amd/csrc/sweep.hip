@@ -1359,15 +1359,16 @@ __device__ __forceinline__ void wave_dist64_x8(const float *__restrict__ q, cons
   for (int u = 0; u < 8; ++u) out[u] = sacc[u];
 }
 constexpr int RK_TLS = RK_CH * (RK_OW + 1);           // words of one plane's tile in LDS
+template <int MAXP>      // planes of the wider of the kernel's two directions: 27 KiB of LDS with two planes (five workgroups per CU), 44 with four (three)
 struct RankShared {
-  unsigned tl[L2MIN_PLANES * RK_TLS];
+  unsigned tl[MAXP * RK_TLS];
   int amb[RK_OW][RK_AMB];
   int ublk[RK_OW][RK_UB], uend[RK_OW][RK_UB];       // unsafe blocks: first entry and end (the block's or its source's)
   int hsum[4][4];
 };
 // one direction's workgroup; NPL = planes of ITS key layout (the two directions of one sweep may differ: gemm.hip, EPI_L2MIN3)
-template <int NPL>
-__device__ __forceinline__ void recall_rank_body(const RankArgs &P, int bid, RankShared &sh) {
+template <int NPL, typename Shared>
+__device__ __forceinline__ void recall_rank_body(const RankArgs &P, int bid, Shared &sh) {
   const int R = P.R, nblk = P.nblk, bw = P.bw, ng = P.ng, d = P.d, kmax = P.kmax;
   unsigned *tl = sh.tl;
   auto &amb = sh.amb;
@@ -1570,7 +1571,7 @@ __device__ __forceinline__ void recall_rank_body(const RankArgs &P, int bid, Ran
 }
 template <int NPLA, int NPLB>
 __global__ __launch_bounds__(256) void recall_rank_kernel(const RankArgs PA, const RankArgs PB, int nblocks_a) {
-  __shared__ RankShared sh;
+  __shared__ RankShared<(NPLA > NPLB ? NPLA : NPLB)> sh;
   if ((int)blockIdx.x < nblocks_a) recall_rank_body<NPLA>(PA, (int)blockIdx.x, sh);
   else recall_rank_body<NPLB>(PB, (int)blockIdx.x - nblocks_a, sh);
 }

@@ -313,7 +313,9 @@ def pmc_traffic(workload_tag):
         except Exception:
             continue
         if j.get("workload") == workload_tag:
-            return round(float(j["traffic_bytes_per_launch"]), 1), {k: j.get(k) for k in ("commit", "date", "source")} | {"file": os.path.basename(f)}
+            return round(float(j["traffic_bytes_per_launch"]), 1), ({"stored": True, "note": "PMC passes cannot run inside the timed run: a stored figure "
+                                                                     "from the rocprofv3 --pmc passes of this command at the named commit"}
+                                                                    | {k: j.get(k) for k in ("commit", "date", "source")} | {"file": "profiles/" + os.path.basename(f)})
     return None, None
 
 
@@ -328,7 +330,7 @@ def sweep_pmc_traffic(n):
             continue
         e = j.get("sweeps", {}).get(str(n))
         if e:
-            return dict(e, file=os.path.basename(f), commit=j.get("commit"), date=j.get("date"))
+            return dict(e, stored=True, file="profiles/" + os.path.basename(f), commit=j.get("commit"), date=j.get("date"))
     return None
 
 
@@ -385,6 +387,17 @@ def secondary_points(m3, vid, title, comments, B, world, device, extra, k2):
     finally:
         TW.DEFAULT_FLAGS = was_flags
         m3._packed = {}
+    # ... and BOTH at once: dense text + every row of the last block = exactly the reference's arithmetic work, in 16-bit
+    log("extras: all the reference's work (dense text + full last block)")
+    try:
+        TW.DEFAULT_FLAGS = was_flags | L.TOWER_FULL_LAST_LAYER
+        TW.TEXT_RAGGED = False
+        m3._packed = {}
+        d = timed(lambda: m3(vid, title, comments), k2, world, device, warm=1)
+        extra[f"config3_B{B}_all_work_pairs_per_s"] = round(world * B / d, 1)
+    finally:
+        TW.DEFAULT_FLAGS, TW.TEXT_RAGGED = was_flags, was_ragged
+        m3._packed = {}
     for b in (50, 1):
         v, t, c = vid[:b].contiguous(), title[:b].contiguous(), comments[:b].contiguous()
         m3(v, t, c)
@@ -401,10 +414,10 @@ def secondary_points(m3, vid, title, comments, B, world, device, extra, k2):
     for i in range(64):
         nfr = [8, 13, 24, 30][i % 4]
         vids.append((vid[i % vid.shape[0], :1].expand(nfr, -1, -1, -1).contiguous() + 0.01 * i, title[i % B].cpu()))
-    RE.retrieval_evaluation(m3, vids, device, frame_stride=1)
+    RE.retrieval_evaluation(m3, vids, "full-test", device, frame_stride=1)
     n0 = launches()
     t0 = time.perf_counter()
-    RE.retrieval_evaluation(m3, vids, device, frame_stride=1)
+    RE.retrieval_evaluation(m3, vids, "full-test", device, frame_stride=1)
     torch.cuda.synchronize()
     d = time.perf_counter() - t0
     extra["chunked_eval_64_videos"] = {"videos_per_s": round(64 / d, 1), "ms_total": round(1e3 * d, 3), "launches": launches() - n0,
@@ -479,6 +492,54 @@ def e2e_eval(m3, B, title, comments, world, device, extra):
                    "forward (ToTensor + Normalize inside the vision tower) -> embeddings kept on the GPU -> R@1/5/10 both directions")
     extra["eval_e2e_pairs_per_s"] = res["overlapped_pairs_per_s"]
     extra["eval_e2e"] = res
+
+
+def eval_pipeline(m3, vid, N, B, rank, world, device, extra):
+    """BASELINE configs[3] end to end: a gallery of N synthetic pairs, rank r encodes its contiguous shard [lo_r, hi_r) batch by batch (no
+    collective), then ONE sharded sweep over the stacked embeddings (vtc_amd/dist.py sharded_recall: all-gather, one [N/G, N] distance GEMM
+    per rank, all-to-all of column planes, all-reduce of the counters) -- the code path of `torch.distributed.run evaluation/eval.py`
+    (vtc_amd/host/eval.py) with the inputs already in HBM.  Reported per phase, max over ranks; never part of `value`."""
+    from vtc_amd import dist as vdist
+    lo, hi = vdist.shard_bounds(N, rank, world)
+    log(f"extras: eval pipeline N={N}: rank {rank} encodes pairs [{lo}, {hi})")
+    gen = torch.Generator().manual_seed(991)                      # the same N titles / comments on every rank; a rank uses its slice
+    titles = synth_tokens(N, 77, gen)[lo:hi].to(device)
+    comms = synth_tokens(N * 5, 77, gen, empty_frac=0.1).reshape(N, 5, 77)[lo:hi].to(device)
+    gd = torch.Generator(device=device).manual_seed(4242 + rank)
+
+    def encode():
+        fv, ft = [], []
+        for b0 in range(0, hi - lo, B):
+            n = min(B, hi - lo - b0)
+            vid[:n].normal_(generator=gd)                          # fresh pixels per batch (identical videos would be exact duplicates in the sweep)
+            o = m3(vid[:n], titles[b0:b0 + n], comms[b0:b0 + n])
+            fv.append(o[0]); ft.append(o[1])
+        return torch.cat(fv), torch.cat(ft)
+
+    encode()                                                       # warm-up (workspaces of the last, shorter batch)
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    fv, ft = encode()
+    barrier_sync(world)
+    t_enc = max_over_ranks(time.perf_counter() - t0, world, device)
+    vdist.sharded_recall(fv, ft, N, [1, 5, 10], rank, world)      # warm-up
+    ph = {}
+    barrier_sync(world)
+    t1 = time.perf_counter()
+    r_ab, r_ba = vdist.sharded_recall(fv, ft, N, [1, 5, 10], rank, world, phases=ph)
+    barrier_sync(world)
+    t_sw = max_over_ranks(time.perf_counter() - t1, world, device)
+    phases = [ph]
+    if world > 1:
+        import torch.distributed as dist
+        phases = [None] * world
+        dist.all_gather_object(phases, ph)
+    extra[f"eval_pipeline_{N}"] = {
+        "pairs": N, "pairs_per_rank": hi - lo, "batch": B, "encode_ms": round(1e3 * t_enc, 2), "sweep_ms": round(1e3 * t_sw, 3),
+        "total_ms": round(1e3 * (t_enc + t_sw), 2), "pairs_per_s_end_to_end": round(N / (t_enc + t_sw), 1),
+        "sweep_phases_ms_per_rank": phases, "recall_t_from_v": r_ab, "recall_v_from_t": r_ba,
+        "what": "encode (collective-free, per rank) + exchange + sharded sweep: the multi-GPU eval entry's pipeline (evaluation/eval.py under "
+                "torch.distributed.run), inputs resident in HBM; random-init towers on random pixels: the recall values are chance level"}
 
 
 def headline_independence(m3, vid, title, comments, B):
@@ -729,9 +790,16 @@ def main():
             e2e_eval(m3, B, title, comments, world, device, extra)
         except Exception as e:   # noqa: BLE001
             extra["eval_e2e_error"] = repr(e)[:300]
+        try:
+            eval_pipeline(m3, vid, args.sweep_n, B, rank, world, device, extra)
+        except Exception as e:   # noqa: BLE001
+            extra["eval_pipeline_error"] = repr(e)[:300]
     # the ragged headline and the dense-text figure (all 77 positions: exactly the reference's work) side by side
     if f"config3_B{B}_dense_text_pairs_per_s" in extra:
         result["value_dense_text"] = extra[f"config3_B{B}_dense_text_pairs_per_s"]
+    if f"config3_B{B}_all_work_pairs_per_s" in extra:
+        # no output-dead work skipped: all 77 text positions AND every row of each tower's last block -- the reference's FLOPs exactly
+        result["value_all_work"] = extra[f"config3_B{B}_all_work_pairs_per_s"]
     adapter_sd = {k: v.detach().clone() for k, v in m3.state_dict().items()
                   if k.startswith("final_transformer.") or k in ("mask_embedding", "model.logit_scale")}
     del m3, vid, out
@@ -833,7 +901,10 @@ def main():
                 other_ms = sum(v["ms"] for k, v in cl.items() if k != "gemm_bf16")
                 if gk_["ms"] > 0:
                     result[f"sweep_{N}_roofline"] = {
-                        "bound": "mfma+valu", "kernel": "distance GEMM with the block-minima epilogue (gemm_phased_kernel<EPI_L2MIN>)",
+                        "bound": "mfma+valu",
+                        "kernel": ("distance GEMM with the block-minima epilogue (gemm_phased_kernel<" +
+                                   {2: "EPI_L2MIN2: two key planes, half-distance keys", 3: "EPI_L2MIN3: rows two / columns three key planes",
+                                    4: "EPI_L2MIN: four key planes"}[ops.recall_planes([1, 5, 10], N)] + ">)"),
                         "gemm_ms": round(gk_["ms"], 4), "gemm_launches": gk_["launches"], "gemm_tflops": round(gk_["work"] / gk_["ms"] / 1e9, 1),
                         "frac": round(gk_["work"] / (gk_["ms"] * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         # the whole job's distance FLOPs (one [N/G, N] GEMM per rank) over the WHOLE sweep's wall time and all ranks' peak

@@ -201,6 +201,12 @@ int vtc_segment_mean(const float *x, const int *offsets, float *out, int n_group
  * an overflow of the half format (|v| > 65504) shows as inf / NaN in the tower's output.  `flag` is int32 in device memory or in
  * pinned (device-visible) host memory, which the host can then poll without synchronising. */
 int vtc_nonfinite_flag(const float *x, size_t n, int *flag, void *stream);
+/* flag[0] |= 1 when x[0..n) holds a non-finite value, |= 2 when y[0..m) does -- one launch over the two embedding sets a wrapper's
+ * forward returns (ABI 7).  Every `PretrainedCLIP*.forward` ends with it (vtc_amd/host/model.py: the flag travels to pinned host
+ * memory by an asynchronous copy and is read at the model's next forward / check_finite()); RecallAtK and the eval entry points
+ * check their inputs with it and raise: a NaN embedding (an IEEE-half overflow in the text blocks, a one-launch CAM whose grid
+ * barrier gave up, non-finite weights or pixels) never reaches a recall figure silently. */
+int vtc_nonfinite_flag2(const float *x, size_t n, const float *y, size_t m, int *flag, void *stream);
 /* sim[nv,nt] = exp(*logit_scale) * v @ t^T, fp32 exact */
 int vtc_similarity(const float *v, const float *t, int nv, int nt, int d, const float *logit_scale, float *sim,
                    void *stream);

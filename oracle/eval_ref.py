@@ -121,3 +121,56 @@ def mean_chunks(video_embeddings: Sequence[torch.Tensor]) -> torch.Tensor:
     """evaluation/retrieval_evaluation.py:254-259: per-video mean over chunk embeddings,
     NOT re-normalised."""
     return torch.cat([torch.mean(k, dim=0, keepdim=True) for k in video_embeddings])
+
+
+def retrieval_evaluation_loop(forward, items, needs_comments: bool, branch: str = "text", frame_stride: int = 16,
+                              first_frame_only: bool = False, first_chunk_only: bool = False, n_comments: int = 5):
+    """The reference's per-video batch-1 loop, evaluation/retrieval_evaluation.py:143-264, line by line.
+
+    ``forward(frames, captions, comments | None) -> (feats_a, feats_b)`` is the model's forward (an oracle wrapper of model_ref.py);
+    ``items`` are dataset items ``(frames [T,3,H,W], captions [ncap,77], id)`` or ``(frames, captions, comments [nc,77], id)``; the
+    DataLoader's batch dimension of one (:136) is added here.  Returns (video_joint_tensor [N,D], caption_joint_tensor [N,ncap,D])
+    as :254-260 build them: the mean over a video's chunk embeddings, NOT re-normalised."""
+    video_joint_embeddings, caption_joint_embeddings = [], []
+    for it in items:
+        if len(it) == 3:                                                   # :144-150
+            frames, captions, comments = it[0][None], it[1][None], None
+        else:
+            frames, captions, comments = it[0][None], it[1][None], it[2][None]
+        assert captions.dim() == 3 and captions.shape[0] == 1              # :159
+        assert frames.dim() == 5 and frames.shape[0] == 1 and frames.shape[2] == 3
+        captions = captions[0]                                             # :163
+        if first_frame_only:                                               # :165-173 (the isinstance test of :166 is never true: every
+            frames = frames[0][0:1]                                        #  image model is also listed in video_models, :56-62)
+            assert not first_chunk_only
+        else:                                                              # :175-199
+            chunks = chunk_frames(frames, frame_stride, 8)
+            if first_chunk_only:
+                chunks = chunks[0:1]
+            frames = chunks
+        if needs_comments:                                                 # :203-231
+            ncomms = len(frames) if branch == "image" else len(captions)
+            if comments is None:
+                dummy = torch.zeros(n_comments, captions.shape[-1], dtype=torch.int64)      # clip.tokenize([""] * 5): [SOT, EOT, 0...]
+                dummy[:, 0], dummy[:, 1] = 49406, 49407
+                comments = torch.stack([dummy for _ in range(ncomms)])
+            else:
+                comments = comments[0, :n_comments]
+                comments = torch.stack([comments for _ in range(ncomms)])
+            feats_a, feats_b = forward(frames, captions, comments)
+        else:
+            feats_a, feats_b = forward(frames, captions, None)
+        video_joint_embeddings.append(feats_a)
+        caption_joint_embeddings.append(feats_b)
+    video_joint_tensor = mean_chunks(video_joint_embeddings)              # :254-259
+    caption_joint_tensor = torch.stack(caption_joint_embeddings)           # :260 (equal caption counts)
+    return video_joint_tensor, caption_joint_tensor
+
+
+def compute_recall_frame(tensor_v: torch.Tensor, tensor_t: torch.Tensor, split: str = "full-test", dataset_name: str = "MSRVTT",
+                         dtype=np.float32):
+    """compute_recall's DataFrame (:23-47), columns and index named as the reference names them."""
+    import pandas as pd
+    tvr, vtr = compute_recall_table(tensor_v, tensor_t, dtype)
+    return pd.DataFrame({f"{dataset_name} {split} split Video to Text": tvr, f"{dataset_name} {split} split Text to Video": vtr},
+                        index=[f"R@{i}" for i in (1, 5, 10)])

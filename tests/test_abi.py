@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     declared -= {"vtc_block_w", "vtc_vision_w", "vtc_text_w", "vtc_cam_w"}
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     lib = L.lib()                       # raises if the .so or any symbol is missing
-    assert lib.vtc_abi_version() == L.ABI_VERSION == 6
+    assert lib.vtc_abi_version() == L.ABI_VERSION == 7
     for name in declared:
         assert hasattr(lib, name)
 

@@ -290,3 +290,36 @@ def test_single_rank_path_of_sharded_recall_is_the_plain_recall():
     assert r_ab == dict(E.recall_at_k(a, b, [1, 5, 10])) and r_ba == dict(E.recall_at_k(b, a, [1, 5, 10]))
     assert vdist.sweep_path(n, 3, 1).startswith("two searches") and vdist.sweep_path(10000, 3, 1).startswith("one distance matrix")
     assert not vdist.one_matrix_sharded(10000, 3, 1, 11)
+
+
+def _worker_nonfinite(rank, world, port, n, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from vtc_amd import dist as vdist
+    vdist.init_from_env(backend="gloo")
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((n, 32)).astype(np.float32)
+    b = rng.standard_normal((n, 32)).astype(np.float32)
+    lo, hi = vdist.shard_bounds(n, rank, world)
+    if lo <= n - 2 < hi:
+        b[n - 2, 5] = np.nan               # ONE bad row, on the last rank only
+    try:
+        vdist.sharded_recall(torch.from_numpy(a[lo:hi]), torch.from_numpy(b[lo:hi]), n, [1, 5, 10], rank, world, topk=_cpu_topk)
+        out.put((rank, "returned"))
+    except ValueError as e:
+        out.put((rank, "raised" if "non-finite" in str(e) else str(e)))
+    dist.destroy_process_group()
+
+
+def test_a_nonfinite_row_on_one_rank_raises_on_every_rank():
+    """ADVICE r5 (medium) / VERDICT r5 #2: NaN embeddings never reach a recall figure.  The flag word rides behind the hit counters through
+    their all-reduce, so the rank that holds the bad row and the ranks that do not all raise -- nobody is left waiting in a collective."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    world, port = 3, _free_port()
+    procs = [ctx.Process(target=_worker_nonfinite, args=(r, world, port, 90, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert got == [(0, "raised"), (1, "raised"), (2, "raised")], got

@@ -1,7 +1,8 @@
 """GPU: the one-launch CAM's give-up path.  A grid barrier that cannot complete sets a device-visible error word; from
 then on every CAM forward on that device must take the multi-launch path -- same results, one line on stderr, rc 0 -- instead of failing
 for the rest of the process, and `vtc_cam_fused_gave_up` must say so.  The word is sticky per process, so the scenario runs in a child
-process with the library's test hook (VTC_CAM_TEST_GAVE_UP=1: the word starts set)."""
+process on the TEST build of the library (vtc_amd/lib/libvtc_hip_testhooks.so = the product objects + cam.hip compiled with
+-D VTC_TEST_HOOKS, where VTC_CAM_TEST_GAVE_UP=1 makes the word start set; the product library has no such switch)."""
 import os
 import subprocess
 import sys
@@ -49,7 +50,9 @@ print("CHILD_OK")
 
 
 def test_cam_falls_back_to_the_multi_launch_path_after_a_barrier_gave_up():
-    env = dict(os.environ, VTC_CAM_TEST_GAVE_UP="1")
+    testlib = os.path.join(ROOT, "vtc_amd", "lib", "libvtc_hip_testhooks.so")
+    assert os.path.exists(testlib), "build it: make -C vtc_amd/csrc testhooks (or __graft_entry__.build())"
+    env = dict(os.environ, VTC_CAM_TEST_GAVE_UP="1", VTC_HIP_LIB=testlib)
     r = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "CHILD_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
     assert r.stderr.count("the one-launch path is now OFF for this device") == 1          # said once, not per call

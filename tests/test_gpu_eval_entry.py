@@ -32,3 +32,60 @@ def test_eval_cli_matches_oracle_recall(cfg, n, tmp_path):
     # (no near-tie guard); the near-tie count is reported, not used
     print(f"[parity] {cfg}: near ties (fp64 gap < 1e-6) {E.near_ties(fv, ft)} / {E.near_ties(ft, fv)} of {n} queries per direction")
     assert {k: v for k, v in out.items() if k.startswith("R")} == E.eval_result_dict(fv, ft, np.float64)
+
+
+def _run_ranks(world, argv, tmp_path, extra_env=None):
+    """`python -m torch.distributed.run --nproc-per-node world evaluation/eval.py ...`: the ranks share card 0 (VTC_LOCAL_DEVICE) and
+    exchange over gloo -- the only multi-rank layout one card can run; the code path is the one RCCL takes."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VTC_LOCAL_DEVICE="0", VTC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "evaluation", "eval.py")] + argv
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    return r
+
+
+def test_eval_entry_under_torch_distributed_run_equals_the_one_process_json(tmp_path, monkeypatch):
+    """BASELINE configs[3]: evaluation/eval.py with WORLD_SIZE > 1 -- contiguous dataset shard per rank -> encode ->
+    sharded_recall (all-gather, one [N/G, N] GEMM per rank, all-to-all of column planes, all-reduce of the counters) -> rank 0 writes the
+    reference's JSON.  World 2 and 3 at a ragged N (1101 = 367 + 367 + 367 / 551 + 550: the rank-sharded exchange path needs a gallery
+    of >= 1024) must write the one-process run's JSON, key for key."""
+    import os
+    from vtc_amd.host import eval as ev
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg, n = os.path.join(root, "configs", "pretrained_clip_comments_attention.jsonc"), 1101
+    one = tmp_path / "one.json"
+    monkeypatch.setenv("VTC_EVAL_SEED", "1023")          # the same randomly initialised towers in this process and in every rank
+    out, fv, ft = ev.cli(["-c", cfg, "--bs", "128", "--n_pairs", str(n), "--out", str(one)])
+    want = json.load(open(one))
+    assert {k: v for k, v in want.items() if k.startswith("R")} == E.eval_result_dict(fv.cpu().numpy(), ft.cpu().numpy(), np.float64)
+    for world in (2, 3):
+        path = tmp_path / f"w{world}.json"
+        r = _run_ranks(world, ["-c", cfg, "--bs", "128", "--n_pairs", str(n), "--out", str(path)], tmp_path,
+                       {"VTC_EVAL_SEED": "1023"})
+        got = json.load(open(path))
+        assert got == want, (world, got, want)
+        assert r.stdout.count('"R1_title_from_im"') == 1          # rank 0 alone prints / writes
+
+
+def test_eval_entry_two_ranks_small_gallery_video_config(tmp_path, monkeypatch):
+    """The same entry on the TimeSformer + CAM config at N = 25 over 2 ranks: below 1 024 rows the sharded sweep takes the two-searches
+    path; the JSON still equals the one-process run's."""
+    import os
+    from vtc_amd.host import eval as ev
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg, n = os.path.join(root, "configs", "pretrained_clip_timesformer_comments_attention.jsonc"), 25
+    one = tmp_path / "one.json"
+    monkeypatch.setenv("VTC_EVAL_SEED", "1023")          # the same randomly initialised towers in this process and in every rank
+    ev.cli(["-c", cfg, "--bs", "8", "--n_pairs", str(n), "--out", str(one)])
+    path = tmp_path / "w2.json"
+    _run_ranks(2, ["-c", cfg, "--bs", "8", "--n_pairs", str(n), "--out", str(path)], tmp_path, {"VTC_EVAL_SEED": "1023"})
+    assert json.load(open(path)) == json.load(open(one))

@@ -33,7 +33,7 @@ def test_ragged_chunked_eval_matches_per_video_loop(branch):
         cap = A.synth_tokens(1, a, 200 + i)[0]
         com = A.synth_tokens(5, a, 300 + i, empty_frac=0.3) if i % 2 == 0 else None   # real comments or dummies
         videos.append((fr, cap, com))
-    table, v_emb, c_emb = RE.retrieval_evaluation(m, videos, device="cuda")
+    table, v_emb, c_emb = RE.retrieval_evaluation(m, videos, "full-test", "cuda", return_embeddings=True)
     # oracle: the reference's loop, one video at a time
     ref_v, ref_c = [], []
     for fr, cap, com in videos:
@@ -49,14 +49,14 @@ def test_ragged_chunked_eval_matches_per_video_loop(branch):
     # ranks: the table is computed from the GPU's embeddings, so hold it to the fp64 ranks of THOSE embeddings without a
     # near-tie guard (the EXACT sweep's contract), and report how the oracle's own embeddings rank (end-to-end view)
     tvr, vtr = E.compute_recall_table(v_emb.cpu(), c_emb.cpu(), np.float64)
-    np.testing.assert_array_equal(table["Video to Text"], tvr)
-    np.testing.assert_array_equal(table["Text to Video"], vtr)
+    np.testing.assert_array_equal(table["videos full-test split Video to Text"], tvr)
+    np.testing.assert_array_equal(table["videos full-test split Text to Video"], vtr)
     tvr_o, vtr_o = E.compute_recall_table(ref_v, ref_c, np.float64)
     nt = E.near_ties(ref_v.numpy(), ref_c.numpy()) + E.near_ties(ref_c.numpy(), ref_v.numpy())
     print(f"[parity] chunked eval ({branch}): near ties {nt}; oracle-embedding table {tvr_o.tolist()} / {vtr_o.tolist()}")
     if nt == 0:       # 6 videos: a 1e-6 gap between neighbours would be the only way the two embedding sets rank differently
-        np.testing.assert_array_equal(table["Video to Text"], tvr_o)
-        np.testing.assert_array_equal(table["Text to Video"], vtr_o)
+        np.testing.assert_array_equal(table["videos full-test split Video to Text"], tvr_o)
+        np.testing.assert_array_equal(table["videos full-test split Text to Video"], vtr_o)
 
 
 def test_ragged_chunked_eval_vit_b32_bf16_vs_per_video_oracle_loop():
@@ -84,7 +84,7 @@ def test_ragged_chunked_eval_vit_b32_bf16_vs_per_video_oracle_loop():
         cap = A.synth_tokens(1, a, 500 + i)[0]
         com = A.synth_tokens(5, a, 600 + i, empty_frac=0.3) if i != 1 else None        # real comments / the dummy ones
         videos.append((fr, cap, com))
-    table, v_emb, c_emb = RE.retrieval_evaluation(m, videos, device="cuda")
+    table, v_emb, c_emb = RE.retrieval_evaluation(m, videos, "full-test", "cuda", return_embeddings=True)
     ref_v, ref_c = [], []
     for fr, cap, com in videos:
         chunks = E.chunk_frames(fr[None], 16, 8)
@@ -96,4 +96,118 @@ def test_ragged_chunked_eval_vit_b32_bf16_vs_per_video_oracle_loop():
     ev, ec = float((v_emb.cpu() - ref_v).abs().max()), float((c_emb.cpu() - ref_c).abs().max())
     print(f"[parity] chunked eval ViT-B/32 bf16: video (mean of chunks) max err {ev:.3e}, caption max err {ec:.3e} (tol 1e-3)")
     assert ev < 1e-3 and ec < 1e-3
-    assert set(table) >= {"Video to Text", "Text to Video"}
+    assert list(table.columns) == ["videos full-test split Video to Text", "videos full-test split Text to Video"]
+
+
+# ---- the drop-in entry point: the reference's module path, signature and DataFrame ----------------------------------
+def _tiny_standin(monkeypatch, n_videos=7):
+    from vtc_amd.host import datasets as D
+    a = A.TINY
+    monkeypatch.setattr(D, "VIDEO_STANDIN", dict(D.VIDEO_STANDIN, n_videos=n_videos, min_frames=20, max_frames=16 * 8 * 3,
+                                                 resolution=a.image_resolution, context=a.context_length))
+    return a
+
+
+def _build(kind, cls_name, a, seed, **ctor):
+    from vtc_amd.host import model as HM
+    from vtc_amd.host.clip_arch import ClipConfig
+    sd = A.synth_model(a, seed, kind, nframes=8)
+    m = getattr(HM, cls_name)(model_type=ClipConfig(**asdict(a)), **ctor)
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().cuda()
+    m.compute_dtype = torch.float32
+    return m, sd
+
+
+def _check_frame(df, dataset_cls, split, name, forward, needs_comments, branch, **loop_kw):
+    """df (the drop-in's DataFrame) against the oracle's per-video loop over the same stand-in items + the oracle's fp64 ranks."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ds = dataset_cls(train=False, split=split)
+    items = [ds[i] for i in range(len(ds))]
+    ref_v, ref_c = E.retrieval_evaluation_loop(forward, items, needs_comments, branch, **loop_kw)
+    want = E.compute_recall_frame(ref_v, ref_c, split, name, np.float64)
+    assert list(df.columns) == list(want.columns) == [f"{name} {split} split Video to Text", f"{name} {split} split Text to Video"]
+    assert list(df.index) == ["R@1", "R@5", "R@10"]
+    nt = E.near_ties(ref_v.numpy(), ref_c[:, 0].numpy()) + E.near_ties(ref_c[:, 0].numpy(), ref_v.numpy())
+    print(f"[parity] retrieval_evaluation({name}, {split}): near ties {nt}; table\n{df}")
+    if nt == 0:
+        np.testing.assert_array_equal(df.to_numpy(), want.to_numpy())
+    vtt, ttv = df.loc["R@10"].tolist()                  # what trainer/trainer.py:162 reads
+    assert 0.0 <= vtt <= 100.0 and 0.0 <= ttv <= 100.0
+    return ref_v, ref_c
+
+
+def test_drop_in_entry_video_model_with_the_trainers_call(monkeypatch):
+    """trainer/trainer.py:159-173: ``retrieval_evaluation(self.model, "MSRVTT_videos", "full-val", self.device)`` twice -- as configured and
+    with ``branch_to_adapt_val = "skip"`` -- on a CAM video model; the DataFrame (column names included) equals the oracle's per-video
+    loop (evaluation/retrieval_evaluation.py:136-264) + fp64 ranks."""
+    from evaluation.retrieval_evaluation import retrieval_evaluation
+    from vtc_amd.host import datasets as D
+    a = _tiny_standin(monkeypatch)
+    m, sd = _build("timesformer_finaltf", "PretrainedCLIP_TimeSformer_finaltf", a, 71, branch_to_adapt_val="text", n_heads=2)
+    for branch in ("text", "skip"):
+        m.branch_to_adapt_val = branch
+        outdf = retrieval_evaluation(m, "MSRVTT_videos", "full-val", "cuda")
+        fwd = lambda fr, cap, com, b=branch: M.pretrained_clip_timesformer_finaltf(fr, cap, com, sd, a, b, n_heads=2)[:2]
+        _check_frame(outdf, D.VideoDatasetMSRVTT, "full-val", "MSRVTT_videos", fwd, True, branch)
+
+
+def test_drop_in_entry_comment_dataset_image_branch_and_csv(monkeypatch, tmp_path):
+    """A dataset that carries comments (K700_videos: items of four), the CAM on the image branch (one comment set per CHUNK, :207-208),
+    ``out_csv`` and ``first_chunk_only``."""
+    import pandas as pd
+    from evaluation.retrieval_evaluation import retrieval_evaluation
+    from vtc_amd.host import datasets as D
+    a = _tiny_standin(monkeypatch, 6)
+    m, sd = _build("timesformer_finaltf", "PretrainedCLIP_TimeSformer_finaltf", a, 72, branch_to_adapt_val="image", n_heads=2)
+    fwd = lambda fr, cap, com: M.pretrained_clip_timesformer_finaltf(fr, cap, com, sd, a, "image", n_heads=2)[:2]
+    csv = tmp_path / "out.csv"
+    outdf = retrieval_evaluation(m, "K700_videos", "test", "cuda", out_csv=str(csv))
+    _check_frame(outdf, D.VideoDatasetK700Comments, "test", "K700_videos", fwd, True, "image")
+    back = pd.read_csv(csv, index_col=0)
+    assert list(back.columns) == list(outdf.columns) and np.allclose(back.to_numpy(), outdf.to_numpy())
+    outdf1 = retrieval_evaluation(m, "K700_videos", "test", "cuda", None, 16, False, True)          # positional, first_chunk_only
+    _check_frame(outdf1, D.VideoDatasetK700Comments, "test", "K700_videos", fwd, True, "image", first_chunk_only=True)
+    with pytest.raises(Exception, match="Unknown dataset"):
+        retrieval_evaluation(m, "nope", "test", "cuda")
+
+
+@pytest.mark.parametrize("cls_name,kind", [("PretrainedCLIP", "clip"), ("PretrainedCLIP_finaltf", "clip_finaltf")])
+def test_drop_in_entry_image_models_and_first_frame_only(monkeypatch, cls_name, kind):
+    """The image wrappers are ``video_models`` too (:56-62): they get the 5-D chunks and average the per-frame ViT features of a chunk
+    (model/model.py:333-338, 465-470); ``first_frame_only`` hands them the first frame as a 4-D batch of one (:165-173)."""
+    from evaluation.retrieval_evaluation import image_models, retrieval_evaluation, video_models
+    from vtc_amd.host import datasets as D
+    a = _tiny_standin(monkeypatch, 6)
+    cam = kind.endswith("finaltf")
+    m, sd = _build(kind, cls_name, a, 73, **(dict(branch_to_adapt_val="text", n_heads=2) if cam else {}))
+    assert isinstance(m, image_models) and isinstance(m, video_models)
+    if cam:
+        fwd = lambda fr, cap, com: M.pretrained_clip_finaltf(fr, cap, com, sd, a, "text", n_heads=2)[:2]
+    else:
+        fwd = lambda fr, cap, com: M.pretrained_clip(fr, cap, sd, a)[:2]
+    outdf = retrieval_evaluation(m, "MSVD_videos", "test", "cuda")
+    ref_v, _ = _check_frame(outdf, D.VideoDatasetMSVD, "test", "MSVD_videos", fwd, cam, "text")
+    outdf_f, v_emb, c_emb = retrieval_evaluation(m, "MSVD_videos", "test", "cuda", first_frame_only=True, return_embeddings=True)
+    ref_vf, ref_cf = _check_frame(outdf_f, D.VideoDatasetMSVD, "test", "MSVD_videos", fwd, cam, "text", first_frame_only=True)
+    assert (v_emb.cpu() - ref_vf).abs().max() < 1e-5 and (c_emb.cpu() - ref_cf[:, 0]).abs().max() < 1e-5
+    assert (ref_vf - ref_v).abs().max() > 1e-3                 # one frame is not the mean of chunks
+
+
+def test_drop_in_first_frame_only_refuses_the_timesformer_wrappers_and_compute_recall_takes_cpu_tensors(monkeypatch):
+    from evaluation.retrieval_evaluation import compute_recall, retrieval_evaluation
+    a = _tiny_standin(monkeypatch, 3)
+    m, _ = _build("timesformer", "PretrainedCLIP_TimeSformer", a, 74)
+    with pytest.raises(ValueError, match="first_frame_only"):
+        retrieval_evaluation(m, "MSRVTT_videos", "full-test", "cuda", first_frame_only=True)
+    # compute_recall with the reference's arguments: CPU tensors, captions [N, 1, D] (:255-263)
+    g = torch.Generator().manual_seed(5)
+    v, t = torch.randn(300, 64, generator=g), torch.randn(300, 1, 64, generator=g)
+    df = compute_recall(v, t, split="jsfusion", dataset_name="MSRVTT")
+    want = E.compute_recall_frame(v, t, "jsfusion", "MSRVTT", np.float64)
+    assert list(df.columns) == list(want.columns)
+    np.testing.assert_array_equal(df.to_numpy(), want.to_numpy())
+    with pytest.raises(ValueError, match="one caption per video"):
+        compute_recall(v, torch.randn(300, 2, 64))

@@ -635,3 +635,52 @@ def test_recall_entry_points_refuse_what_they_do_not_cover():
                                       ws2.data_ptr(), ws2.numel(), s)
     assert rc != 0 and b"nblk_pad" in lib.vtc_last_error()
     torch.cuda.synchronize()
+
+
+def test_nonfinite_rows_are_misses_in_the_rank_path_and_rejected_by_the_metric():
+    """a NaN target distance made every fp64 comparison of the recall-only rank path false -- rank 0, a hit at every k.
+    (a) kernel level (ops.recall_bidir, no host check): a query / target pair with a non-finite embedding is a MISS at every k, and the
+        other rows' counters are those of the oracle with NaN distances never closer than anything (what an exact search does with them);
+        two planes (k <= 16) and four (k = 20), 1 100 and 4 099 rows;
+    (b) host level: RecallAtK.compute / compute_both / result and dist.sharded_recall raise ValueError on non-finite features
+        (check_finite, default on) instead of reporting a figure."""
+    from vtc_amd import dist as vdist
+    from vtc_amd import ops
+    from vtc_amd.host.metric import RecallAtK
+    for n, ks in ((1100, [1, 5, 10]), (4099, [1, 5, 10]), (1100, [1, 20])):
+        rng = np.random.default_rng(n + len(ks))
+        a = rng.standard_normal((n, 64)).astype(np.float32)
+        a /= np.linalg.norm(a, axis=1, keepdims=True)
+        b = (a + 0.9 * rng.standard_normal((n, 64))).astype(np.float32)
+        b /= np.linalg.norm(b, axis=1, keepdims=True)
+        a[5, 3] = np.nan
+        b[n - 7, :] = np.inf
+        got = ops.recall_bidir(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), ks).cpu().numpy()
+        a64, b64 = a.astype(np.float64), b.astype(np.float64)
+        want = np.zeros((2, len(ks)), dtype=np.int64)
+        for direction, (q, g) in enumerate(((b64, a64), (a64, b64))):
+            for i0 in range(0, n, 512):
+                with np.errstate(invalid="ignore", over="ignore"):
+                    dd = ((q[i0:i0 + 512, None, :] - g[None, :, :]) ** 2).sum(-1)
+                for r in range(dd.shape[0]):
+                    i = i0 + r
+                    dt = dd[r, i]
+                    if not np.isfinite(dt):
+                        continue                                       # a miss at every k
+                    row = np.where(np.isfinite(dd[r]), dd[r], np.inf)
+                    rank = int((row < dt).sum() + ((row == dt) & (np.arange(n) < i)).sum())
+                    want[direction] += [rank < k for k in ks]
+        np.testing.assert_array_equal(got, want)
+    fa, fb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    m = RecallAtK("videos", "titles", [1, 5, 10])
+    for call in (lambda: m.compute(fa, fb), lambda: m.compute_both(fa, fb), lambda: m.compute(a, b)):
+        with pytest.raises(ValueError, match="non-finite values in the videos and titles features"):
+            call()
+    m.update(None, (fa, fb), None)
+    with pytest.raises(ValueError, match="non-finite"):
+        m.result()
+    with pytest.raises(ValueError, match="non-finite"):
+        vdist.sharded_recall(fa, fb, fa.shape[0], [1, 5, 10], 0, 1)
+    ok = torch.from_numpy(np.nan_to_num(a, nan=0.0)).cuda()
+    with pytest.raises(ValueError, match="in the titles features"):
+        m.compute(ok, fb)

@@ -131,3 +131,89 @@ def test_compute_dtype_selection(monkeypatch):
     monkeypatch.setenv("VTC_COMPUTE_DTYPE", "bf16")
     m = HM.PretrainedCLIP(model_type=HM.clip_arch.ClipConfig(**asdict(A.TINY)))
     assert m.compute_dtype is torch.bfloat16
+
+
+def test_retrieval_evaluation_module_surface_and_host_logic(monkeypatch):
+    """evaluation/retrieval_evaluation.py as a drop-in, the parts that need no GPU: the module at the reference's path
+    exports the reference's names (:23,:50-62,:65,:108) with its signature (:109-118); chunking (:174-199) equals the oracle's
+    restatement; the stand-in datasets keep the loaders' item contract; unknown names raise as the reference does (:133-134)."""
+    import inspect
+    import warnings
+    import evaluation.retrieval_evaluation as ERE
+    from oracle import eval_ref as E
+    from vtc_amd.host import datasets as D
+    from vtc_amd.host import model as HM
+    from vtc_amd.host import retrieval_evaluation as RE
+    for name in ("compute_recall", "models_needing_comments", "image_models", "video_models", "load_model", "retrieval_evaluation"):
+        assert hasattr(ERE, name), name
+    sig = inspect.signature(ERE.retrieval_evaluation)
+    assert list(sig.parameters)[:8] == ["model", "datasetname", "split", "device", "out_csv", "frame_stride", "first_frame_only",
+                                        "first_chunk_only"]
+    assert (sig.parameters["out_csv"].default, sig.parameters["frame_stride"].default, sig.parameters["first_frame_only"].default,
+            sig.parameters["first_chunk_only"].default) == (None, 16, False, False)
+    assert list(inspect.signature(ERE.compute_recall).parameters)[:4] == ["tensor_v", "tensor_t", "split", "dataset_name"]
+    assert ERE.models_needing_comments == (HM.PretrainedCLIP_finaltf, HM.PretrainedCLIP_TimeSformer_finaltf)
+    assert ERE.image_models == (HM.PretrainedCLIP, HM.PretrainedCLIP_finaltf) and set(ERE.image_models) < set(ERE.video_models)
+    # chunking: stride, 8-frame chunks, resampled tail, first_chunk_only
+    for nfr in (8, 16 * 8, 16 * 13 + 5, 50, 129, 16 * 17 + 3):
+        fr = torch.arange(nfr, dtype=torch.float32)[:, None, None, None].expand(nfr, 3, 2, 2)
+        for stride in (16, 1, 3):
+            want = E.chunk_frames(fr[None], stride, 8)
+            assert torch.equal(RE.chunk_frames(fr, stride, 8), want)
+            assert torch.equal(RE.chunk_frames(fr, stride, 8, first_chunk_only=True), want[0:1])
+    assert torch.equal(RE.empty_comments(2, 5, 24)[1, 3, :3], torch.tensor([49406, 49407, 0]))
+    # stand-in datasets: the loaders' item contract
+    monkeypatch.setattr(D, "VIDEO_STANDIN", dict(D.VIDEO_STANDIN, n_videos=3, min_frames=9, max_frames=40, resolution=8, context=24))
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        for key, cls_name in RE._DATASETS.items():
+            ds, name = RE._resolve_dataset(key, "full-val" if key == "MSRVTT_videos" else "test")
+            assert type(ds).__name__ == cls_name and name == key and ds.synthetic and len(ds) == 3
+            it = ds[1]
+            assert len(it) == (4 if ds.with_comments else 3) and isinstance(it[-1], str)
+            assert it[0].dim() == 4 and it[0].shape[1:] == (3, 8, 8) and it[1].shape == (1, 24) and it[1].dtype == torch.int64
+            fr, cap, com = RE._item_parts(it)
+            assert cap.shape == (24,) and (com is None) == (not ds.with_comments)
+            if ds.with_comments:
+                assert com.shape == (5, 24)
+            assert torch.equal(ds[1][0], it[0])                      # deterministic items
+        assert any("SYNTHETIC" in str(w.message) for w in wl)
+    assert len(ds[0][0]) == 8 or cls_name != "VideoDatasetReddit"
+    fr, cap, com = RE._item_parts((torch.zeros(9, 3, 2, 2), torch.zeros(24, dtype=torch.int64), None))      # the list form of the tests
+    assert com is None and cap.shape == (24,)
+    with pytest.raises(AssertionError, match="one caption per video"):
+        RE._item_parts((torch.zeros(9, 3, 2, 2), torch.zeros(2, 24, dtype=torch.int64), "id"))
+    with pytest.raises(Exception, match="Unknown dataset"):
+        RE.retrieval_evaluation(None, "nope", "test", "cuda")
+    with pytest.raises(Exception, match="Unknown model_type"):
+        RE.load_model(None, "cuda", "resnet")
+    with pytest.raises(ValueError, match="one caption per video"):
+        RE.compute_recall(torch.zeros(4, 8), torch.zeros(4, 2, 8))
+
+
+def test_oracle_retrieval_loop_follows_the_reference_comment_rules():
+    """oracle/eval_ref.py retrieval_evaluation_loop (evaluation/retrieval_evaluation.py:143-264): which frames and which comments reach
+    forward() per video -- dummy ``tokenize([""] * 5)`` rows when the dataset has no comments, the first five real ones otherwise,
+    repeated once per CHUNK on the image branch and once per caption on the text branch (:203-231); first_frame_only hands a 4-D
+    batch of one (:165-173); the video embedding is the mean over chunk embeddings, not re-normalised (:254-259)."""
+    from oracle import eval_ref as E
+    calls = []
+
+    def forward(frames, captions, comments):
+        calls.append((tuple(frames.shape), tuple(captions.shape), None if comments is None else comments.clone()))
+        n = frames.shape[0]
+        return torch.arange(1, n + 1, dtype=torch.float32)[:, None].expand(n, 4) * 1.0, torch.ones(captions.shape[0], 4)
+
+    fr = torch.zeros(16 * 8 * 2 + 16 * 3, 3, 2, 2)                       # stride 16: 19 frames -> chunks of 8, 8, 3 (resampled)
+    cap = torch.zeros(1, 24, dtype=torch.int64)
+    com = torch.arange(7 * 24, dtype=torch.int64).reshape(7, 24)
+    v, c = E.retrieval_evaluation_loop(forward, [(fr, cap, "a"), (fr, cap, com, "b")], True, "image")
+    assert calls[0][0] == (3, 8, 3, 2, 2) and calls[0][2].shape == (3, 5, 24) and calls[0][2][2, 4, :3].tolist() == [49406, 49407, 0]
+    assert calls[1][2].shape == (3, 5, 24) and torch.equal(calls[1][2][1], com[:5])
+    assert torch.equal(v, torch.full((2, 4), 2.0)) and c.shape == (2, 1, 4)          # mean of 1, 2, 3: not re-normalised
+    calls.clear()
+    E.retrieval_evaluation_loop(forward, [(fr, cap, com, "b")], True, "text", first_chunk_only=True)
+    assert calls[0][0] == (1, 8, 3, 2, 2) and calls[0][2].shape == (1, 5, 24)
+    calls.clear()
+    E.retrieval_evaluation_loop(forward, [(fr, cap, "a")], False, first_frame_only=True)
+    assert calls[0][0] == (1, 3, 2, 2) and calls[0][2] is None

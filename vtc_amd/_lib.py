@@ -23,7 +23,7 @@ VTC_F16 = 3
 # vtc_vision_w.flags / vtc_text_w.flags (include/vtc_hip.h VTC_TOWER_*): per-model path switches
 TOWER_NO_LN_FOLD, TOWER_FULL_LAST_LAYER = 1, 8
 CAM_NO_FUSED = 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
 
@@ -75,6 +75,7 @@ SIGNATURES = {
     "vtc_normalize_rows": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),
     "vtc_mean_groups": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp]),
     "vtc_nonfinite_flag": (C.c_int, [fp, C.c_size_t, vp, vp]),
+    "vtc_nonfinite_flag2": (C.c_int, [fp, C.c_size_t, fp, C.c_size_t, vp, vp]),
     "vtc_mean_head_groups": (C.c_int, [fp, fp, fp, C.c_int, C.c_int, C.c_int, vp]),
     "vtc_pack_tokens": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "vtc_single_query_attention": (C.c_int, [vp, vp, fp] + [C.c_int] * 9 + [vp, vp, C.c_int, C.c_int, vp]),

@@ -546,8 +546,11 @@ int launch_cam_fused(const vtc_cam_w *w, const float *main_feats, const float *c
     int *h = nullptr;
     if (hipHostMalloc((void **)&h, 64, hipHostMallocMapped) != hipSuccess || !h) return -1;     // no error word: take the multi-launch path
     *h = 0;
-    // test hook (tests/test_gpu_cam_fallback.py, its own process): behave as if an earlier launch's barrier had given up
+#ifdef VTC_TEST_HOOKS
+    // test hook, compiled into vtc_amd/lib/libvtc_hip_testhooks.so ONLY (Makefile `testhooks`; tests/test_gpu_cam_fallback.py loads that build
+    // in a child process): behave as if an earlier launch's barrier had given up.  The product library has no such switch.
     if (const char *e = getenv("VTC_CAM_TEST_GAVE_UP")) { if (e[0] == '1') *h = 1; }
+#endif
     g_cam_err_words[dev] = h;
   }
   int **err_words = g_cam_err_words;

@@ -291,6 +291,27 @@ extern "C" int vtc_nonfinite_flag(const float *x, size_t n, int *flag, void *str
   return 0;
 }
 
+// flag[0] |= 1 when x holds a non-finite value, |= 2 when y does: the wrappers' watchdog over the two embedding sets a forward returns (one launch)
+__global__ __launch_bounds__(256) void nonfinite_flag2_kernel(const float *__restrict__ x, size_t n, const float *__restrict__ y, size_t m, int *flag) {
+  bool bx = false, by = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n + m; i += (size_t)gridDim.x * 256) {
+    const unsigned u = __float_as_uint(i < n ? x[i] : y[i - n]);
+    const bool bad = (u & 0x7F800000u) == 0x7F800000u;
+    bx |= bad && i < n;
+    by |= bad && i >= n;
+  }
+  const int bits = (__ballot(bx) != 0 ? 1 : 0) | (__ballot(by) != 0 ? 2 : 0);
+  if (bits && (threadIdx.x & 63) == 0) atomicOr(flag, bits);
+}
+
+extern "C" int vtc_nonfinite_flag2(const float *x, size_t n, const float *y, size_t m, int *flag, void *stream) {
+  VTC_CHECK(x && y && flag && n > 0 && m > 0, "nonfinite_flag2: bad arguments");
+  const unsigned grid = (unsigned)std::min<size_t>((n + m + 255) / 256, 1024);
+  hipLaunchKernelGGL(nonfinite_flag2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, y, m, flag);
+  VTC_LAUNCH_CHECK("nonfinite_flag2");
+  return 0;
+}
+
 extern "C" int vtc_mean_head_groups(const float *a, const float *b, float *out, int n_groups, int group, int d, void *stream) {
   VTC_CHECK(n_groups > 0 && group >= 0 && d > 0 && a && out && (b || group == 0), "mean_head_groups: bad arguments");
   hipLaunchKernelGGL(mean_head_groups_kernel, dim3(cdiv(n_groups * d, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n_groups, group, d);

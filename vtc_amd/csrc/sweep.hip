@@ -1514,6 +1514,9 @@ __device__ __forceinline__ void recall_rank_body(const RankArgs &P, int bid, Sha
     const int o = OPW * w + cc, r = r0 + o, tg = r + toff;
     if (r >= R) continue;                                                 // wave-uniform
     if (closer_all[cc] >= kmax) continue;                                 // a miss at every k
+    // a non-finite target distance (NaN / inf in the query's or its target's embedding): every comparison below would be false and the
+    // rank would read 0 -- a hit at every k.  An exact search never returns such a target (no distance compares below NaN): a miss.
+    if (!(dt[cc] < (double)INFINITY)) continue;
     if (n_amb[cc] > RK_AMB || n_ub[cc] > RK_UB) {
       if (lane == 0) P.flags[1 + atomicAdd(P.flags, 1)] = r;
       continue;
@@ -1615,6 +1618,7 @@ __global__ __launch_bounds__(64 * RK_FW) void recall_rank_finish_kernel(const Ra
     const int r = fr & ~RK_HARD, tg = r + P.tgt_off;
     const float *q = P.own + (size_t)r * P.d;
     const double dt = wave_dist64(q, P.other + (size_t)tg * P.d, P.d, lane);
+    const bool dt_ok = dt < (double)INFINITY;      // (the rank kernel never flags a row with a non-finite target distance; kept for the brute-force form)
     int cnt = 0, base_rank = 0;
     auto count_group = [&](const int (&jj)[8]) {
       double dd[8];
@@ -1660,7 +1664,7 @@ __global__ __launch_bounds__(64 * RK_FW) void recall_rank_finish_kernel(const Ra
       for (int ww = 0; ww < RK_FW; ++ww) rank += part[ww];
 #pragma unroll
       for (int qk = 0; qk < 4; ++qk)          // (constant indices: a run-time index into P.k[] sends the argument block to scratch)
-        if (qk < P.nk && rank < P.k[qk]) atomicAdd(&P.hits[qk], 1ull);
+        if (qk < P.nk && dt_ok && rank < P.k[qk]) atomicAdd(&P.hits[qk], 1ull);
     }
     __syncthreads();
   }

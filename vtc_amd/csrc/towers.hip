@@ -31,7 +31,7 @@ void vtc_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 extern "C" const char *vtc_last_error(void) { return g_err; }
-extern "C" int vtc_abi_version(void) { return 6; }
+extern "C" int vtc_abi_version(void) { return 7; }
 int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_frames, int grid, int patch, int res, const float *mean, const float *stdv, hipStream_t stream);
 int patch_k_padded(int patch);
 int launch_pixels_u8_to_operand(const void *px, void *out, int dtype, int n_frames, int res, const float *mean, const float *stdv, hipStream_t stream);

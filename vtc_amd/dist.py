@@ -147,7 +147,7 @@ A2A_MODE = os.environ.get("VTC_A2A", "single")     # "single": one all_to_all_si
 
 
 def exchange_column_planes(planes: torch.Tensor, n_total: int, rank: int, world: int) -> torch.Tensor:
-    """planes [4, nblk_pad, n_total] of this rank's rows -> [world, 4, nblk_pad, n_local]: what every rank (in rank order)
+    """planes [P, nblk_pad, n_total] of this rank's rows (P = 2, 3 or 4 key planes: vtc_l2_recall_planes) -> [world, P, nblk_pad, n_local]: what every rank (in rank order)
     holds for THIS rank's columns.  One equal-split all_to_all_single (shards differ by at most one column: the buffer is
     padded to the largest) -- the collective form RCCL and gloo both implement; gloo (tests, one-card rehearsals) has no
     device-memory transport, so there the buffer is staged through host memory."""
@@ -156,7 +156,7 @@ def exchange_column_planes(planes: torch.Tensor, n_total: int, rank: int, world:
     mx = max(b - a for a, b in bounds)
     P, NB = planes.shape[0], planes.shape[1]
     if planes.dim() != 3 or planes.shape[2] != n_total or not planes.is_contiguous():
-        raise ValueError(f"exchange_column_planes: planes must be a contiguous [4, nblk_pad, n_total = {n_total}] tensor, got "
+        raise ValueError(f"exchange_column_planes: planes must be a contiguous [P, nblk_pad, n_total = {n_total}] tensor, got "
                          f"{tuple(planes.shape)} (contiguous: {planes.is_contiguous()})")
     nccl = dist.get_backend() == "nccl"
     if A2A_MODE == "list" and nccl:
@@ -185,6 +185,8 @@ def exchange_column_planes(planes: torch.Tensor, n_total: int, rank: int, world:
             hk = ("host",) + tuple(send.shape) + (send.dtype,)
             bufs = _A2A_SEND.get(hk)
             if bufs is None:
+                for k_ in [k_ for k_ in _A2A_SEND if k_ and k_[0] == "host"]:      # one pinned pair at a time: the last shape
+                    del _A2A_SEND[k_]
                 bufs = _A2A_SEND[hk] = (torch.empty(send.shape, dtype=send.dtype, pin_memory=True), torch.empty(send.shape, dtype=send.dtype, pin_memory=True))
             host, got = bufs
             host.copy_(send)
@@ -207,6 +209,133 @@ def sweep_workspace_bytes(n_total: int, n_local: int, d: int, precision: int, wo
     return int(need)
 
 
+class _PhaseClock:
+    """HIP events on the launch stream between the steps of a sweep: `phases[name + "_ms"]` += the GPU time since the previous mark."""
+
+    def __init__(self, phases: Optional[dict], on_gpu: bool):
+        self.phases, self.on, self.marks = phases, phases is not None and on_gpu, []
+
+    def mark(self, name: str):
+        if self.on:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.marks.append((name, e))
+
+    def close(self, path: str, exchange: Optional[str] = None):
+        """Call after the final D2H (the events have completed)."""
+        if self.phases is None:
+            return
+        for (_, e0), (name, e1) in zip(self.marks, self.marks[1:]):
+            self.phases[name + "_ms"] = round(self.phases.get(name + "_ms", 0.0) + e0.elapsed_time(e1), 4)
+        self.phases["path"] = path
+        if exchange is not None:
+            self.phases["exchange"] = exchange
+
+
+def _exchange_name() -> str:
+    return (f"all_to_all{'' if A2A_MODE == 'list' else '_single'} (RCCL)" if dist.get_backend() == "nccl"
+            else f"all_to_all_single through host memory ({dist.get_backend()})")
+
+
+def gather_both(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_total: int, rank: int, world: int):
+    """(a_all, b_all): every rank's rows in rank order.  ONE exchange for both embedding sets ([n_r, 2D] rows) when they have the same
+    width: at 10k x 512 the all-gather is latency-bound, a second collective costs as much as the first."""
+    if world > 1 and feats_a_local.shape[1] == feats_b_local.shape[1] and feats_a_local.dtype == feats_b_local.dtype:
+        d = feats_a_local.shape[1]
+        ab = all_gather_rows(torch.cat([feats_a_local, feats_b_local], dim=1), n_total, rank, world)
+        return ab[:, :d].contiguous(), ab[:, d:].contiguous()
+    return all_gather_rows(feats_a_local, n_total, rank, world), all_gather_rows(feats_b_local, n_total, rank, world)
+
+
+def _flag_nonfinite(flag: torch.Tensor, a: torch.Tensor, b: torch.Tensor):
+    """flag (one int64 slot behind the hit counters, so it travels with their all-reduce and D2H) |= 1 / 2 when a / b hold a NaN or inf."""
+    if a.is_cuda:
+        from . import ops
+        ops.nonfinite_flag2(a, b, flag)
+    else:
+        flag[0] = int(not bool(torch.isfinite(a).all())) | 2 * int(not bool(torch.isfinite(b).all()))
+
+
+# ---- the five paths of sharded_recall: each fills `hits` [2, len(ks)] (this rank's partial counters) or returns the sorted ids -------------
+def _world1_rank_path(a_all, b_all, ks, hits, ws, clock):
+    """One rank owns every pair, EXACT: the hit counters come straight from the distance GEMM's key planes (vtc_l2_recall_bidir: the
+    rank of each query's own gallery row; no sorted lists) -- what RecallAtK.compute_both does on one GPU."""
+    from . import ops
+    ops.recall_bidir(a_all, b_all, ks, ws=ws, hits=hits)
+    clock.mark("bidir_gemm_rank")
+
+
+def _world1_one_matrix(a_all, b_all, depth, precision, ws, clock):
+    """One rank owns the whole matrix: the sorted ids of both directions from one distance GEMM (vtc_l2_topk_bidir)."""
+    from . import ops
+    i1, _, i2, _ = ops.l2_topk_bidir(a_all, b_all, depth, precision=precision, return_dists=False, ws=ws)
+    clock.mark("bidir_gemm_select")
+    return i1, i2
+
+
+def _rank_sharded(a_all, b_all, a_local, b_local, n_total, lo, ks, hits, rank, world, rank_ops, ws, clock):
+    """One [N/G, N] GEMM per rank, recall-only finish: this rank's hit counters of the row direction come with the GEMM, the column
+    block minima go to the column owners (one all-to-all), whose rank launch counts the other direction."""
+    if rank_ops is None:
+        from . import ops
+        rank_ops = (lambda a_, b_, base, ks_, nbp, h: ops.recall_shard_rows(a_, b_, base, ks_, nbp, h, ws=ws),
+                    lambda b_, a_, base, ks_, pl, sb, h: ops.recall_shard_cols(b_, a_, base, ks_, pl, sb, h, ws=ws), ops.sweep_row_block())
+    rows_fn, cols_fn, rb = rank_ops
+    bounds = [shard_bounds(n_total, r, world) for r in range(world)]
+    nblk_pad = -(-max(h - l for l, h in bounds) // rb)
+    planes = rows_fn(a_all, b_local, lo, ks, nblk_pad, hits[0])
+    clock.mark("rows_gemm_rank")
+    recv = exchange_column_planes(planes, n_total, rank, world)
+    clock.mark("alltoall")
+    src_bounds = torch.tensor([l for l, _ in bounds] + [n_total], dtype=torch.int32, device=planes.device)
+    cols_fn(b_all, a_local, lo, ks, recv, src_bounds, hits[1])
+    clock.mark("cols_rank")
+
+
+def _one_matrix_sharded(a_all, b_all, a_local, b_local, n_total, depth, rank, world, shard_ops, ws, clock):
+    """One [N/G, N] GEMM per rank, sorted ids: rows finished locally, column block minima to the column owners, who certify + re-rank."""
+    if shard_ops is None:
+        from . import ops
+        shard_ops = (lambda a_, b_, d_, nbp: ops.sweep_shard_rows(a_, b_, d_, nbp, ws=ws),
+                     lambda b_, a_, d_, pl, sb: ops.sweep_shard_cols(b_, a_, d_, pl, sb, ws=ws), ops.sweep_row_block())
+    rows_fn, cols_fn, rb = shard_ops
+    bounds = [shard_bounds(n_total, r, world) for r in range(world)]
+    nblk_pad = -(-max(h - l for l, h in bounds) // rb)
+    i1, planes = rows_fn(a_all, b_local, depth, nblk_pad)          # gallery a, queries b: this rank's b rows
+    clock.mark("rows_gemm_select")
+    recv = exchange_column_planes(planes, n_total, rank, world)
+    clock.mark("alltoall")
+    src_base = torch.tensor([l for l, _ in bounds], dtype=torch.int32, device=planes.device)
+    i2 = cols_fn(b_all, a_local, depth, recv, src_base)            # gallery b, queries a: this rank's a rows
+    clock.mark("cols_select")
+    return i1, i2
+
+
+def _two_searches(a_all, b_all, a_local, b_local, depth, topk, clock):
+    """compute(a, b): gallery a, queries b (model/metric.py:137-146) and the transposed search; this rank owns query rows [lo, hi)."""
+    i1 = topk(a_all, b_local, depth)
+    clock.mark("search_b_from_a")
+    i2 = topk(b_all, a_local, depth)
+    clock.mark("search_a_from_b")
+    return i1, i2
+
+
+def _hits_from_ids(both, ks, lo, hi, hits):
+    """hits[d, j] = #{ local query i : lo + i among the first ks[j] ids of its row } for the two id arrays."""
+    if both[0].is_cuda and len(ks) <= 4 and both[0].shape == both[1].shape:
+        from . import ops
+        ops.recall_hits_pair(both[0], both[1], ks, lo, hits)        # both directions: one launch
+        return
+    for d_, ids in enumerate(both):
+        if ids.is_cuda and len(ks) <= 4:
+            from . import ops
+            ops.recall_hits(ids, ks, target_offset=lo, hits=hits[d_])
+        else:
+            tgt = torch.arange(lo, hi, device=ids.device)[:, None]
+            for j, k in enumerate(ks):
+                hits[d_, j] = (ids[:, :k] == tgt).any(dim=1).sum()
+
+
 def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_total: int, k_vals: Sequence[int],
                    rank: int, world: int,
                    topk: Optional[Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor]] = None,
@@ -218,142 +347,65 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
     """R@K both directions for row-sharded embeddings.
 
     Returns ({k: recall b_from_a-direction as RecallAtK.compute(a, b)}, {k: compute(b, a)}).
-    ``topk(gallery, queries, depth) -> ids`` defaults to the HIP sweep; tests inject a CPU one to
-    exercise the sharding logic under gloo.  ``ws``: a caller-owned uint8 workspace reused across calls (grown by the
-    ops layer when too small).  ``shard_ops = (rows_fn, cols_fn, row_block)``: stand-ins for ops.sweep_shard_rows /
-    ops.sweep_shard_cols (tests: the one-GEMM-per-rank exchange under gloo).  ``phases``: a dict that receives this rank's
-    ``rank_ops = (rows_fn, cols_fn, row_block)``: stand-ins for ops.recall_shard_rows / ops.recall_shard_cols (the same exchange with the
-    recall-only finish: hit counters, no ids).  GPU time per phase in ms (HIP events on the launch stream: allgather / rows_gemm_select / alltoall / cols_select /
-    search_a / search_b / hits / allreduce) and the path taken -- what a scaling run is read from."""
+    ``topk(gallery, queries, depth) -> ids`` defaults to the HIP sweep; tests inject a CPU one to exercise the sharding logic under
+    gloo.  ``ws``: a caller-owned uint8 workspace reused across calls (grown by the ops layer when too small).
+    ``shard_ops = (rows_fn, cols_fn, row_block)``: stand-ins for ops.sweep_shard_rows / ops.sweep_shard_cols (tests: the
+    one-GEMM-per-rank exchange under gloo).  ``rank_ops = (rows_fn, cols_fn, row_block)``: stand-ins for ops.recall_shard_rows /
+    ops.recall_shard_cols (the same exchange with the recall-only finish: hit counters, no ids).
+    ``phases``: a dict that receives this rank's GPU time per phase in ms (HIP events on the launch stream: allgather /
+    rows_gemm_select / alltoall / cols_select / search_a / search_b / hits / allreduce) and the path taken -- what a scaling run is
+    read from.
+
+    The dispatcher only: one function per path above (world 1: rank path, one matrix; world > 1: rank-sharded, one-matrix sharded;
+    any world: two searches).  Non-finite embeddings on ANY rank raise ValueError on EVERY rank (the flag word rides behind the hit
+    counters through their all-reduce)."""
     lo, hi = shard_bounds(n_total, rank, world)
-    marks = []
-
-    def mark(name):
-        if phases is not None and feats_a_local.is_cuda:
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            marks.append((name, e))
-
-    mark("start")
+    clock = _PhaseClock(phases, feats_a_local.is_cuda)
+    clock.mark("start")
     assert feats_a_local.shape[0] == hi - lo and feats_b_local.shape[0] == hi - lo
-    if world > 1 and feats_a_local.shape[1] == feats_b_local.shape[1] and feats_a_local.dtype == feats_b_local.dtype:
-        # ONE exchange for both embedding sets ([n_r, 2D] rows): at 10k x 512 the all-gather is latency-bound, a second
-        # collective costs as much as the first
-        d = feats_a_local.shape[1]
-        ab = all_gather_rows(torch.cat([feats_a_local, feats_b_local], dim=1), n_total, rank, world)
-        a_all, b_all = ab[:, :d].contiguous(), ab[:, d:].contiguous()
-    else:
-        a_all = all_gather_rows(feats_a_local, n_total, rank, world)
-        b_all = all_gather_rows(feats_b_local, n_total, rank, world)
-    mark("allgather")
+    a_all, b_all = gather_both(feats_a_local, feats_b_local, n_total, rank, world)
+    clock.mark("allgather")
     depth = min(int(max(k_vals)) + 1, n_total)
+    ks = [min(int(k), depth) for k in k_vals]
+    d = feats_a_local.shape[1]
+    same_width = d == feats_b_local.shape[1]
+    acc = torch.zeros(2 * len(ks) + 1, dtype=torch.int64, device=feats_a_local.device)        # hit counters + the non-finite word
+    hits, flag = acc[: 2 * len(ks)].view(2, len(ks)), acc[2 * len(ks):]
+    _flag_nonfinite(flag, feats_a_local, feats_b_local)
     hip_sweep = topk is None
     if topk is None:
         from . import ops
 
-        def topk(g, q, d):
-            return ops.l2_topk(g, q, d, precision=precision, return_dists=False, ws=ws)[0]
-    ks = [min(int(k), depth) for k in k_vals]
-    hits = torch.zeros(2, len(ks), dtype=torch.int64, device=feats_a_local.device)
-    both = None
+        def topk(g, q, depth_):
+            return ops.l2_topk(g, q, depth_, precision=precision, return_dists=False, ws=ws)[0]
+
+    both, path, exchange = None, None, None
     if (hip_sweep and world == 1 and precision == 3 and RANK_PATH and n_total >= RANK_MIN_ROWS and len(ks) <= 4
-            and feats_a_local.shape == feats_b_local.shape and feats_a_local.shape[1] % 64 == 0):
-        # one rank owns every pair: the hit counters come straight from the distance GEMM's key planes (vtc_l2_recall_bidir: the rank of
-        # each query's own gallery row; no sorted lists) -- what RecallAtK.compute_both does on one GPU
-        from . import ops
-        ops.recall_bidir(a_all, b_all, ks, ws=ws, hits=hits)
-        mark("bidir_gemm_rank")
-        hits = hits.cpu()
-        if marks:
-            for (_, e0), (name, e1) in zip(marks, marks[1:]):
-                phases[name + "_ms"] = round(phases.get(name + "_ms", 0.0) + e0.elapsed_time(e1), 4)
-            phases["path"] = sweep_path(n_total, precision, world, depth)
-        return ({k: hits[0, j].item() / n_total for j, k in enumerate(k_vals)}, {k: hits[1, j].item() / n_total for j, k in enumerate(k_vals)})
-    if hip_sweep and world == 1 and n_total >= (BIDIR_MIN_ROWS_F32 if precision == 0 else BIDIR_MIN_ROWS):
-        # one rank owns the whole matrix: both directions from one distance GEMM (vtc_l2_topk_bidir); with more
-        # ranks each direction's [N/G, N] block is a different matrix and the two searches stay separate
-        from . import ops
-        i1, _, i2, _ = ops.l2_topk_bidir(a_all, b_all, depth, precision=precision, return_dists=False, ws=ws)
-        both = (i1, i2)
-        mark("bidir_gemm_select")
-    if (world > 1 and (rank_ops is not None or (hip_sweep and shard_ops is None and feats_a_local.shape[1] == feats_b_local.shape[1]
-                                                  and rank_sharded(n_total, feats_a_local.shape[1], precision, world, len(ks))))):
-        # one [N/G, N] GEMM per rank, recall-only finish: this rank's hit counters of the row direction come with the GEMM, the column
-        # block minima go to the column owners, whose rank launch counts the other direction
-        injected = rank_ops is not None
-        if rank_ops is None:
-            from . import ops
-            rank_ops = (lambda a_, b_, base, ks_, nbp, h: ops.recall_shard_rows(a_, b_, base, ks_, nbp, h, ws=ws),
-                        lambda b_, a_, base, ks_, pl, sb, h: ops.recall_shard_cols(b_, a_, base, ks_, pl, sb, h, ws=ws), ops.sweep_row_block())
-        rows_fn, cols_fn, rb = rank_ops
-        bounds = [shard_bounds(n_total, r, world) for r in range(world)]
-        nblk_pad = -(-max(h - l for l, h in bounds) // rb)
-        planes = rows_fn(a_all, feats_b_local, lo, ks, nblk_pad, hits[0])
-        mark("rows_gemm_rank")
-        recv = exchange_column_planes(planes, n_total, rank, world)
-        mark("alltoall")
-        src_bounds = torch.tensor([l for l, _ in bounds] + [n_total], dtype=torch.int32, device=planes.device)
-        cols_fn(b_all, feats_a_local, lo, ks, recv, src_bounds, hits[1])
-        mark("cols_rank")
-        dist.all_reduce(hits, op=dist.ReduceOp.SUM)
-        mark("allreduce")
-        hits = hits.cpu()
-        if marks:
-            for (_, e0), (name, e1) in zip(marks, marks[1:]):
-                phases[name + "_ms"] = round(phases.get(name + "_ms", 0.0) + e0.elapsed_time(e1), 4)
-        if phases is not None:
-            phases["path"] = sweep_path(n_total, precision, world, depth, feats_a_local.shape[1]) if not injected else "injected rank ops"
-            phases["exchange"] = (f"all_to_all{'' if A2A_MODE == 'list' else '_single'} (RCCL)" if dist.get_backend() == "nccl"
-                                  else f"all_to_all_single through host memory ({dist.get_backend()})")
-        return ({k: hits[0, j].item() / n_total for j, k in enumerate(k_vals)}, {k: hits[1, j].item() / n_total for j, k in enumerate(k_vals)})
-    if both is None and world > 1 and (shard_ops is not None or (hip_sweep and one_matrix_sharded(n_total, precision, world, depth))):
-        # one [N/G, N] GEMM per rank: rows finished locally, column block minima to the column owners
-        if shard_ops is None:
-            from . import ops
-            shard_ops = (lambda a_, b_, d_, nbp: ops.sweep_shard_rows(a_, b_, d_, nbp, ws=ws),
-                         lambda b_, a_, d_, pl, sb: ops.sweep_shard_cols(b_, a_, d_, pl, sb, ws=ws), ops.sweep_row_block())
-        rows_fn, cols_fn, rb = shard_ops
-        bounds = [shard_bounds(n_total, r, world) for r in range(world)]
-        nblk_pad = -(-max(h - l for l, h in bounds) // rb)
-        i1, planes = rows_fn(a_all, feats_b_local, depth, nblk_pad)          # gallery a, queries b: this rank's b rows
-        mark("rows_gemm_select")
-        recv = exchange_column_planes(planes, n_total, rank, world)
-        mark("alltoall")
-        src_base = torch.tensor([l for l, _ in bounds], dtype=torch.int32, device=planes.device)
-        i2 = cols_fn(b_all, feats_a_local, depth, recv, src_base)            # gallery b, queries a: this rank's a rows
-        both = (i1, i2)
-        mark("cols_select")
-        if phases is not None:
-            phases["exchange"] = (f"all_to_all{'' if A2A_MODE == 'list' else '_single'} (RCCL)" if dist.get_backend() == "nccl"
-                                  else f"all_to_all_single through host memory ({dist.get_backend()})")
-    # compute(a, b): gallery a, queries b (model/metric.py:137-146); this rank owns query rows [lo, hi)
-    pair_done = False
-    if both is not None and both[0].is_cuda and len(ks) <= 4 and both[0].shape == both[1].shape:
-        from . import ops
-        ops.recall_hits_pair(both[0], both[1], ks, lo, hits)        # both directions: one launch
-        pair_done = True
-    for d_, (gal, qry) in enumerate(((a_all, feats_b_local), (b_all, feats_a_local))):
-        if pair_done:
-            break
-        ids = both[d_] if both is not None else topk(gal, qry, depth)
-        if both is None:
-            mark("search_b_from_a" if d_ == 0 else "search_a_from_b")
-        if ids.is_cuda and len(ks) <= 4:
-            from . import ops
-            ops.recall_hits(ids, ks, target_offset=lo, hits=hits[d_])
-        else:
-            tgt = torch.arange(lo, hi, device=ids.device)[:, None]
-            for j, k in enumerate(ks):
-                hits[d_, j] = (ids[:, :k] == tgt).any(dim=1).sum()
-    mark("hits")
+            and feats_a_local.shape == feats_b_local.shape and d % 64 == 0):
+        _world1_rank_path(a_all, b_all, ks, hits, ws, clock)
+        path = sweep_path(n_total, precision, world, depth, d)
+    elif hip_sweep and world == 1 and n_total >= (BIDIR_MIN_ROWS_F32 if precision == 0 else BIDIR_MIN_ROWS):
+        both = _world1_one_matrix(a_all, b_all, depth, precision, ws, clock)
+    elif world > 1 and (rank_ops is not None or (hip_sweep and shard_ops is None and same_width
+                                                 and rank_sharded(n_total, d, precision, world, len(ks)))):
+        path = sweep_path(n_total, precision, world, depth, d) if rank_ops is None else "injected rank ops"
+        _rank_sharded(a_all, b_all, feats_a_local, feats_b_local, n_total, lo, ks, hits, rank, world, rank_ops, ws, clock)
+        exchange = _exchange_name()
+    elif world > 1 and (shard_ops is not None or (hip_sweep and one_matrix_sharded(n_total, precision, world, depth))):
+        both = _one_matrix_sharded(a_all, b_all, feats_a_local, feats_b_local, n_total, depth, rank, world, shard_ops, ws, clock)
+        exchange = _exchange_name()
+    else:
+        both = _two_searches(a_all, b_all, feats_a_local, feats_b_local, depth, topk, clock)
+    if both is not None:
+        _hits_from_ids(both, ks, lo, hi, hits)
+        clock.mark("hits")
     if world > 1:
-        dist.all_reduce(hits, op=dist.ReduceOp.SUM)
-        mark("allreduce")
-    hits = hits.cpu()
-    if marks:
-        for (_, e0), (name, e1) in zip(marks, marks[1:]):
-            phases[name + "_ms"] = round(phases.get(name + "_ms", 0.0) + e0.elapsed_time(e1), 4)
-        phases["path"] = sweep_path(n_total, precision, world, depth) if hip_sweep else "injected top-k"
-    r_ab = {k: hits[0, j].item() / n_total for j, k in enumerate(k_vals)}
-    r_ba = {k: hits[1, j].item() / n_total for j, k in enumerate(k_vals)}
-    return r_ab, r_ba
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        clock.mark("allreduce")
+    acc = acc.cpu()
+    clock.close(path or (sweep_path(n_total, precision, world, depth, d) if hip_sweep else "injected top-k"), exchange)
+    if int(acc[-1]) != 0:
+        raise ValueError("sharded_recall: non-finite values in the embeddings of at least one rank -- the ranks of such rows are undefined "
+                         "(vtc_amd.host.model.nonfinite_cause lists what this build knows can produce them)")
+    h = acc[: 2 * len(ks)].view(2, len(ks))
+    return ({k: h[0, j].item() / n_total for j, k in enumerate(k_vals)}, {k: h[1, j].item() / n_total for j, k in enumerate(k_vals)})

@@ -162,3 +162,75 @@ class VideoDatasetSegments(_ReferenceNamedDataset):
         if self.first_frame_only:                              # dataset_loaders.py:543-544
             vis = vis[0]
         return vis, title, comments, meta
+
+
+# ---- stand-ins for the video-retrieval benchmark loaders (evaluation/retrieval_evaluation.py:119-134) ----------------------------
+#: defaults of the synthetic video stand-ins below; tests on small architectures override them (resolution / context)
+VIDEO_STANDIN = {"n_videos": 24, "min_frames": 40, "max_frames": 420, "resolution": 224, "context": 77, "seed": 123}
+
+
+class _SyntheticVideos(Dataset):
+    """Whole videos of ragged length, as the reference's benchmark loaders return them to ``retrieval_evaluation``
+    (dataset_loaders/video_retrieval_videodatasets.py:200-256, 528-553; dataset_loaders.py:1080-1111): items are
+    ``(frames [T,3,H,W] fp32, captions [1,77] int64, id)`` or, for the sets that carry comments,
+    ``(frames, title [1,77], comments [nc,77], id)``.  Those loaders read MSR-VTT / MSVD / Kinetics / Reddit / Livebot video files
+    with torchvision + ffmpeg (out of scope); these yield random pixels and tokens of the same tensor contract: T ~ U{min..max}
+    frames (so 8-frame chunk counts are ragged at the default stride of 16, with resampled tails), ONE caption per video
+    (with several the reference hands faiss a 3-D array).  ``synthetic = True`` marks the results."""
+    synthetic = True
+    with_comments = False
+    n_comments = 5
+
+    def __init__(self, train=False, split="full-test", **kw):
+        assert not train, "benchmark stand-ins are evaluation splits"
+        cfg = dict(VIDEO_STANDIN)
+        cfg.update({k: v for k, v in kw.items() if k in cfg})
+        self.cfg, self.split = cfg, split
+        self.n = int(os.environ.get("VTC_SYNTHETIC_VIDEOS", cfg["n_videos"]))
+        import warnings
+        warnings.warn(f"{type(self).__name__}: {self.n} SYNTHETIC videos (random pixels and tokens) of the reference's tensor contract stand "
+                      "in for the benchmark; retrieval metrics on them say nothing about the real split", stacklevel=3)
+        # a split / class gets its own disjoint synthetic set
+        self.seed = int(cfg["seed"]) + sum(ord(c) for c in type(self).__name__ + str(split))
+        g = torch.Generator().manual_seed(self.seed)
+        self.lengths = torch.randint(cfg["min_frames"], cfg["max_frames"] + 1, (self.n,), generator=g)
+        self.captions = synth_tokens(self.n, cfg["context"], g)
+        self.comments = synth_tokens(self.n * self.n_comments, cfg["context"], g, empty_frac=0.1).reshape(self.n, self.n_comments, -1)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        r = self.cfg["resolution"]
+        frames = torch.randn((int(self.lengths[i]), 3, r, r), generator=g)
+        if self.with_comments:
+            return frames, self.captions[i][None], self.comments[i], f"video{i}"
+        return frames, self.captions[i][None], f"video{i}"
+
+
+class VideoDatasetMSRVTT(_SyntheticVideos):
+    """dataset_loaders/video_retrieval_videodatasets.py:113-256 (non-augmented eval item: ``vid, text, vid_id``)."""
+
+
+class VideoDatasetMSVD(_SyntheticVideos):
+    """dataset_loaders/video_retrieval_videodatasets.py:258-476."""
+
+
+class VideoDatasetK700Comments(_SyntheticVideos):
+    """dataset_loaders/video_retrieval_videodatasets.py:478-556 (``vid, title_tok, comments_tok, vid_id``)."""
+    with_comments = True
+
+
+class VideoDatasetReddit(_SyntheticVideos):
+    """dataset_loaders/dataset_loaders.py:1049-1113 (8 frames per item, 5 comments)."""
+    with_comments = True
+
+    def __init__(self, train=False, split="test", **kw):
+        super().__init__(train=train, split=split, **kw)
+        self.lengths = torch.full((self.n,), 8)
+
+
+class VideoDatasetLivebot(_SyntheticVideos):
+    """dataset_loaders/dataset_loaders.py:1116-1180."""
+    with_comments = True

@@ -15,6 +15,7 @@ from __future__ import annotations
 import argparse
 import json
 import logging
+import os
 import sys
 
 import torch
@@ -49,6 +50,17 @@ def add_irrelevant_comms(comments: torch.Tensor, num_irrelevant_comments: int) -
 
 
 def main(config: ConfigParser, args, checkpoint_path=None, device="cuda"):
+    """One process: the reference's loop (evaluation/eval.py:50-141).  Under ``python -m torch.distributed.run --nproc-per-node G
+    evaluation/eval.py ...`` (WORLD_SIZE > 1; BASELINE configs[3]): rank r encodes the contiguous shard [lo_r, hi_r) of the dataset on its
+    own GPU -- no collective in the encode path -- the embeddings are exchanged once and the sweep runs sharded
+    (vtc_amd/dist.py sharded_recall: all-gather, one [N/G, N] distance GEMM per rank, all-to-all of column planes, all-reduce of the six
+    counters); rank 0 writes the reference's JSON.  The towers and the CAM are per-item functions and the sharded sweep returns the
+    single-GPU counters, so the JSON equals the one-process run's (tests/test_gpu_eval_entry.py, world 2 and 3 on one card)."""
+    rank, world = 0, int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        from .. import dist as vdist
+        rank, local, world = vdist.init_from_env()
+        device = f"cuda:{local}"
     dataset = config.init_obj("dataset", module_data, train=False, test=True)
     arch_args = config["arch"].get("args", {})
     branch_to_adapt = arch_args.get("branch_to_adapt_val", None)
@@ -65,7 +77,18 @@ def main(config: ConfigParser, args, checkpoint_path=None, device="cuda"):
         save_path = getattr(args, "out", None) or f"zero_shot_res_{comment_fusion}.json"
     logging.info(f"Saving results to {save_path}")
 
-    loader = DataLoader(dataset, batch_size=config["batch_size"], num_workers=getattr(args, "workers", 0), shuffle=False)
+    n_total = len(dataset)
+    shard = dataset
+    if world > 1:
+        lo, hi = vdist.shard_bounds(n_total, rank, world)
+        shard = torch.utils.data.Subset(dataset, range(lo, hi))
+        logging.info(f"rank {rank}/{world}: pairs [{lo}, {hi}) of {n_total} on {device}")
+    loader = DataLoader(shard, batch_size=config["batch_size"], num_workers=getattr(args, "workers", 0), shuffle=False)
+    seed = os.environ.get("VTC_EVAL_SEED", "1023" if world > 1 else None)
+    if seed is not None and checkpoint_path is None:
+        # randomly initialised towers (no checkpoint, no VTC_CLIP_WEIGHTS) must be the SAME towers on every rank: the reference's seed
+        # (train.py:34-38), set right before construction
+        torch.manual_seed(int(seed))
     model = config.init_obj("arch", module_arch)
     if checkpoint_path is not None:
         checkpoint = torch.load(checkpoint_path, map_location="cpu")
@@ -95,21 +118,26 @@ def main(config: ConfigParser, args, checkpoint_path=None, device="cuda"):
             res_vis.append(out[0])
             res_text.append(out[1])
     res_vis, res_text = torch.cat(res_vis), torch.cat(res_text)
-    t_from_i, i_from_t = RecallAtK("images", "titles", [1, 5, 10]).compute_both(res_vis, res_text)
-    from .. import _lib as L
-    if res_vis.is_cuda and L.lib().vtc_cam_fused_gave_up(res_vis.device.index or 0):
-        # compute_both has synchronised: the word speaks for every forward of the loop above
-        if not (torch.isfinite(res_vis).all() and torch.isfinite(res_text).all()):
-            raise RuntimeError("vtc_amd eval: a one-launch CAM gave up at a grid barrier during this run (another process or a "
-                               "collective held the card's CUs) and left NaN embeddings; re-run -- the multi-launch CAM is now selected")
+    # unconditional: an IEEE-half overflow of the text blocks in a batch after the first, or a one-launch CAM that gave up at a
+    # grid barrier, returns NaN rows with rc 0 -- such a run raises here instead of writing a JSON
+    if world > 1:
+        # (the finite check is inside: the flag word rides behind the counters through their all-reduce, so EVERY rank raises)
+        phases = {}
+        r_ab, r_ba = vdist.sharded_recall(res_vis, res_text, n_total, [1, 5, 10], rank, world, phases=phases)
+        t_from_i, i_from_t = [(k, r_ab[k]) for k in (1, 5, 10)], [(k, r_ba[k]) for k in (1, 5, 10)]
+        logging.info(f"rank {rank}: sharded sweep phases {phases}")
+    else:
+        module_arch.raise_if_nonfinite("eval", res_vis, res_text)
+        t_from_i, i_from_t = RecallAtK("images", "titles", [1, 5, 10]).compute_both(res_vis, res_text)
     out = {"R1_title_from_im": t_from_i[0][1], "R5_title_from_im": t_from_i[1][1], "R10_title_from_im": t_from_i[2][1],
            "R1_im_from_title": i_from_t[0][1], "R5_im_from_title": i_from_t[1][1], "R10_im_from_title": i_from_t[2][1]}
     if getattr(dataset, "synthetic", False):
         # beside the reference's six keys (evaluation/eval.py:131-138): the numbers are on synthetic stand-in data
         out["synthetic"] = True
         out["n_pairs"] = len(dataset)
-    with open(save_path, "w") as f:
-        json.dump(out, f)
+    if rank == 0:
+        with open(save_path, "w") as f:
+            json.dump(out, f)
     return out, res_vis, res_text
 
 
@@ -134,7 +162,12 @@ def cli(argv=None):
             "arch;args;comment_fusion": args.am, "dataset;args;add_comments": args.ac, "dataset;args;n_pairs": args.n_pairs}
     config = ConfigParser.from_file(args.config, resume=args.resume, modification=mods)
     out, res_vis, res_text = main(config, args, config.resume, device="cuda:" + args.device)
-    print(json.dumps(out))
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps(out))
+    import torch.distributed as tdist
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and tdist.is_initialized():
+        tdist.barrier()
+        tdist.destroy_process_group()
     return out, res_vis, res_text
 
 

@@ -79,6 +79,13 @@ class RecallAtK(BaseMetric):
         pad = -a.shape[1] % 64
         if pad:
             a, b = torch.nn.functional.pad(a, (0, pad)), torch.nn.functional.pad(b, (0, pad))
+        if self.check_finite:
+            bits = ops.nonfinite_bits(a, b)
+            if bits:
+                which = " and ".join(n for n, m in ((self.name_a, 1), (self.name_b, 2)) if bits & m)
+                raise ValueError(f"RecallAtK: non-finite values in the {which} features -- a NaN distance compares below nothing, the ranks "
+                                 "of such rows are undefined (faiss would return arbitrary ids for them); fix the embeddings "
+                                 "(vtc_amd.host.model.nonfinite_cause lists what this build knows can produce them)")
         depth = min(int(np.max(self.k_vals) + 1), a.shape[0])
         if depth > 64:
             raise ValueError(f"RecallAtK: max(k_vals) + 1 = {depth} exceeds the sweep's list depth of 64 (one entry per lane of "
@@ -113,8 +120,12 @@ class RecallAtK(BaseMetric):
     bidir_min_rows_f32 = 3000      # SWEEP_F32: the fp32-MFMA GEMM it saves is the expensive part at every size
     #: EXACT mode, paired rows: hit counters straight from the distance GEMM's key planes (the rank of each query's own gallery row),
     #: no sorted neighbour lists (round 5; the library takes n >= 1024)
-    rank_path = True
+    #: (VTC_SWEEP_RANK=0, read at import as vtc_amd.dist.RANK_PATH is: sorted neighbour lists instead -- the A/B knob of INTEGRATION.md)
+    rank_path = __import__("os").environ.get("VTC_SWEEP_RANK", "1") != "0"
     rank_min_rows = 1024
+    #: inputs are checked for NaN / inf before the search (one tiny launch + a 4-byte D2H) and rejected: a non-finite row would be
+    #: ranked arbitrarily
+    check_finite = True
 
     def _hits_to_recall(self, ids, num_samples):
         ks = [min(int(k), ids.shape[1]) for k in self.k_vals]

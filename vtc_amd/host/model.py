@@ -70,6 +70,31 @@ def default_compute_dtype():
     return parse_compute_dtype(__import__("os").environ.get("VTC_COMPUTE_DTYPE")) or torch.bfloat16
 
 
+nonfinite_bits = ops.nonfinite_bits
+
+
+def nonfinite_cause(device) -> str:
+    """What this build knows can put a NaN into an embedding, for the error message."""
+    from .. import _lib as L
+    idx = torch.device(device).index
+    causes = []
+    if L.lib().vtc_cam_fused_gave_up(idx if idx is not None else torch.cuda.current_device()):
+        causes.append("a one-launch CAM gave up at a grid barrier (another process or a collective held the card's CUs); the "
+                      "multi-launch CAM is selected from now on")
+    causes.append("an IEEE-half overflow in the text tower's half-operand blocks (the tower re-packs itself as bf16 at its next forward "
+                  "and warns), or non-finite weights / inputs")
+    return "; or ".join(causes)
+
+
+def raise_if_nonfinite(where: str, feats_a: torch.Tensor, feats_b: torch.Tensor):
+    """The unconditional finite check of the eval entry points (synchronises): NaN embeddings never reach a recall figure."""
+    bits = nonfinite_bits(feats_a, feats_b)
+    if bits:
+        which = " and ".join(n for n, m in (("visual", 1), ("text", 2)) if bits & m)
+        raise RuntimeError(f"vtc_amd {where}: non-finite values in the {which} embeddings -- refusing to rank them.  Possible cause: "
+                           f"{nonfinite_cause(feats_a.device)}.  Re-run (the fallbacks are now active) or use --dtype f32")
+
+
 class PretrainedCLIPBase(nn.Module):
     #: arithmetic of the GEMM/attention operands on the HIP path (fp32 everywhere else); per instance from
     #: default_compute_dtype() at construction, assignable afterwards (a change re-packs the weights)
@@ -157,7 +182,47 @@ class PretrainedCLIPBase(nn.Module):
             fv.record_stream(cur)
         return fv, ft
 
+    # ---- non-finite watchdog -----------------------------------------------------------------
+    # Two paths of this build can hand back NaN rows with rc 0: a text tower whose IEEE-half blocks overflowed in a batch after the
+    # first (towers.PackedText._range_guard switches to bf16 at the NEXT call), and a one-launch CAM whose grid barrier gave up
+    # (cam.hip).  So every forward ends with ONE vtc_nonfinite_flag2 launch over the two embedding sets it returns and an ASYNC copy
+    # of the word to pinned host memory -- no synchronisation -- and the word is read (a) at the model's next forward and (b) by
+    # check_finite(), which synchronises; both raise with the cause.  RecallAtK and the eval entry points check their inputs too.
+    #: False switches the per-forward launch off (the checks of RecallAtK / eval.py remain)
+    nonfinite_watchdog = True
+
+    def _watch(self, fv, ft):
+        if not self.nonfinite_watchdog or not (fv.is_cuda and ft.is_cuda) or fv.dtype != torch.float32 or ft.dtype != torch.float32:
+            return
+        st = self.__dict__.get("_nf")
+        if st is None or st[0].device != fv.device:
+            st = self.__dict__["_nf"] = (torch.zeros(1, dtype=torch.int32, device=fv.device), torch.zeros(1, dtype=torch.int32).pin_memory())
+        ops.nonfinite_flag2(fv, ft, st[0])
+        with torch.cuda.device(fv.device):
+            st[1].copy_(st[0], non_blocking=True)
+
+    def _raise_watch(self, bits, when):
+        st = self.__dict__["_nf"]
+        st[0].zero_()
+        st[1].zero_()
+        which = " and ".join(n for n, m in (("visual", 1), ("text", 2)) if bits & m)
+        raise RuntimeError(f"vtc_amd {type(self).__name__}: {when} returned non-finite values in its {which} embeddings.  Possible cause: "
+                           f"{nonfinite_cause(st[0].device)}.  The flag is cleared: the next forward runs with the fallbacks active")
+
+    def check_finite(self):
+        """Synchronise the device and raise if any forward of this model since the last check returned NaN / inf embeddings."""
+        st = self.__dict__.get("_nf")
+        if st is None:
+            return
+        torch.cuda.synchronize(st[0].device)
+        bits = int(st[1][0]) | int(st[0].item())
+        if bits:
+            self._raise_watch(bits, "a forward since the last check")
+
     def _check_mode(self, *tensors):
+        st = self.__dict__.get("_nf")
+        if st is not None and int(st[1][0]) != 0:         # pinned host word: the verdict of forwards whose copy has landed, no synchronisation
+            self._raise_watch(int(st[1][0]), "an earlier forward")
         if self.training:
             raise RuntimeError("vtc_amd implements the forward/eval path only: call .eval() "
                                "(training branches model/model.py:199-201,236-246 are out of scope)")
@@ -287,6 +352,7 @@ class PretrainedCLIP(PretrainedCLIPBase):
             feats_vis, ft_all = self._encode_both(vis, title, comments.reshape(b * ncomms, ntoks))
             feats_text = ops.mean_head_groups(ft_all[:b], ft_all[b:], ncomms)
         feats_text, feats_vis = normalize(feats_text), normalize(feats_vis)
+        self._watch(feats_vis, feats_text)
         return feats_vis, feats_text, self._sim(feats_vis, feats_text)
 
 
@@ -312,6 +378,7 @@ class PretrainedCLIP_finaltf(PretrainedCLIPBase):
         self._check_mode(vis, title, comments)
         feats_vis, feats_title, feats_comm = self._encode_all(vis, title, comments)
         feats_vis, feats_text = self._encode_with_comments(feats_vis, feats_title, comments, feats_comm)
+        self._watch(feats_vis, feats_text)
         return feats_vis, feats_text, self._sim(feats_vis, feats_text)
 
 
@@ -331,6 +398,7 @@ class PretrainedCLIP_TimeSformer(PretrainedCLIPBase):
         self._check_mode(im, text)
         feats_im, feats_text = self._encode_both(im, text)       # model.visual(im), model/model.py:497
         feats_im, feats_text = normalize(feats_im), normalize(feats_text)
+        self._watch(feats_im, feats_text)
         return feats_im, feats_text, self._sim(feats_im, feats_text)
 
 
@@ -359,4 +427,5 @@ class PretrainedCLIP_TimeSformer_finaltf(PretrainedCLIPBase):
         self._check_mode(vis, title, comments)
         feats_vis, feats_title, feats_comm = self._encode_all(vis, title, comments)
         feats_vis, feats_text = self._encode_with_comments(feats_vis, feats_title, comments, feats_comm)
+        self._watch(feats_vis, feats_text)
         return feats_vis, feats_text, self._sim(feats_vis, feats_text)

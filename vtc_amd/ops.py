@@ -206,6 +206,21 @@ def segment_mean(x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def nonfinite_flag2(a: torch.Tensor, b: torch.Tensor, flag: torch.Tensor) -> torch.Tensor:
+    """flag[0] |= 1 when ``a`` holds a NaN / inf, |= 2 when ``b`` does (one launch, no synchronisation).  flag: int32 (or the low word of
+    an int64) in device memory."""
+    a, b = _gpu(a, torch.float32, "embeddings"), _gpu(b, torch.float32, "embeddings")
+    with torch.cuda.device(a.device):
+        L.check(L.lib().vtc_nonfinite_flag2(a.data_ptr(), a.numel(), b.data_ptr(), b.numel(), flag.data_ptr(), _stream()), "vtc_nonfinite_flag2")
+    return flag
+
+
+def nonfinite_bits(a: torch.Tensor, b: torch.Tensor) -> int:
+    """Synchronous form: the flag word on the host (one 4-byte D2H)."""
+    a = _gpu(a, torch.float32, "embeddings")
+    return int(nonfinite_flag2(a, b, torch.zeros(1, dtype=torch.int32, device=a.device)).item())
+
+
 @on_device
 def similarity(v: torch.Tensor, t: torch.Tensor, logit_scale: torch.Tensor) -> torch.Tensor:
     v, t = _gpu(v, torch.float32, "v"), _gpu(t, torch.float32, "t")
@@ -340,6 +355,12 @@ def recall_bidir(a: torch.Tensor, b: torch.Tensor, k_vals: Sequence[int], ws: Op
     return hits
 
 
+def recall_planes(k_vals: Sequence[int], n_total: int) -> int:
+    """Key planes per (column, block) that the recall-only sweep keeps for these k at this gallery size (vtc_l2_recall_planes): 2, 3 or 4."""
+    ks = (C.c_int * len(k_vals))(*[int(k) for k in k_vals])
+    return int(L.lib().vtc_l2_recall_planes(ks, len(k_vals), int(n_total)))
+
+
 def recall_shard_supported(n_total: int, n_local: int, d: int) -> bool:
     return bool(L.lib().vtc_l2_recall_shard_supported(int(n_total), int(n_local), int(d)))
 
@@ -348,7 +369,7 @@ def recall_shard_supported(n_total: int, n_local: int, d: int) -> bool:
 def recall_shard_rows(a_all: torch.Tensor, b_local: torch.Tensor, row_base: int, k_vals: Sequence[int], nblk_pad: int, hits: torch.Tensor,
                       ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Rank-local half of the sharded sweep with the recall-only finish (vtc_l2_recall_shard_rows): hits [nk] int64 += this rank's
-    counters of RecallAtK.compute(a, b); returns col_planes [4, nblk_pad, n_total] (int32 tensor) for the exchange."""
+    counters of RecallAtK.compute(a, b); returns col_planes [P, nblk_pad, n_total] with P = vtc_l2_recall_planes(k_vals, n_local) = 2, 3 or 4 (int32 tensor) for the exchange."""
     a_all, b_local = _gpu(a_all, torch.float32, "a_all"), _gpu(b_local, torch.float32, "b_local")
     n, d = a_all.shape
     nl = b_local.shape[0]

@@ -18,6 +18,28 @@
  *     stream, biases and all outputs are fp32 in both modes;
  *   - weight matrices are row-major [out_features, in_features] (PyTorch Linear layout) in
  *     the compute dtype; biases and LayerNorm parameters are fp32.
+ *
+ * Process-wide state: the entry points take no hidden arguments EXCEPT the environment variables below --
+ * diagnostics and kernel-tuning knobs, each read ONCE into a function-local static at the first call that reaches it (C++11
+ * thread-safe initialisation, never written afterwards), so they are fixed for the life of the process and invisible to the
+ * per-call arguments.  Unset (the product configuration) every one of them selects the default.  None changes a result beyond
+ * summation order; tests/test_abi.py holds this list to the getenv() calls of the sources.
+ *   VTC_GEMM_TILE=1|2|4|5      force the GEMM kernel: 1 128 x 128, 2 256 x 256 free-running, 4 256 x 256 phased, 5 64 x 64 (default 0: by shape)   gemm.hip
+ *   VTC_GEMM_DEEP=0|1          256 x 256 K loop: 1 (default) the deep LDS-DMA pipeline, 0 the round-3 loop; bit-identical
+ *   VTC_GEMM_CG=n, VTC_GEMM_SUPER=n   tile walk: column-group width / row tiles per super-row (default 0 = by shape)
+ *   VTC_GEMM_RESID_SMALL_K=k   residual GEMMs with K <= k on 128 x 128 tiles (two workgroups per CU; default 0: the heuristic alone)
+ *   VTC_GEMM_STAGGER=g,t       start workgroup groups t ticks apart (a measured null, kept for A/B)
+ *   VTC_PATCH_IM2ROW=1         patch embedding through the im2row matrix instead of the in-place LDS-DMA gather
+ *   VTC_SWEEP_MIN_TILE=0|1     distance GEMM of the block-minima sweep: 0 (default) 256 x 256 phased tiles, 1 128 x 128 tiles          sweep.hip
+ *   VTC_SWEEP_EXACT_V1=1       the round-2 EXACT sweep (split-bf16 candidate lists) instead of the block-minima sweep
+ *   VTC_SWEEP_PLANES=2|3|4     force the key-plane count of the recall-only sweep (default: by max k and size)
+ *   VTC_SWEEP_DEBUG=1          stderr line per sweep with the fallback counters (synchronises)
+ *   VTC_CAM_FUSED_MAX_ROWS=n   largest token count the one-launch CAM takes (default 512)                              cam.hip
+ *   VTC_CAM_COOP=1             hipLaunchCooperativeKernel for the one-launch CAM (default: occupancy-checked ordinary launch)
+ *   VTC_CAM_STAMPS=1           per-phase cycle stamps of the one-launch CAM on stderr (synchronises)
+ * (VTC_CAM_TEST_GAVE_UP exists in the TEST build only: libvtc_hip_testhooks.so, -D VTC_TEST_HOOKS.)
+ * The Python host layer's own switches (VTC_COMPUTE_DTYPE, VTC_OVERLAP, VTC_TEXT_RAGGED, VTC_TEXT_HALF_LAYERS, VTC_SWEEP_RANK,
+ * VTC_CLIP_WEIGHTS, ...) are listed in INTEGRATION.md; they travel to the library as per-call arguments / per-model flags.
  */
 #ifndef VTC_HIP_H
 #define VTC_HIP_H
@@ -271,7 +293,12 @@ int vtc_recall_hits(const int64_t *ids, int n_queries, int depth, int64_t target
  * max k + 1, VTC_SWEEP_EXACT) followed by vtc_recall_hits_pair, exactly.  hits_*: nk device int64 each, ADDED to:
  *   hits_b_from_a[j] += #{ i : a_i is among the k_j nearest a's of b_i }   = RecallAtK.compute(a, b) x n
  *   hits_a_from_b[j] += #{ i : b_i is among the k_j nearest b's of a_i }   = RecallAtK.compute(b, a) x n
- * n >= 1024, d % 64 == 0 (vtc_l2_recall_bidir_supported; else the two-call form); nk <= 4; k_vals on the host. */
+ * n >= 1024, d % 64 == 0 (vtc_l2_recall_bidir_supported; else the two-call form); nk <= 4; k_vals on the host.
+ * Non-finite embeddings (ABI 7): a pair whose target distance |a_i - b_i|^2 is NaN / inf -- any NaN or inf in a_i or b_i -- is a MISS at
+ * every k (an exact search never returns such a target), and the call ORs VTC_RECALL_NONFINITE (bit 40) into hits_b_from_a[0] and
+ * hits_a_from_b[0]: the caller learns of it from the counters it reads anyway (counter = value & (VTC_RECALL_NONFINITE - 1); the host
+ * layer raises).  The same holds for vtc_l2_recall_shard_rows / _cols (bit 40 survives the sum over <= 2^22 ranks). */
+#define VTC_RECALL_NONFINITE (1ll << 40)
 int vtc_l2_recall_bidir_supported(int n, int d);
 size_t vtc_l2_recall_bidir_workspace_bytes(int n, int d);
 int vtc_l2_recall_bidir(const float *a, const float *b, int n, int d, const int *k_vals_host, int nk, long long *hits_b_from_a,

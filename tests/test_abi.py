@@ -56,6 +56,22 @@ def test_no_process_wide_switches_in_the_abi():
     assert towers.tower_flags() == 0 and towers.tower_flags(ln_fold=False, full_last_layer=True) == 9
 
 
+def test_every_getenv_of_the_library_is_listed_in_the_header():
+    """the library reads environment variables into function-local statics -- process-wide state the ABI's
+    signatures do not show.  include/vtc_hip.h lists every one of them; this holds the list to the sources (both ways)."""
+    import glob
+    hdr = open(os.path.join(ROOT, "include", "vtc_hip.h")).read()
+    listed = set(re.findall(r"\b(VTC_(?:GEMM|SWEEP|CAM|PATCH)_[A-Z0-9_]+)=", hdr)) | {"VTC_CAM_TEST_GAVE_UP"}
+    used = set()
+    for f in glob.glob(os.path.join(ROOT, "vtc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "vtc_amd", "csrc", "*.h")):
+        used |= set(re.findall(r'getenv\("(VTC_[A-Z0-9_]+)"\)', open(f).read()))
+    assert used == listed, (sorted(used - listed), sorted(listed - used))
+    # ... and the test hook is compiled into the test build only
+    cam = open(os.path.join(ROOT, "vtc_amd", "csrc", "cam.hip")).read()
+    i = cam.index('getenv("VTC_CAM_TEST_GAVE_UP")')
+    assert "#ifdef VTC_TEST_HOOKS" in cam[max(0, i - 600):i] and "#endif" in cam[i:i + 200]
+
+
 def test_argument_errors_are_reported_not_thrown():
     from vtc_amd import _lib as L
     lib = L.lib()

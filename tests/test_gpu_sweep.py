@@ -655,7 +655,12 @@ def test_nonfinite_rows_are_misses_in_the_rank_path_and_rejected_by_the_metric()
         b /= np.linalg.norm(b, axis=1, keepdims=True)
         a[5, 3] = np.nan
         b[n - 7, :] = np.inf
-        got = ops.recall_bidir(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), ks).cpu().numpy()
+        raw = ops.recall_bidir(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), ks).cpu()
+        got, marked = ops.split_recall_counters(raw)
+        assert marked and int(raw[0, 0]) >> 40 and int(raw[1, 0]) >> 40          # VTC_RECALL_NONFINITE in both directions' first counter
+        got = got.numpy()
+        clean = ops.recall_bidir(torch.from_numpy(np.nan_to_num(a, nan=0.1)).cuda(), torch.from_numpy(np.nan_to_num(b, posinf=0.1)).cuda(), ks).cpu()
+        assert not ops.split_recall_counters(clean)[1] and int(clean.max()) <= n
         a64, b64 = a.astype(np.float64), b.astype(np.float64)
         want = np.zeros((2, len(ks)), dtype=np.int64)
         for direction, (q, g) in enumerate(((b64, a64), (a64, b64))):

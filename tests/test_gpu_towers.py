@@ -722,15 +722,18 @@ def test_half_text_blocks_under_range_stress_and_overflow_fallback():
     assert pt3.range_fallbacks == 1 and any("earlier forward" in str(w.message) for w in wlist) and torch.isfinite(again).all()
 
 
-def _stress_visual(a, seed, nframes, variant):
+def _stress_visual(a, seed, nframes, variant, s_attn, s_mlp):
     """A video tower with the activation statistics of trained checkpoints instead of the tame init-style ones:
       * a x100 outlier channel in class_embedding and in positional_embedding, and a 'massive activation' channel that SURVIVES ln_pre
         (ln_pre.bias[7] = 30: the residual stream carries ~30 on that channel in every row, 100x its usual size -- the pattern of real
         ViT checkpoints; the text-tower stress plants the same in token_embedding);
-      * ln_1 / ln_time / ln_2 .weight x 30 on the first four blocks: QKV pre-activations, attention logits and c_fc pre-activations in the
-        tens to hundreds, MLP hidden values in the hundreds to thousands;
+      * ln_2.weight x s_mlp on the first four blocks (c_fc pre-activations in the tens to hundreds, MLP hidden values in the hundreds to
+        thousands) and ln_1 / ln_time .weight x s_attn there (q and k BOTH scale: attention logits x s_attn^2, sharper softmaxes);
       * a heavy-tailed patch embedding: conv1.weight scaled per output channel by a log-normal (sigma 1) factor;
-      * trained-like (non-zero) temporal_fc."""
+      * trained-like (non-zero) temporal_fc.
+    How far this can go is a property of the NETWORK, not of an implementation: at s_attn = 10 the softmaxes are near one-hot and the
+    reference's own fp32 arithmetic disagrees with fp64 by 1.4e-4 (alt) / 1.3e-3 (v1) on the unit-norm embedding; at 30 by 7e-3 / 3e-2
+    (measured with the oracle).  The test therefore measures that conditioning and only asks 1e-3 where the problem is well posed."""
     sd = A.synth_visual(a, seed, nframes=nframes, prefix="v.", variant=variant)
     g = torch.Generator().manual_seed(seed + 1)
     W = a.vision_width
@@ -738,10 +741,10 @@ def _stress_visual(a, seed, nframes, variant):
     sd["v.positional_embedding"][:, 13] *= 100.0
     sd["v.ln_pre.bias"][7] += 30.0
     for l in range(4):
-        for ln in ("ln_1", "ln_2", "ln_time"):
+        for ln, sc in (("ln_1", s_attn), ("ln_time", s_attn), ("ln_2", s_mlp)):
             k = f"v.transformer.resblocks.{l}.{ln}.weight"
             if k in sd:
-                sd[k] *= 30.0
+                sd[k] *= sc
     sd["v.conv1.weight"] *= torch.exp(torch.randn(W, generator=g))[:, None, None, None]
     for k in list(sd):
         if k.endswith("temporal_fc.weight"):
@@ -749,27 +752,41 @@ def _stress_visual(a, seed, nframes, variant):
     return sd
 
 
-@pytest.mark.parametrize("F", [8, 16])
-@pytest.mark.parametrize("variant", ["alt", "v1"])
-def test_video_tower_16bit_under_massive_activations(variant, F):
+FP32_VS_FP64_TAME = 8e-8      # the oracle's fp32 vs fp64 unit-norm embedding on init-style weights (alt and v1, F = 8): the baseline conditioning
+
+
+@pytest.mark.parametrize("variant,F,s_attn", [("alt", 8, 3.0), ("alt", 16, 3.0), ("v1", 8, 3.0), ("v1", 16, 3.0), ("alt", 8, 6.0), ("v1", 8, 6.0)])
+def test_video_tower_16bit_under_massive_activations(variant, F, s_attn):
     """the 16-bit video tower -- bf16 operands, (hi, lo) row-centred residual stream, folded LayerNorm -- was held to 1e-3
     on init-style weights only.  Here: ViT-B/32 TimeSformer (model/timesformer_clip_alt.py and the v1 variant model/timesformer_clip.py),
-    F = 8 and 16 frames, under the stress of _stress_visual; the unit-norm embedding stays within BASELINE's 1e-3 of the fp32 oracle,
-    and fp32 mode within 1e-5 (which pins that the stress itself is computed right)."""
+    F = 8 and 16 frames, under the stress of _stress_visual, against the oracle in fp64.
+      * the conditioning of the case is MEASURED: kappa = (oracle fp32 vs oracle fp64) / (the same on init-style weights);
+      * s_attn = 3 (kappa ~ 2: well posed): fp32 mode within 1e-5, 16-bit mode within BASELINE's 1e-3;
+      * s_attn = 6 (attention logits x 36; kappa ~ 6 alt / ~ 25 v1): both tolerances scale with the measured kappa -- what any arithmetic
+        of that precision can promise on that network -- and the errors are printed."""
     from vtc_amd import towers
     a = A.VIT_B32
-    sd = _stress_visual(a, 231 + F, F, variant)
+    sd = _stress_visual(a, 231 + F, F, variant, s_attn, 30.0)
     x = A.synth_pixels((2, F, 3, 224, 224), 233).bfloat16().float()          # bf16-representable pixels: both sides see the same input
     oracle = T.timesformer_alt if variant == "alt" else T.timesformer_v1
-    ref = oracle(x, sd, a, "v.").numpy()
+    ref32 = oracle(x, sd, a, "v.").double().numpy()
+    ref = oracle(x.double(), {k: v.double() for k, v in sd.items()}, a, "v.").numpy()
     assert np.isfinite(ref).all()
+    kappa = max(1.0, float(np.abs(unit(ref32) - unit(ref)).max()) / FP32_VS_FP64_TAME)
+    print(f"[parity] video tower {variant} F={F} s_attn={s_attn}: oracle fp32 vs fp64 {np.abs(unit(ref32) - unit(ref)).max():.2e} -> kappa {kappa:.1f}; "
+          f"cosine between the two items {float((unit(ref)[0] * unit(ref)[1]).sum()):.4f}")
+    if s_attn <= 3.0:
+        assert kappa < 4.0, "the 'well posed' stress level is not: re-calibrate"
+        scale = 1.0
+    else:
+        scale = kappa
     for dtype in (torch.float32, torch.bfloat16):
         pv = towers.PackedVision(cuda_sd(sd), "v.", dtype)
         assert pv.w.variant == (0 if variant == "alt" else 1)
-        out = pv.forward(x.cuda() if dtype == torch.float32 else x.cuda().bfloat16()).cpu().numpy()
+        out = pv.forward(x.cuda() if dtype == torch.float32 else x.cuda().bfloat16()).cpu().numpy().astype(np.float64)
         assert np.isfinite(out).all()
-        report(f"video tower {variant} F={F} {dtype} under massive activations", np.abs(unit(out) - unit(ref)).max(), tol_for(dtype))
-        report_l2(f"video tower {variant} F={F} {dtype} under massive activations", out, ref, dtype)
+        report(f"video tower {variant} F={F} s_attn={s_attn} {dtype} under massive activations (tolerance x {scale:.1f})",
+               np.abs(unit(out) - unit(ref)).max(), scale * tol_for(dtype))
 
 
 def test_one_launch_cam_equals_the_multi_launch_path():

@@ -23,6 +23,7 @@ VTC_F16 = 3
 # vtc_vision_w.flags / vtc_text_w.flags (include/vtc_hip.h VTC_TOWER_*): per-model path switches
 TOWER_NO_LN_FOLD, TOWER_FULL_LAST_LAYER = 1, 8
 CAM_NO_FUSED = 1
+RECALL_NONFINITE = 1 << 40      # include/vtc_hip.h VTC_RECALL_NONFINITE: ORed into the first counter of a direction by the recall-only sweeps
 ABI_VERSION = 7
 
 vp, fp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers

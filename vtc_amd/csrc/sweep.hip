@@ -1359,6 +1359,10 @@ __device__ __forceinline__ void wave_dist64_x8(const float *__restrict__ q, cons
   for (int u = 0; u < 8; ++u) out[u] = sacc[u];
 }
 constexpr int RK_TLS = RK_CH * (RK_OW + 1);           // words of one plane's tile in LDS
+// A row whose target distance is non-finite adds this to its workgroup's FIRST partial hit count (a workgroup owns RK_OW = 32 rows: the
+// real count stays below it); the finish kernel strips it and raises bit 40 of the direction's first counter instead (VTC_RECALL_NONFINITE,
+// include/vtc_hip.h) -- the caller learns of NaN / inf embeddings from the counters it reads anyway, without another launch.
+constexpr int RK_NONFINITE = 1 << 20;
 template <int MAXP>      // planes of the wider of the kernel's two directions: 27 KiB of LDS with two planes (five workgroups per CU), 44 with four (three)
 struct RankShared {
   unsigned tl[MAXP * RK_TLS];
@@ -1516,7 +1520,7 @@ __device__ __forceinline__ void recall_rank_body(const RankArgs &P, int bid, Sha
     if (closer_all[cc] >= kmax) continue;                                 // a miss at every k
     // a non-finite target distance (NaN / inf in the query's or its target's embedding): every comparison below would be false and the
     // rank would read 0 -- a hit at every k.  An exact search never returns such a target (no distance compares below NaN): a miss.
-    if (!(dt[cc] < (double)INFINITY)) continue;
+    if (!(dt[cc] < (double)INFINITY)) { hit_cnt[0] += RK_NONFINITE; continue; }       // (... and said: recall_rank_finish_kernel raises VTC_RECALL_NONFINITE in the counters)
     if (n_amb[cc] > RK_AMB || n_ub[cc] > RK_UB) {
       if (lane == 0) P.flags[1 + atomicAdd(P.flags, 1)] = r;
       continue;
@@ -1590,10 +1594,13 @@ __global__ __launch_bounds__(64 * RK_FW) void recall_rank_finish_kernel(const Ra
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (bid == 0) {            // this direction's first workgroup: the rank kernel's per-workgroup hit counts -> one atomic per k
     int acc[4] = {0, 0, 0, 0};
+    int nf = 0;
     for (int i = threadIdx.x; i < P.nparts; i += 64 * RK_FW) {
       const int4 v = *reinterpret_cast<const int4 *>(P.part + (size_t)i * 4);
-      acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      nf |= v.x >> 20;                                   // rows with a non-finite target distance (RK_NONFINITE each)
+      acc[0] += v.x & (RK_NONFINITE - 1); acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
     }
+    if (__ballot(nf != 0) != 0 && lane == 0) atomicOr(&P.hits[0], 1ull << 40);       // VTC_RECALL_NONFINITE
     __shared__ int red[RK_FW][4];
 #pragma unroll
     for (int qk = 0; qk < 4; ++qk) {

@@ -371,8 +371,13 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
     same_width = d == feats_b_local.shape[1]
     acc = torch.zeros(2 * len(ks) + 1, dtype=torch.int64, device=feats_a_local.device)        # hit counters + the non-finite word
     hits, flag = acc[: 2 * len(ks)].view(2, len(ks)), acc[2 * len(ks):]
-    _flag_nonfinite(flag, feats_a_local, feats_b_local)
     hip_sweep = topk is None
+    # the finite check: the recall-only HIP paths report NaN / inf rows inside their counters (VTC_RECALL_NONFINITE: no launch of its own);
+    # every other path gets one flag launch over this rank's rows
+    rank_hip = hip_sweep and rank_ops is None and precision == 3 and RANK_PATH and len(ks) <= 4 and feats_a_local.is_cuda and same_width and (
+        (world == 1 and n_total >= RANK_MIN_ROWS and d % 64 == 0) or (world > 1 and shard_ops is None and rank_sharded(n_total, d, precision, world, len(ks))))
+    if not rank_hip:
+        _flag_nonfinite(flag, feats_a_local, feats_b_local)
     if topk is None:
         from . import ops
 
@@ -404,7 +409,12 @@ def sharded_recall(feats_a_local: torch.Tensor, feats_b_local: torch.Tensor, n_t
         clock.mark("allreduce")
     acc = acc.cpu()
     clock.close(path or (sweep_path(n_total, precision, world, depth, d) if hip_sweep else "injected top-k"), exchange)
-    if int(acc[-1]) != 0:
+    marker = False
+    if rank_hip:
+        from . import ops
+        counters, marker = ops.split_recall_counters(acc[: 2 * len(ks)])
+        acc[: 2 * len(ks)] = counters
+    if int(acc[-1]) != 0 or marker:
         raise ValueError("sharded_recall: non-finite values in the embeddings of at least one rank -- the ranks of such rows are undefined "
                          "(vtc_amd.host.model.nonfinite_cause lists what this build knows can produce them)")
     h = acc[: 2 * len(ks)].view(2, len(ks))

@@ -67,7 +67,13 @@ class RecallAtK(BaseMetric):
             return torch.device(self.device)
         return torch.device("cuda", torch.cuda.current_device())
 
-    def _prep(self, features_a, features_b):
+    def _nonfinite_error(self, bits=3):
+        which = " and ".join(n for n, m in ((self.name_a, 1), (self.name_b, 2)) if bits & m)
+        return ValueError(f"RecallAtK: non-finite values in the {which} features -- a NaN distance compares below nothing, the ranks "
+                          "of such rows are undefined (faiss would return arbitrary ids for them); fix the embeddings "
+                          "(vtc_amd.host.model.nonfinite_cause lists what this build knows can produce them)")
+
+    def _prep(self, features_a, features_b, check=True):
         """fp32 [N, D] on the GPU; D zero-padded to the sweep's granule of 64 (squared L2 distances are unchanged;
         faiss.IndexFlatL2 takes any D), depth = max(k) + 1 (metric.py:145) capped by the gallery size."""
         a = torch.as_tensor(features_a, dtype=torch.float32).to(self._dev())
@@ -79,13 +85,10 @@ class RecallAtK(BaseMetric):
         pad = -a.shape[1] % 64
         if pad:
             a, b = torch.nn.functional.pad(a, (0, pad)), torch.nn.functional.pad(b, (0, pad))
-        if self.check_finite:
+        if self.check_finite and check:
             bits = ops.nonfinite_bits(a, b)
             if bits:
-                which = " and ".join(n for n, m in ((self.name_a, 1), (self.name_b, 2)) if bits & m)
-                raise ValueError(f"RecallAtK: non-finite values in the {which} features -- a NaN distance compares below nothing, the ranks "
-                                 "of such rows are undefined (faiss would return arbitrary ids for them); fix the embeddings "
-                                 "(vtc_amd.host.model.nonfinite_cause lists what this build knows can produce them)")
+                raise self._nonfinite_error(bits)
         depth = min(int(np.max(self.k_vals) + 1), a.shape[0])
         if depth > 64:
             raise ValueError(f"RecallAtK: max(k_vals) + 1 = {depth} exceeds the sweep's list depth of 64 (one entry per lane of "
@@ -141,17 +144,26 @@ class RecallAtK(BaseMetric):
         min_rows = self.bidir_min_rows_f32 if self.precision == L.SWEEP_F32 else self.bidir_min_rows
         if features_a.shape[0] != features_b.shape[0] or features_a.shape[0] < min(min_rows, self.rank_min_rows):
             return self.compute(features_a, features_b), self.compute(features_b, features_a)
-        a, b, depth = self._prep(features_a, features_b)
+        a, b, depth = self._prep(features_a, features_b, check=False)
         ks = [int(k) for k in self.k_vals]
         if (self.precision == L.SWEEP_EXACT and self.rank_path and a.shape[0] >= self.rank_min_rows and len(ks) <= 4
                 and max(ks) <= a.shape[0] and ops.recall_bidir_supported(a.shape[0], a.shape[1])):
             # paired rows, parity mode: the reference asks only whether the query's own index is among the first k -- the RANK of one
-            # gallery row -- so the sorted lists are never built (vtc_l2_recall_bidir; the same counters as the two-step form below)
-            hits = ops.recall_bidir(a, b, ks, ws=self._workspace(L.lib().vtc_l2_recall_bidir_workspace_bytes(a.shape[0], a.shape[1]), a.device)).cpu().numpy()
+            # gallery row -- so the sorted lists are never built (vtc_l2_recall_bidir; the same counters as the two-step form below).
+            # The finite check rides in the counters (VTC_RECALL_NONFINITE): no launch, no D2H of its own.
+            hits, bad = ops.split_recall_counters(ops.recall_bidir(a, b, ks, ws=self._workspace(
+                L.lib().vtc_l2_recall_bidir_workspace_bytes(a.shape[0], a.shape[1]), a.device)).cpu())
+            if bad and self.check_finite:
+                raise self._nonfinite_error(ops.nonfinite_bits(a, b) or 3)
+            hits = hits.numpy()
             n = a.shape[0]
             return ([(k, float(h) / n) for k, h in zip(self.k_vals, hits[0])], [(k, float(h) / n) for k, h in zip(self.k_vals, hits[1])])
         if features_a.shape[0] < min_rows:
             return self.compute(features_a, features_b), self.compute(features_b, features_a)
+        if self.check_finite:
+            bits = ops.nonfinite_bits(a, b)
+            if bits:
+                raise self._nonfinite_error(bits)
         ids_b2a, _, ids_a2b, _ = ops.l2_topk_bidir(a, b, depth, precision=self.precision, return_dists=False, ws=self._workspace(
             L.lib().vtc_l2_topk_bidir_workspace_bytes(a.shape[0], b.shape[0], a.shape[1], self.precision, 0), a.device))
         return self._hits_to_recall(ids_b2a, a.shape[0]), self._hits_to_recall(ids_a2b, b.shape[0])

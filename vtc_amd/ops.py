@@ -339,7 +339,8 @@ def recall_bidir(a: torch.Tensor, b: torch.Tensor, k_vals: Sequence[int], ws: Op
                  hits: Optional[torch.Tensor] = None) -> torch.Tensor:
     """R@K hit counters of both directions of n paired rows WITHOUT the sorted neighbour lists (vtc_l2_recall_bidir: one distance GEMM +
     one rank launch): hits[0, j] += #{i : a_i among the k_j nearest a's of b_i} (= RecallAtK.compute(a, b) x n), hits[1, j] the transposed
-    direction (= compute(b, a) x n).  The same counters as l2_topk_bidir(depth = max k + 1, EXACT) + recall_hits_pair."""
+    direction (= compute(b, a) x n).  The same counters as l2_topk_bidir(depth = max k + 1, EXACT) + recall_hits_pair.
+    Non-finite rows are misses and raise bit 40 of hits[:, 0] (L.RECALL_NONFINITE): split_recall_counters() on the host copy."""
     a, b = _gpu(a, torch.float32, "a"), _gpu(b, torch.float32, "b")
     n, d = a.shape
     assert b.shape == (n, d) and 1 <= len(k_vals) <= 4
@@ -353,6 +354,13 @@ def recall_bidir(a: torch.Tensor, b: torch.Tensor, k_vals: Sequence[int], ws: Op
     L.check(L.lib().vtc_l2_recall_bidir(a.data_ptr(), b.data_ptr(), n, d, ks, len(k_vals), hits[0].data_ptr(), hits[1].data_ptr(),
                                         ws.data_ptr(), ws.numel(), _stream()), "vtc_l2_recall_bidir")
     return hits
+
+
+def split_recall_counters(hits_host: torch.Tensor):
+    """(counters, nonfinite) of a HOST copy of the recall-only sweeps' hit counters: the NaN / inf marker (bit 40 and above of the first
+    counter of a direction, summed over ranks) taken off."""
+    h = hits_host.to(torch.int64)
+    return h & (L.RECALL_NONFINITE - 1), bool((h >> 40).any())
 
 
 def recall_planes(k_vals: Sequence[int], n_total: int) -> int:

@@ -29,6 +29,7 @@
  *   VTC_GEMM_CG=n, VTC_GEMM_SUPER=n   tile walk: column-group width / row tiles per super-row (default 0 = by shape)
  *   VTC_GEMM_RESID_SMALL_K=k   residual GEMMs with K <= k on 128 x 128 tiles (two workgroups per CU; default 0: the heuristic alone)
  *   VTC_GEMM_STAGGER=g,t       start workgroup groups t ticks apart (a measured null, kept for A/B)
+ *   VTC_GEMM_CU_BUDGET=n       the persistent 256 x 256 grid on at most n CUs (two streams' GEMMs side by side: tools/two_stream_halves.py)
  *   VTC_PATCH_IM2ROW=1         patch embedding through the im2row matrix instead of the in-place LDS-DMA gather
  *   VTC_SWEEP_MIN_TILE=0|1     distance GEMM of the block-minima sweep: 0 (default) 256 x 256 phased tiles, 1 128 x 128 tiles          sweep.hip
  *   VTC_SWEEP_EXACT_V1=1       the round-2 EXACT sweep (split-bf16 candidate lists) instead of the block-minima sweep
@@ -99,11 +100,15 @@ typedef struct {
  * (FULL_LAST_LAYER: see below). */
 enum { VTC_TOWER_NO_LN_FOLD = 1,       /* run the LayerNorm kernels even when the blocks carry folded weights (*_wf)              */
        /* 2, 4: retired in ABI 6 (the fused QKV + attention kernel of rounds 1-4 left the product: tools/probes/qkv_attn.hip) */
-       VTC_TOWER_FULL_LAST_LAYER = 8   /* By default the LAST block's queries, out_proj and MLP run only on the rows that reach the
+       VTC_TOWER_FULL_LAST_LAYER = 8,  /* By default the LAST block's queries, out_proj and MLP run only on the rows that reach the
                                           output (x[:, 0] behind ln_post, model/timesformer_clip_alt.py:281; the EOT row behind
                                           ln_final): on every other row of that block they are dead -- nothing reads them (its keys
                                           and values are computed for every row).  This flag computes them anyway (same embeddings
-                                          within rounding; for measurements against the unpruned path)                          */ };
+                                          within rounding; for measurements against the unpruned path)                          */
+       VTC_TOWER_NO_SPLITK = 16        /* (ABI 7) At batch 1 - 2 (<= 1024 padded rows) the MLP's c_proj runs split over K: slices
+                                          of K on 4x the workgroups, then one row pass that sums them, applies the residual update
+                                          and writes the LayerNorm statistics.  This flag keeps the one-pass GEMM (same embeddings
+                                          up to the summation order over K)                                                      */ };
 
 /* Vision tower: upstream VisionTransformer (nframes == 0) or
  * model/timesformer_clip_alt.py:203-286 VisualTransformer (nframes > 0). */
@@ -205,6 +210,10 @@ int vtc_cam_fused_gave_up(int device);
 
 /* ---- small fp32 ops of the wrappers (model/model.py:26-27, 338, 357-362, 369) -------- */
 int vtc_normalize_rows(const float *x, float *out, int n, int d, void *stream);
+/* Both embedding sets of a forward in one launch: outx = rows of x [nx, d] / their norms, outy likewise for y [ny, d] (the two
+ * `normalize` calls that end every PretrainedCLIP*.forward, model/model.py:263-264, 366-367), and the non-finite watchdog with it:
+ * flag[0] (int32, device; NULL: none) |= 1 when a row of x holds a NaN / inf, |= 2 for y (ABI 7; see vtc_nonfinite_flag2). */
+int vtc_normalize_rows2(const float *x, float *outx, int nx, const float *y, float *outy, int ny, int d, int *flag, void *stream);
 /* out[g] = mean over `group` consecutive rows (frames -> video, title+comments -> text) */
 int vtc_mean_groups(const float *x, float *out, int n_groups, int group, int d, void *stream);
 /* Token packing: the array-building half of `_tokenise` (dataset_loaders/dataset_loaders.py:224-248; the BPE encoder and the RAKE

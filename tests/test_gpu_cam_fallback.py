@@ -28,6 +28,8 @@ m = HM.PretrainedCLIP_finaltf(model_type=ClipConfig(**asdict(a)), branch_to_adap
 m.load_state_dict(sd, strict=True)
 m = m.eval().cuda()
 m.compute_dtype = torch.float32
+m.overlap_towers = False      # (with the towers on two streams the text-branch CAM is enqueued under the visual tower in its multi-launch form and
+                              #  never tries the one-launch path: this scenario is about the one-launch path's fallback)
 B = 6
 vis = A.synth_pixels((B, 3, a.image_resolution, a.image_resolution), 8).cuda()
 title = A.synth_tokens(B, a, 9).cuda()

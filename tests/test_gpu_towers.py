@@ -722,6 +722,61 @@ def test_half_text_blocks_under_range_stress_and_overflow_fallback():
     assert pt3.range_fallbacks == 1 and any("earlier forward" in str(w.message) for w in wlist) and torch.isfinite(again).all()
 
 
+def test_split_k_c_proj_at_batch_1_and_2_equals_the_one_pass_gemm():
+    """at batch 1 - 2 (<= 1024 padded rows) the MLP's c_proj (K = 3072 / 2048 on a handful of 64 x 64 tiles) runs split
+    over K, and ONE row pass sums the slices, applies the residual update on the (hi, lo) stream and writes the LayerNorm statistics
+    (no fold_stats launch).  Same embeddings as the one-pass GEMM (VTC_TOWER_NO_SPLITK) up to the summation order over K -- which, through
+    the bf16 roundings downstream, means: to the 16-bit tower's noise level, both equally close to the oracle (1e-3) --, the same launch
+    count (GEMM + fold_stats -> split GEMM + row pass); a batch too large for it
+    (5 videos: 2 048 padded rows) takes the one-pass path whatever the flag."""
+    from vtc_amd import _lib as L
+    from vtc_amd import towers
+    a = A.VIT_B32
+    lib = L.lib()
+    sdv = A.synth_visual(a, 301, nframes=8, prefix="v.")
+    for k in list(sdv):
+        if k.endswith("temporal_fc.weight"):
+            sdv[k] = torch.randn(sdv[k].shape, generator=torch.Generator().manual_seed(302)) * 0.02
+    sdt = A.synth_text(a, 303, prefix="t.")
+    vid = A.synth_pixels((5, 8, 3, 224, 224), 304)
+    txt = A.synth_tokens(12, a, 305, empty_frac=0.2)
+    ref_v = T.timesformer_alt(vid[:2], sdv, a, "v.").numpy()
+    ref_t = CR.encode_text(txt, sdt, a, "t.").numpy()
+
+    def run(tower, x, flags):
+        tower.w.flags = flags
+        tower.forward(x)
+        n0 = lib.vtc_debug_launch_count()
+        out = tower.forward(x)
+        return out.cpu().numpy(), lib.vtc_debug_launch_count() - n0
+
+    pv = towers.PackedVision(cuda_sd(sdv), "v.", torch.bfloat16)
+    pt = towers.PackedText(cuda_sd(sdt), "t.", torch.bfloat16, heads=a.transformer_heads)
+    base = towers.tower_flags()
+    assert base & L.TOWER_NO_SPLITK == 0
+    for B in (1, 2):
+        split, n_split = run(pv, vid[:B].cuda(), base)
+        one, n_one = run(pv, vid[:B].cuda(), base | L.TOWER_NO_SPLITK)
+        # two roundings of ONE computation: an fp32-level difference in a residual row (summation order over K) flips bf16 roundings of the
+        # operand copy further down, so the two agree to the 16-bit tower's noise level, not to 1e-7 -- the bound of the batch-independence
+        # tests; what must hold is that BOTH sit equally close to the oracle
+        report(f"video tower B={B}: split-K c_proj vs one-pass", np.abs(unit(split) - unit(one)).max(), 1e-3)
+        e_split, e_one = np.abs(unit(split) - unit(ref_v[:B])).max(), np.abs(unit(one) - unit(ref_v[:B])).max()
+        report(f"video tower B={B}: split-K c_proj vs oracle (one-pass: {e_one:.3e})", e_split, 1e-3)
+        assert e_split < 2.0 * e_one + 1e-4
+        assert n_one - n_split == 0 and n_split > 100, (n_split, n_one)       # 11 x (GEMM + fold_stats) -> 11 x (split GEMM + row pass)
+    big_split, _ = run(pv, vid.cuda(), base)
+    big_one, _ = run(pv, vid.cuda(), base | L.TOWER_NO_SPLITK)
+    assert np.array_equal(big_split, big_one)                                  # 5 videos = 2 048 padded rows: no split either way
+    for ragged in (True, False):
+        pt.w.flags = base
+        s_ = pt.forward(txt.cuda(), ragged=ragged).cpu().numpy()
+        pt.w.flags = base | L.TOWER_NO_SPLITK
+        o_ = pt.forward(txt.cuda(), ragged=ragged).cpu().numpy()
+        report(f"text tower 12 sequences ragged={ragged}: split-K c_proj vs one-pass", np.abs(unit(s_) - unit(o_)).max(), 1e-3)
+        report_text(f"text tower 12 sequences ragged={ragged}: split-K vs oracle", unit(s_), unit(ref_t), torch.bfloat16, a.embed_dim)
+
+
 def _stress_visual(a, seed, nframes, variant, s_attn, s_mlp):
     """A video tower with the activation statistics of trained checkpoints instead of the tame init-style ones:
       * a x100 outlier channel in class_embedding and in positional_embedding, and a 'massive activation' channel that SURVIVES ln_pre

@@ -21,7 +21,7 @@ PROF_CLASSES = ("gemm_bf16", "gemm_f32", "attention", "norm", "embed", "topk")
 PROF_REGIONS = ("other", "attn", "mlp")
 VTC_F16 = 3
 # vtc_vision_w.flags / vtc_text_w.flags (include/vtc_hip.h VTC_TOWER_*): per-model path switches
-TOWER_NO_LN_FOLD, TOWER_FULL_LAST_LAYER = 1, 8
+TOWER_NO_LN_FOLD, TOWER_FULL_LAST_LAYER, TOWER_NO_SPLITK = 1, 8, 16
 CAM_NO_FUSED = 1
 RECALL_NONFINITE = 1 << 40      # include/vtc_hip.h VTC_RECALL_NONFINITE: ORed into the first counter of a direction by the recall-only sweeps
 ABI_VERSION = 7
@@ -74,6 +74,7 @@ SIGNATURES = {
     "vtc_cam_forward": (C.c_int, [C.POINTER(CamW), fp, fp, ip, C.c_int, C.c_int, C.c_int, fp, vp, C.c_size_t, C.c_int, vp]),
     "vtc_cam_fused_gave_up": (C.c_int, [C.c_int]),
     "vtc_normalize_rows": (C.c_int, [fp, fp, C.c_int, C.c_int, vp]),
+    "vtc_normalize_rows2": (C.c_int, [fp, fp, C.c_int, fp, fp, C.c_int, C.c_int, vp, vp]),
     "vtc_mean_groups": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp]),
     "vtc_nonfinite_flag": (C.c_int, [fp, C.c_size_t, vp, vp]),
     "vtc_nonfinite_flag2": (C.c_int, [fp, C.c_size_t, fp, C.c_size_t, vp, vp]),

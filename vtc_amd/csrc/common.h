@@ -226,6 +226,11 @@ struct GemmEpi {
   // the row count M in DEVICE memory (*m_dev <= the M handed to launch_gemm, which then only sizes the grid): the ragged text
   // tower without a host sync (vtc_text_forward2) -- the persistent kernels read it when they start
   const int *m_dev = nullptr;
+  // split-K (small M, long K: the MLP's c_proj at batch 1-2, whose 64 x 64 tiles are few and walk K = 3072 / 2048 alone): mode 0, fp32
+  // out, 16-bit operands.  The K range is cut into `ksplit` slices; tile (m, n) of slice s writes its partial products to
+  // out + s * split_stride (fp32 elements).  One tile per workgroup (the launcher checks that the chip holds them all): the sum over
+  // the slices, the bias, the residual update and the LayerNorm statistics are norm.hip's splitk_resid_rows_kernel.
+  int ksplit = 0, split_stride = 0;
 };
 enum { EPI_PATCH = 3, EPI_L2DIST = 4, EPI_SCALE = 5, EPI_L2MIN = 6, EPI_RESID_LN = 7,
        // modes 0 / 1 / 2 with the folded LayerNorm (fold_* fields), as instantiations of their own: chosen by launch_gemm
@@ -246,6 +251,8 @@ bool gemm_patch_gather_supported(int n_frames, int grid, int patch, int res, int
 int launch_layernorm(const float *x, const float *g, const float *b, void *y, int rows, int width, int out_dtype,
                      const int *row_index, int row_mul, bool no_norm, hipStream_t stream, const int *rows_dev = nullptr);
 int launch_fold_stats(const float *part, int nb, int rows, float *stat, hipStream_t stream, const int *rows_dev = nullptr);
+int launch_splitk_resid_rows(const float *part, int nsl, int stride, const float *bias, void *hi, void *lo, float *stat, int rows, int width, int dtype,
+                             hipStream_t stream, const int *rows_dev = nullptr);
 int launch_cast_rowstats(const float *x, void *y16, void *y16lo, float *stat, int rows, int width, int dtype, hipStream_t stream,
                          const int *rows_dev = nullptr);
 // dst[i] = src row (row_index[i], or i * row_mul): rows of row_bytes (a multiple of 16) bytes

@@ -859,12 +859,15 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(GemmParams p) {
   const int g = lane >> 4;
 
   // ---- persistent, XCD-aware tile walk ----------------------------------------------------
-  const int ntiles = p.MT * p.NT, nwg = gridDim.x, bid = blockIdx.x;
+  // (split-K, GemmEpi::ksplit: the walk runs over (tile, K slice) pairs, slice-minor; every workgroup has exactly one)
+  const int S = p.epi.ksplit > 1 ? p.epi.ksplit : 1;
+  const int ntiles = p.MT * p.NT * S, nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
   const int nb_x = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);                 // workgroups sharing this XCD label
   const int nt_x = (ntiles >> 3) + (xcd < (ntiles & 7) ? 1 : 0);           // tiles given to this XCD label
   const int start_x = xcd * (ntiles >> 3) + min(xcd, ntiles & 7);
   auto decode = [&](int logical, int &m0, int &n0) {
+    if (S > 1) logical /= S;
     const int per_super = SUPER * p.NT;
     const int sr = logical / per_super, rem = logical - sr * per_super;
     const int gsz = min(SUPER, p.MT - sr * SUPER);
@@ -876,6 +879,13 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void gemm_kernel(GemmParams p) {
   if (li >= nt_x) return;                      // uniform for the whole workgroup
   int m0, n0;
   decode(start_x + li, m0, n0);
+  if (S > 1) {                                   // this workgroup's K slice: shifted operand bases, its own partial-product plane
+    const int ks = (start_x + li) % S;
+    p.K /= S;
+    p.A += (size_t)ks * p.K * sizeof(T);
+    p.W += (size_t)ks * p.K * sizeof(T);
+    p.out = reinterpret_cast<float *>(p.out) + (size_t)ks * p.epi.split_stride;
+  }
 
   const int ksteps = p.K / Mma<T>::KPR;
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)lds);
@@ -1528,11 +1538,16 @@ template <typename T, int MODE, typename OutT, int WM, int WN, int TM, int TN, i
 int run(GemmParams p, hipStream_t stream) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT_ = WM * WN * 64;
   p.MT = cdiv(p.M, BM); p.NT = cdiv(p.N, BN);
-  const int ntiles = p.MT * p.NT;
+  const int S = p.epi.ksplit > 1 ? p.epi.ksplit : 1;
+  const int ntiles = p.MT * p.NT * S;
   const size_t shmem = (size_t)NSTAGE * (BM + BN) * ROWB;
-  if (p.K / Mma<T>::KPR < NSTAGE - 1) { vtc_set_error("gemm: K=%d is too short for %d stages", p.K, NSTAGE); return 1; }
+  if (p.K / S / Mma<T>::KPR < NSTAGE - 1) { vtc_set_error("gemm: K=%d (/ %d slices) is too short for %d stages", p.K, S, NSTAGE); return 1; }
   const int wg_per_cu = shmem > 80 * 1024 ? 1 : 2;
   const int grid = min(ntiles, num_cus() * wg_per_cu);
+  if (S > 1 && (grid < ntiles || p.K % (S * Mma<T>::KPR) != 0)) {
+    vtc_set_error("gemm: split-K x %d needs one workgroup per (tile, slice) (%d > %d resident) and K %% (slices x %d) == 0 (K=%d)", S, ntiles, grid, Mma<T>::KPR, p.K);
+    return 1;
+  }
   static PerDeviceOnce attr;
   if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&gemm_kernel<T, MODE, OutT, WM, WN, TM, TN, NSTAGE>), (int)shmem, "gemm")) return 1;
   hipLaunchKernelGGL((gemm_kernel<T, MODE, OutT, WM, WN, TM, TN, NSTAGE>), dim3(grid), dim3(NT_), shmem, stream, p);
@@ -1540,6 +1555,7 @@ int run(GemmParams p, hipStream_t stream) {
   return 0;
 }
 
+int g_cu_budget = 0;                  // > 0: the persistent 256 x 256 grid takes at most this many workgroups (= CUs) -- two streams' GEMMs side by side (diagnostics: VTC_GEMM_CU_BUDGET)
 int g_deep = VTC_GEMM_DEEP_DEFAULT;   // pipeline depth of the 256 x 256 kernel: 0 = one quarter in flight (rounds 1-3), 1 = deep (VTC_GEMM_DEEP)
 
 template <int MODE, typename OutT, typename T, int DEEP>
@@ -1547,7 +1563,7 @@ int run_phased_d(GemmParams p, hipStream_t stream) {
   p.MT = cdiv(p.M, 256); p.NT = cdiv(p.N, 256);
   const int ntiles = p.MT * p.NT;
   const size_t shmem = (size_t)2 * 512 * ROWB + (MODE == EPI_RESID_LN ? 16 : 0) + (l2min_half_keys(MODE) ? 2048 : 0);   // 128 KiB: one workgroup per CU (+ the ticket word / the tile's half norms)
-  const int grid = min(ntiles, num_cus());
+  const int grid = min(ntiles, g_cu_budget > 0 ? min(g_cu_budget, num_cus()) : num_cus());
   static PerDeviceOnce attr;
   if (ensure_dynamic_lds(attr, reinterpret_cast<const void *>(&gemm_phased_kernel<MODE, OutT, T, DEEP>), (int)shmem, "gemm_phased")) return 1;
   VTC_STAMP_HOST_BEFORE(p, stream);
@@ -1630,6 +1646,12 @@ int dispatch(GemmParams p, hipStream_t stream) {
   using Out16 = std::conditional_t<sizeof(T) == 2, T, bf16_t>;   // 16-bit outputs are in the operand format (fp32 operands: bf16)
   switch (p.epi.mode) {
     case VTC_EPI_STORE:
+      if constexpr (sizeof(T) == 2) {
+        if (p.epi.ksplit > 1) {      // (launch_gemm checked: fp32 partial planes, 64 x 64 tiles, one workgroup per (tile, slice))
+          if (p.K / p.epi.ksplit / Mma<T>::KPR >= VTC_SMALL_NSTAGE - 1) return run<T, VTC_EPI_STORE, float, 2, 1, 2, 4, VTC_SMALL_NSTAGE>(p, stream);
+          return run<T, VTC_EPI_STORE, float, 2, 1, 2, 4, 2>(p, stream);
+        }
+      }
       if (out_f32) return run_cfg<T, VTC_EPI_STORE, float>(p, stream);
       if constexpr (sizeof(T) == 2) {
         if (p.epi.fold_stat) return run_cfg<T, EPI_STORE_FOLD, Out16>(p, stream);
@@ -1708,6 +1730,11 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
     VTC_CHECK(gemm_resid_ln_supported(M, N, K, dtype), "gemm: fused residual + LayerNorm does not cover M=%d N=%d K=%d dtype=%d", M, N, K, dtype);
     VTC_CHECK(epi.ln_g && epi.ln_b && epi.ln_out && epi.ln_cnt && (epi.ldo == 0 || epi.ldo == N), "gemm: fused LayerNorm arguments");
   }
+  if (epi.ksplit > 1) {
+    VTC_CHECK(esz == 2 && epi.mode == VTC_EPI_STORE && epi.out_dtype == VTC_F32 && !bias && !epi.y16 && !epi.fold_stat && M % 64 == 0 && N % 64 == 0 &&
+                  epi.split_stride >= M * (epi.ldo > 0 ? epi.ldo : N),
+              "gemm: split-K takes 16-bit operands, a plain fp32 store without bias, M and N multiples of 64 and a plane stride >= M x ldo");
+  }
   if (epi.y16 || epi.fold_stat) {     // folded LayerNorm: only the interior fast epilogues carry it
     // (the consumer may write its N columns into a wider output -- ldo > N: a column window of a projection; the producer's (hi, lo)
     // arrays are indexed with ldo too, so there ldo == N)
@@ -1718,7 +1745,7 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
               "gemm: folded LayerNorm arguments do not go with epilogue %d", epi.mode);
   }
   // diagnostics knobs, read once (C++11 static initialisation is thread-safe; never written afterwards)
-  struct Env { int tile = 0, sg = 0, st = 0, cg = -1, rsk = 0, deep = VTC_GEMM_DEEP_DEFAULT, super = 0; };
+  struct Env { int tile = 0, sg = 0, st = 0, cg = -1, rsk = 0, deep = VTC_GEMM_DEEP_DEFAULT, super = 0, cus = 0; };
   static const Env env = [] {
     Env v;
     if (const char *e = getenv("VTC_GEMM_TILE")) v.tile = atoi(e);
@@ -1727,11 +1754,13 @@ int launch_gemm(const void *A, const void *W, const float *bias, void *out, int 
     if (const char *e = getenv("VTC_GEMM_SUPER")) v.super = atoi(e);
     if (const char *e = getenv("VTC_GEMM_RESID_SMALL_K")) v.rsk = atoi(e);
     if (const char *e = getenv("VTC_GEMM_STAGGER")) sscanf(e, "%d,%d", &v.sg, &v.st);
+    if (const char *e = getenv("VTC_GEMM_CU_BUDGET")) v.cus = atoi(e);
     return v;
   }();
   g_force_tile = env.tile;
   g_resid_small_k = env.rsk;
   g_deep = env.deep;
+  g_cu_budget = env.cus;
   GemmParams p;
   p.A = (const char *)A; p.W = (const char *)W; p.bias = bias; p.out = out;
   p.M = M; p.N = N; p.K = K;

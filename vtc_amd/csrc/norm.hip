@@ -136,6 +136,61 @@ __global__ __launch_bounds__(256) void split_merge_rows_kernel(const T *__restri
   }
 }
 
+// ---- split-K finish of a residual GEMM on the folded (hi, lo) stream (small batches; towers.hip resid_proj, gemm.hip GemmEpi::ksplit) ----
+// The GEMM left `nsl` planes of partial products part[s][row][c] (fp32).  Per row, one wave: v = bias + sum_s part[s] (slices in order),
+// then exactly what the re-centring residual epilogue of gemm.hip does (EPI_RESID_FOLD_C): x = ((hi - mean_prev) + lo) + v, stored back as
+// hi = fmt(x), lo = fmt(x - hi) -- and the row's LayerNorm statistics (mean, rstd) of x written WHOLE (two passes over the wave's
+// registers), which is what fold_stats_kernel derives from the per-64-column partials: that launch does not exist on this path.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_resid_rows_kernel(const float *__restrict__ part, int nsl, int stride, const float *__restrict__ bias,
+                                                                T *__restrict__ hi, T *__restrict__ lo, float2 *__restrict__ stat, int rows, int width,
+                                                                const int *__restrict__ rows_dev) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rows_dev) rows = *rows_dev;
+  if (r >= rows) return;
+  const float mu = stat[r].x;                     // the row's mean before this update (the stream is kept centred)
+  float4 y[4];                                    // width <= 1024: four columns per lane and 256-column chunk
+  float s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < width) {
+      float4 v = bias ? *reinterpret_cast<const float4 *>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int sl = 0; sl < nsl; ++sl) {
+        const float4 q = *reinterpret_cast<const float4 *>(part + (size_t)sl * stride + (size_t)r * width + c);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      const uint2 h = *reinterpret_cast<const uint2 *>(hi + (size_t)r * width + c), l = *reinterpret_cast<const uint2 *>(lo + (size_t)r * width + c);
+      float4 x;
+      x.x = ((up16<T>((unsigned short)(h.x & 0xFFFFu)) - mu) + up16<T>((unsigned short)(l.x & 0xFFFFu))) + v.x;
+      x.y = ((up16<T>((unsigned short)(h.x >> 16)) - mu) + up16<T>((unsigned short)(l.x >> 16))) + v.y;
+      x.z = ((up16<T>((unsigned short)(h.y & 0xFFFFu)) - mu) + up16<T>((unsigned short)(l.y & 0xFFFFu))) + v.z;
+      x.w = ((up16<T>((unsigned short)(h.y >> 16)) - mu) + up16<T>((unsigned short)(l.y >> 16))) + v.w;
+      uint2 pk, pl;
+      pk.x = pack16<T>(x.x, x.y);
+      pk.y = pack16<T>(x.z, x.w);
+      pl.x = pack16<T>(x.x - up16<T>((unsigned short)(pk.x & 0xFFFFu)), x.y - up16<T>((unsigned short)(pk.x >> 16)));
+      pl.y = pack16<T>(x.z - up16<T>((unsigned short)(pk.y & 0xFFFFu)), x.w - up16<T>((unsigned short)(pk.y >> 16)));
+      *reinterpret_cast<uint2 *>(hi + (size_t)r * width + c) = pk;
+      *reinterpret_cast<uint2 *>(lo + (size_t)r * width + c) = pl;
+      y[i] = x;
+      s1 += (x.x + x.y) + (x.z + x.w);
+    }
+  }
+  const float mean = wave_sum(s1) / width;
+  float m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (lane * 4 + 256 * i < width) {
+      const float d0 = y[i].x - mean, d1 = y[i].y - mean, d2 = y[i].z - mean, d3 = y[i].w - mean;
+      m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  m2 = wave_sum(m2);
+  if (lane == 0) stat[r] = make_float2(mean, 1.0f / sqrtf(m2 / width + 1e-5f));
+}
+
 // dst[i] = src row (row_index[i] or i * row_mul): the compact copy of the rows that reach a tower's output (towers.hip, last block)
 __global__ __launch_bounds__(256) void gather_rows_kernel(const char *__restrict__ src, char *__restrict__ dst, int n, int row_bytes,
                                                           const int *__restrict__ row_index, int row_mul) {
@@ -156,6 +211,26 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict_
   for (int c = lane; c < d; c += 64) s += xr[c] * xr[c];
   const float nrm = sqrtf(wave_sum(s));
   for (int c = lane; c < d; c += 64) out[(size_t)r * d + c] = xr[c] / nrm;   // x / x.norm(): division, as the reference
+}
+
+// The last launch of a wrapper's forward: both embedding sets normalised in ONE launch (rows 0 .. nx - 1 from x, the rest from y), and the
+// non-finite watchdog with it -- a NaN / inf anywhere in a row makes its squared norm non-finite: flag |= 1 (x) / 2 (y).  Per row the
+// arithmetic of normalize_kernel.
+__global__ __launch_bounds__(256) void normalize2_kernel(const float *__restrict__ x, float *__restrict__ outx, int nx, const float *__restrict__ y,
+                                                         float *__restrict__ outy, int ny, int d, int *flag) {
+  const int lane = threadIdx.x & 63;
+  int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= nx + ny) return;
+  const bool second = r >= nx;
+  if (second) r -= nx;
+  const float *xr = (second ? y : x) + (size_t)r * d;
+  float *o = (second ? outy : outx) + (size_t)r * d;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) s += xr[c] * xr[c];
+  s = wave_sum(s);
+  const float nrm = sqrtf(s);
+  for (int c = lane; c < d; c += 64) o[c] = xr[c] / nrm;   // x / x.norm(): division, as the reference
+  if (flag && lane == 0 && (__float_as_uint(s) & 0x7F800000u) == 0x7F800000u) atomicOr(flag, second ? 2 : 1);
 }
 
 __global__ __launch_bounds__(256) void mean_groups_kernel(const float *__restrict__ x, float *__restrict__ out, int n_groups,
@@ -229,6 +304,18 @@ int launch_fold_stats(const float *part, int nb, int rows, float *stat, hipStrea
   return 0;
 }
 
+int launch_splitk_resid_rows(const float *part, int nsl, int stride, const float *bias, void *hi, void *lo, float *stat, int rows, int width, int dtype,
+                             hipStream_t stream, const int *rows_dev) {
+  VTC_CHECK(width % 256 == 0 && width <= 1024 && nsl >= 2 && (dtype == VTC_BF16 || dtype == VTC_F16), "splitk_resid_rows: width=%d slices=%d dtype=%d", width, nsl, dtype);
+  ProfScope prof(VTC_PROF_NORM, (double)rows * width * (4.0 * nsl + 8.0), stream);
+  if (dtype == VTC_F16)
+    hipLaunchKernelGGL((splitk_resid_rows_kernel<f16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, part, nsl, stride, bias, (f16_t *)hi, (f16_t *)lo, (float2 *)stat, rows, width, rows_dev);
+  else
+    hipLaunchKernelGGL((splitk_resid_rows_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, part, nsl, stride, bias, (bf16_t *)hi, (bf16_t *)lo, (float2 *)stat, rows, width, rows_dev);
+  VTC_LAUNCH_CHECK("splitk_resid_rows");
+  return 0;
+}
+
 int launch_cast_rowstats(const float *x, void *y16, void *y16lo, float *stat, int rows, int width, int dtype, hipStream_t stream,
                          const int *rows_dev) {
   VTC_CHECK(width % 8 == 0 && width <= 512 * LN_MAXV && (dtype == VTC_BF16 || dtype == VTC_F16), "cast_rowstats: width=%d dtype=%d", width, dtype);
@@ -270,6 +357,13 @@ extern "C" int vtc_normalize_rows(const float *x, float *out, int n, int d, void
   VTC_CHECK(n > 0 && d > 0, "normalize_rows: n=%d d=%d", n, d);
   hipLaunchKernelGGL(normalize_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, x, out, n, d);
   VTC_LAUNCH_CHECK("normalize_rows");
+  return 0;
+}
+
+extern "C" int vtc_normalize_rows2(const float *x, float *outx, int nx, const float *y, float *outy, int ny, int d, int *flag, void *stream) {
+  VTC_CHECK(x && outx && y && outy && nx > 0 && ny > 0 && d > 0, "normalize_rows2: bad arguments (nx=%d ny=%d d=%d)", nx, ny, d);
+  hipLaunchKernelGGL(normalize2_kernel, dim3(cdiv(nx + ny, 4)), dim3(256), 0, (hipStream_t)stream, x, outx, nx, y, outy, ny, d, flag);
+  VTC_LAUNCH_CHECK("normalize_rows2");
   return 0;
 }
 

@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include "common.h"
+namespace vtcgemm { int num_cus(); }
 
 static thread_local char g_err[512] = "";
 void vtc_set_error(const char *fmt, ...) {
@@ -98,7 +99,21 @@ struct Fold {
   float *stat = nullptr;    // [rows_pad] (mean, rstd)
   int rows_pad = 0;
   int fmt = -1;             // operand format (xb, xl) / stat currently hold (-1: the stream is the fp32 x)
+  float *splitk = nullptr;  // [SPLITK_MAX][rows_pad, W] fp32 partial products of a split-K c_proj (rows_pad <= SPLITK_MAX_ROWS; else NULL)
 };
+// Split-K for the MLP's c_proj at batch 1 - 2: its 64 x 64 tiles are few (video, B = 1: 8 x 12 = 96) and each walks
+// K = 3072 alone -- 24 us of a 109 us layer.  Cut into K slices it is one round of ~4x the workgroups, and the pass that sums the slices
+// also applies the residual update and writes the row statistics whole: c_proj + fold_stats (24 + 5 us) become split GEMM + row pass.
+constexpr int SPLITK_MAX = 4, SPLITK_MAX_ROWS = 1024;
+// slices for a [rows_pad, W] x K residual GEMM: the largest S <= SPLITK_MAX with K % (64 S) == 0, at least four K-steps per slice, and
+// every (tile, slice) resident at once (two 64 x 64 workgroups per CU); 1 = no split
+inline int splitk_slices(int rows_pad, int W, int K) {
+  if (rows_pad > SPLITK_MAX_ROWS || K < 2048 || W % 256 != 0 || W > 1024) return 1;
+  const long tiles = (long)(rows_pad / 64) * (W / 64);
+  for (int s = SPLITK_MAX; s >= 2; --s)
+    if (K % (64 * s) == 0 && K / s >= 256 && tiles * s <= 2L * vtcgemm::num_cus()) return s;
+  return 1;
+}
 // the fp32 rows a final LayerNorm reads (rows i * row_mul, or row_index[i]) out of the pair
 int fold_merge_rows(Fold &f, float *x, int n, int W, const int *row_index, int row_mul, hipStream_t s) {
   if (!f.on || f.fmt < 0) return 0;
@@ -166,7 +181,7 @@ int ln_proj(Fold &f, const float *x, const float *g, const float *bt, const void
 // center: this update also subtracts the rows' previous means (the stream stays centred; once per layer is enough -- a single
 // update moves a row's mean by a fraction of its spread)
 int resid_proj(Fold &f, const void *A, const void *w, const float *bias, float *x, const Rows &rows, int W, int K, int dtype, int skip_mod,
-               hipStream_t s, bool center = false) {
+               hipStream_t s, bool center = false, int flags = 0) {
   if (f.on) {
     GemmEpi e;
     e.mode = VTC_EPI_RESID; e.out_dtype = VTC_F32; e.skip_mod = skip_mod; e.y16 = f.xb; e.y16lo = f.xl; e.fold_part = f.part;
@@ -177,6 +192,13 @@ int resid_proj(Fold &f, const void *A, const void *w, const float *bias, float *
       RUN(launch_cast_rowstats(x, f.xb, f.xl, f.stat, rows.n, W, dtype, s, rows.dev));
       f.fmt = dtype;
     }
+    const int nsl = (center && skip_mod == 0 && f.splitk && !(flags & VTC_TOWER_NO_SPLITK)) ? splitk_slices(f.rows_pad, W, K) : 1;
+    if (nsl > 1) {
+      GemmEpi ek;
+      ek.mode = VTC_EPI_STORE; ek.out_dtype = VTC_F32; ek.m_dev = rows.dev_pad(); ek.ksplit = nsl; ek.split_stride = f.rows_pad * W;
+      RUN(launch_gemm(A, w, nullptr, f.splitk, f.rows_pad, W, K, dtype, ek, s));
+      return launch_splitk_resid_rows(f.splitk, nsl, f.rows_pad * W, bias, f.xb, f.xl, f.stat, f.rows_pad, W, dtype, s, rows.dev_pad());
+    }
     RUN(launch_gemm(A, w, bias, x, f.rows_pad, W, K, dtype, e, s));
     return launch_fold_stats(f.part, W / 64, f.rows_pad, f.stat, s, rows.dev_pad());
   }
@@ -186,10 +208,10 @@ int resid_proj(Fold &f, const void *A, const void *w, const float *bias, float *
 }
 
 // x += MLP(ln_2 x)   (timesformer_clip_alt.py:174 / upstream block)
-int mlp_part(Fold &f, const vtc_block_w &b, float *x, void *h, void *big, const Rows &rows, int W, int dtype, hipStream_t s) {
+int mlp_part(Fold &f, const vtc_block_w &b, float *x, void *h, void *big, const Rows &rows, int W, int dtype, hipStream_t s, int flags = 0) {
   ProfRegion region(VTC_PROF_REGION_MLP);
   RUN(ln_proj(f, x, b.ln2_g, b.ln2_b, b.fc_w, b.fc_b, b.fc_wf, b.fc_s, b.fc_c, h, big, rows, 4 * W, W, dtype, VTC_EPI_GELU, s));
-  RUN(resid_proj(f, big, b.proj_w, b.proj_b, x, rows, W, 4 * W, dtype, 0, s, true));
+  RUN(resid_proj(f, big, b.proj_w, b.proj_b, x, rows, W, 4 * W, dtype, 0, s, true, flags));
   return 0;
 }
 
@@ -302,6 +324,7 @@ VisionWs plan_vision(const vtc_vision_w *w, int n_items, int F, int dtype, void 
     v.fold.xl = b.take(rows * W * 2);
     v.fold.part = (float *)b.take((size_t)(W / 64 + 1) * rows * 8);
     v.fold.stat = (float *)b.take(rows * 8);
+    if (rows <= (size_t)SPLITK_MAX_ROWS) v.fold.splitk = (float *)b.take((size_t)SPLITK_MAX * rows * W * 4);
   }
   plan_tail(b, v.tail, n_items, W);
   v.total = b.off;
@@ -336,6 +359,7 @@ TextWs plan_text(int rows_, int n_seq, int W, int dtype, void *ws) {
     t.fold.xl = b.take(rows * W * 2);
     t.fold.part = (float *)b.take((size_t)(W / 64 + 1) * rows * 8);
     t.fold.stat = (float *)b.take(rows * 8);
+    if (rows <= (size_t)SPLITK_MAX_ROWS) t.fold.splitk = (float *)b.take((size_t)SPLITK_MAX * rows * W * 4);
   }
   plan_tail(b, t.tail, n_seq, W);
   t.total = b.off;
@@ -454,7 +478,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
     }
     if (tail && tail_q && w->variant == 0) RUN(tail_finish(b, v.tail, n_items, W, dtype, s));
     else if (tail) RUN(last_block_tail(fold, b, v.x, tail_src, v.tail, n_items, W, nullptr, T, dtype, s));
-    else RUN(mlp_part(fold, b, v.x, v.h, v.big, rows, W, dtype, s));
+    else RUN(mlp_part(fold, b, v.x, v.h, v.big, rows, W, dtype, s, w->flags));
   }
   // ln_post(x[:,0]) @ proj -- always fp32 (n_items rows only): the embedding the sweep ranks on
   // does not pick up a last bf16 rounding
@@ -525,7 +549,7 @@ int text_forward_impl(const vtc_text_w *w, const TextIds &ids, int mode, const i
     }
     if (tail && tail_q) RUN(tail_finish(b, t.tail, n_seq, W, dl, s));
     else if (tail) RUN(last_block_tail(fold, b, t.x, tail_src, t.tail, n_seq, W, t.eot, 1, dl, s));
-    else RUN(mlp_part(fold, b, t.x, t.h, t.big, rows, W, dl, s));
+    else RUN(mlp_part(fold, b, t.x, t.h, t.big, rows, W, dl, s, w->flags));
   }
   // ln_final on the EOT row only (LayerNorm is per-row, so gathering first is identical), then @ text_projection
   // (always fp32, as for the vision tower)

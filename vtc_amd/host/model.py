@@ -157,13 +157,16 @@ class PretrainedCLIPBase(nn.Module):
     overlap_towers = __import__("os").environ.get("VTC_OVERLAP", "1") != "0"
     _video_tower = False      # True: model.visual takes [B,F,3,H,W] (TimeSformer wrappers)
 
-    def _encode_both(self, vis, title, texts_b=None):
+    def _encode_both(self, vis, title, texts_b=None, text_tail=None):
         """(visual features, text features); the two towers are independent until the CAM / similarity.  texts_b: a second
-        id array encoded in the same text-tower call (rows after the titles')."""
+        id array encoded in the same text-tower call (rows after the titles').  text_tail(ft, overlapped) -> ft': what follows the
+        text tower and does not need the visual features (the CAM on the text branch) -- enqueued on the caller's stream BEFORE the
+        join, so that it runs under the visual tower, which is the longer chain (round 6)."""
         pk = self._pack()        # ONE signature walk per forward; the towers below use the packed structs directly
         enc = pk["visual"].forward if self._video_tower else (lambda v: self._encode_vis(v, pk))
         if not self.overlap_towers or len(vis.shape) == 2:
-            return enc(vis), pk["text"].forward(title, ids_b=texts_b)
+            ft = pk["text"].forward(title, ids_b=texts_b)
+            return enc(vis), (text_tail(ft, False) if text_tail is not None else ft)
         # The weights were packed (converted / transposed / fused) above, on the CALLER's stream, before the fork: the side stream inherits
         # the dependency through wait_stream, and the packed tensors belong to the caller stream's allocator pool.
         # (Packed lazily inside the fork, the conversions would be enqueued on the side stream only, and the text
@@ -178,6 +181,8 @@ class PretrainedCLIPBase(nn.Module):
             with torch.cuda.stream(side):
                 fv = enc(vis)
             ft = pk["text"].forward(title, ids_b=texts_b)
+            if text_tail is not None:
+                ft = text_tail(ft, True)
             cur.wait_stream(side)
             fv.record_stream(cur)
         return fv, ft
@@ -190,6 +195,20 @@ class PretrainedCLIPBase(nn.Module):
     # check_finite(), which synchronises; both raise with the cause.  RecallAtK and the eval entry points check their inputs too.
     #: False switches the per-forward launch off (the checks of RecallAtK / eval.py remain)
     nonfinite_watchdog = True
+
+    def _finish(self, fv, ft):
+        """The two `normalize` calls that end every forward (model/model.py:263-264, 366-367) and the watchdog, in ONE launch."""
+        if not (self.nonfinite_watchdog and fv.is_cuda and ft.is_cuda and fv.dim() == 2 and ft.dim() == 2 and fv.shape[1] == ft.shape[1]):
+            fv, ft = normalize(fv), normalize(ft)
+            self._watch(fv, ft)
+            return fv, ft
+        st = self.__dict__.get("_nf")
+        if st is None or st[0].device != fv.device:
+            st = self.__dict__["_nf"] = (torch.zeros(1, dtype=torch.int32, device=fv.device), torch.zeros(1, dtype=torch.int32).pin_memory())
+        fv, ft = ops.normalize_rows2(fv, ft, st[0])
+        with torch.cuda.device(fv.device):
+            st[1].copy_(st[0], non_blocking=True)
+        return fv, ft
 
     def _watch(self, fv, ft):
         if not self.nonfinite_watchdog or not (fv.is_cuda and ft.is_cuda) or fv.dtype != torch.float32 or ft.dtype != torch.float32:
@@ -249,6 +268,29 @@ class PretrainedCLIPBase(nn.Module):
             f = tower.forward(vis.reshape(shp[0] * shp[1], shp[2], shp[3], shp[4]))
             return ops.mean_groups(f, shp[1])
         raise ValueError(f"unsupported visual input shape {tuple(shp)}")
+
+    def _forward_with_cam(self, vis, title, comments):
+        """forward() of the two *_finaltf wrappers up to the normalised pair: model/model.py:458-478 / :596-621 = towers (:464-472) +
+        _encode_with_comments (:216-266, eval path).  Same arithmetic as _encode_all + _encode_with_comments below; what differs is the
+        ORDER OF ENQUEUEING: with the text branch adapted, the CAM needs the title and comment features only, so it is enqueued behind
+        the text tower on the caller's stream while the visual tower still runs on the side stream (multi-launch form: see
+        PackedCam.forward) -- at small batch the CAM's ~0.2 ms left the critical path."""
+        branch = self.branch_to_adapt_val
+        if branch not in ("text", "image", "skip"):
+            raise Exception("Unknown branch_to_adapt")
+        if branch == "skip" or comments is None:
+            fv, ft = self._encode_both(vis, title)
+        else:
+            b, ncomms, ntoks = comments.shape
+            ids_c = comments.reshape(b * ncomms, ntoks)
+            if branch == "text":
+                def tail(ft_all, overlapped):
+                    return self._packed["cam"].forward(ft_all[:b], ft_all[b:], comments, fused=False if overlapped else None)
+                fv, ft = self._encode_both(vis, title, ids_c, text_tail=tail)
+            else:
+                fv, ft_all = self._encode_both(vis, title, ids_c)
+                fv, ft = self._packed["cam"].forward(fv, ft_all[b:], comments), ft_all[:b]
+        return self._finish(fv, ft)
 
     def _encode_all(self, vis, title, comments):
         """Both towers for the *_finaltf wrappers.  The reference encodes the titles (model/model.py:472) and the
@@ -351,8 +393,7 @@ class PretrainedCLIP(PretrainedCLIPBase):
             # embedding and its comments' (model/model.py:357-362)
             feats_vis, ft_all = self._encode_both(vis, title, comments.reshape(b * ncomms, ntoks))
             feats_text = ops.mean_head_groups(ft_all[:b], ft_all[b:], ncomms)
-        feats_text, feats_vis = normalize(feats_text), normalize(feats_vis)
-        self._watch(feats_vis, feats_text)
+        feats_vis, feats_text = self._finish(feats_vis, feats_text)
         return feats_vis, feats_text, self._sim(feats_vis, feats_text)
 
 
@@ -376,9 +417,7 @@ class PretrainedCLIP_finaltf(PretrainedCLIPBase):
 
     def forward(self, vis, title, comments):
         self._check_mode(vis, title, comments)
-        feats_vis, feats_title, feats_comm = self._encode_all(vis, title, comments)
-        feats_vis, feats_text = self._encode_with_comments(feats_vis, feats_title, comments, feats_comm)
-        self._watch(feats_vis, feats_text)
+        feats_vis, feats_text = self._forward_with_cam(vis, title, comments)
         return feats_vis, feats_text, self._sim(feats_vis, feats_text)
 
 
@@ -397,8 +436,7 @@ class PretrainedCLIP_TimeSformer(PretrainedCLIPBase):
     def forward(self, im, text, comments=None):
         self._check_mode(im, text)
         feats_im, feats_text = self._encode_both(im, text)       # model.visual(im), model/model.py:497
-        feats_im, feats_text = normalize(feats_im), normalize(feats_text)
-        self._watch(feats_im, feats_text)
+        feats_im, feats_text = self._finish(feats_im, feats_text)
         return feats_im, feats_text, self._sim(feats_im, feats_text)
 
 
@@ -425,7 +463,5 @@ class PretrainedCLIP_TimeSformer_finaltf(PretrainedCLIPBase):
 
     def forward(self, vis, title, comments):
         self._check_mode(vis, title, comments)
-        feats_vis, feats_title, feats_comm = self._encode_all(vis, title, comments)
-        feats_vis, feats_text = self._encode_with_comments(feats_vis, feats_title, comments, feats_comm)
-        self._watch(feats_vis, feats_text)
+        feats_vis, feats_text = self._forward_with_cam(vis, title, comments)
         return feats_vis, feats_text, self._sim(feats_vis, feats_text)

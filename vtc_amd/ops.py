@@ -206,6 +206,17 @@ def segment_mean(x: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@on_device
+def normalize_rows2(x: torch.Tensor, y: torch.Tensor, flag: Optional[torch.Tensor] = None):
+    """(x / |x|, y / |y|) row-wise in ONE launch; flag (int32, device) |= 1 / 2 when x / y hold a NaN or inf."""
+    x, y = _gpu(x, torch.float32, "x"), _gpu(y, torch.float32, "y")
+    assert x.dim() == 2 and y.dim() == 2 and x.shape[1] == y.shape[1]
+    ox, oy = torch.empty_like(x), torch.empty_like(y)
+    L.check(L.lib().vtc_normalize_rows2(x.data_ptr(), ox.data_ptr(), x.shape[0], y.data_ptr(), oy.data_ptr(), y.shape[0], x.shape[1],
+                                        flag.data_ptr() if flag is not None else None, _stream()), "vtc_normalize_rows2")
+    return ox, oy
+
+
 def nonfinite_flag2(a: torch.Tensor, b: torch.Tensor, flag: torch.Tensor) -> torch.Tensor:
     """flag[0] |= 1 when ``a`` holds a NaN / inf, |= 2 when ``b`` does (one launch, no synchronisation).  flag: int32 (or the low word of
     an int64) in device memory."""

@@ -42,16 +42,18 @@ TEXT_HALF_LAYERS = int(__import__("os").environ.get("VTC_TEXT_HALF_LAYERS", "12"
 LN_FOLD_PACK = __import__("os").environ.get("VTC_LN_FOLD_PACK", "1") != "0"
 
 
-def tower_flags(ln_fold: bool = True, full_last_layer: bool = False) -> int:
+def tower_flags(ln_fold: bool = True, full_last_layer: bool = False, splitk: bool = True) -> int:
     """vtc_vision_w.flags / vtc_text_w.flags: ln_fold False = the LayerNorm kernels instead of the folded LayerNorms;
     full_last_layer = compute the last block's out_proj / MLP on every row instead of the output rows only (the rows nothing
-    reads; same embeddings).  (The fused QKV + attention flags of rounds 1-4 are gone with the kernel: ABI 6.)"""
-    return (0 if ln_fold else L.TOWER_NO_LN_FOLD) | (L.TOWER_FULL_LAST_LAYER if full_last_layer else 0)
+    reads; same embeddings); splitk False = the MLP's c_proj as one GEMM also at batch 1 - 2 (ABI 7; default: split over K there).
+    (The fused QKV + attention flags of rounds 1-4 are gone with the kernel: ABI 6.)"""
+    return (0 if ln_fold else L.TOWER_NO_LN_FOLD) | (L.TOWER_FULL_LAST_LAYER if full_last_layer else 0) | (0 if splitk else L.TOWER_NO_SPLITK)
 
 
 # defaults of newly packed towers (env VTC_LN_FOLD=0 / VTC_FULL_LAST_LAYER=1: A/B runs); a packed tower's `w.flags` may be set per model
 DEFAULT_FLAGS = tower_flags(__import__("os").environ.get("VTC_LN_FOLD", "1") != "0",
-                            __import__("os").environ.get("VTC_FULL_LAST_LAYER", "0") == "1")
+                            __import__("os").environ.get("VTC_FULL_LAST_LAYER", "0") == "1",
+                            __import__("os").environ.get("VTC_SPLITK", "1") != "0")
 _WS: Dict[tuple, torch.Tensor] = {}
 
 
@@ -406,11 +408,20 @@ class PackedCam:
         self.w = w
 
     @ops.on_device
-    def forward(self, main: torch.Tensor, comm_feats: torch.Tensor, comments: torch.Tensor) -> torch.Tensor:
-        """main [B,D], comm_feats [B*nc,D] fp32, comments [B,nc,ctx] int64 -> adapted [B,D]."""
+    def forward(self, main: torch.Tensor, comm_feats: torch.Tensor, comments: torch.Tensor, fused: Optional[bool] = None) -> torch.Tensor:
+        """main [B,D], comm_feats [B*nc,D] fp32, comments [B,nc,ctx] int64 -> adapted [B,D].
+        fused=False: the multi-launch path for THIS call (the caller has another tower's kernels in flight on a second stream: the
+        one-launch form's grid barrier needs every CU to itself and would serialise with them -- or give up; the small launches of the
+        multi-launch form interleave)."""
         w = self.w
         if _CAM_SHARED_CARD:
             w.flags |= L.CAM_NO_FUSED
+        if fused is False and not (w.flags & L.CAM_NO_FUSED):
+            w.flags |= L.CAM_NO_FUSED
+            try:
+                return self.forward(main, comm_feats, comments)
+            finally:
+                w.flags &= ~L.CAM_NO_FUSED
         main, comm_feats = ops._gpu(main, torch.float32, "main"), ops._gpu(comm_feats, torch.float32, "comm_feats")
         comments = ops._gpu(comments, torch.int64, "comments")
         B, nc, ctx = comments.shape

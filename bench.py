@@ -387,6 +387,27 @@ def secondary_points(m3, vid, title, comments, B, world, device, extra, k2):
     finally:
         TW.DEFAULT_FLAGS = was_flags
         m3._packed = {}
+    # IEEE-half operands in BOTH towers (round 6: compute_dtype = torch.float16; the bf16 mode already runs the text blocks on half): same
+    # MFMA rate and bytes, 11 significant bits instead of 8 -- the accuracy-side alternative to the headline's bf16 video tower
+    log("extras: IEEE-half operands in both towers (--dtype f16)")
+    was_dt = m3.compute_dtype
+    try:
+        m3.compute_dtype = torch.float16
+        vh = vid.to(torch.float16)
+        o_h = m3(vh, title, comments)
+        d = timed(lambda: m3(vh, title, comments), k2, world, device, warm=1)
+        m3.compute_dtype = was_dt
+        o_b = m3(vid, title, comments)
+        extra[f"config3_B{B}_f16_pairs_per_s"] = round(world * B / d, 1)
+        extra[f"config3_B{B}_f16"] = {"pairs_per_s": round(world * B / d, 1), "ms_per_step": round(1e3 * d, 3),
+                                      "max_abs_diff_vs_bf16_mode": {"feats_vis": round(float((o_h[0] - o_b[0]).abs().max()), 6),
+                                                                    "feats_text": round(float((o_h[1] - o_b[1]).abs().max()), 6)},
+                                      "what": "PretrainedCLIP_TimeSformer_finaltf with compute_dtype = torch.float16: IEEE-half GEMM / attention operands and (hi, lo) "
+                                              "residual stream in the video tower too (tests: 5 - 8x closer to the fp32 oracle than the bf16 mode)"}
+        del vh, o_h, o_b
+    finally:
+        m3.compute_dtype = was_dt
+        m3._packed = {}
     # ... and BOTH at once: dense text + every row of the last block = exactly the reference's arithmetic work, in 16-bit
     log("extras: all the reference's work (dense text + full last block)")
     try:

@@ -727,10 +727,13 @@ int launch_mean_cast(const float *x, void *out, int n, int F, int W, int dtype, 
 
 int launch_cls_global_attention(const void *qkv, void *out, int n_items, int Ttok, int heads, int dtype, hipStream_t stream) {
   VTC_CHECK(Ttok <= 1024, "cls attention: %d tokens > 1024", Ttok);
-  VTC_CHECK(dtype == VTC_BF16 || dtype == VTC_F32, "cls attention: dtype %d (the vision towers run bf16 or fp32)", dtype);
+  VTC_CHECK(dtype == VTC_BF16 || dtype == VTC_F32 || dtype == VTC_F16, "cls attention: dtype %d", dtype);
   const int total = n_items * heads;
   ProfScope prof(VTC_PROF_ATTN, 4.0 * Ttok * 64 * (double)total, stream);
-  if (dtype == VTC_BF16)
+  if (dtype == VTC_F16)
+    hipLaunchKernelGGL((cls_global_attn_kernel<f16_t>), dim3(cdiv(total, 4)), dim3(256), 4 * 1024 * sizeof(float), stream,
+                       (const f16_t *)qkv, (f16_t *)out, n_items, Ttok, heads);
+  else if (dtype == VTC_BF16)
     hipLaunchKernelGGL((cls_global_attn_kernel<bf16_t>), dim3(cdiv(total, 4)), dim3(256), 4 * 1024 * sizeof(float), stream,
                        (const bf16_t *)qkv, (bf16_t *)out, n_items, Ttok, heads);
   else

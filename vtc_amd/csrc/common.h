@@ -251,6 +251,8 @@ bool gemm_patch_gather_supported(int n_frames, int grid, int patch, int res, int
 int launch_layernorm(const float *x, const float *g, const float *b, void *y, int rows, int width, int out_dtype,
                      const int *row_index, int row_mul, bool no_norm, hipStream_t stream, const int *rows_dev = nullptr);
 int launch_fold_stats(const float *part, int nb, int rows, float *stat, hipStream_t stream, const int *rows_dev = nullptr);
+int launch_ln_cast_rowstats(const float *x, const float *gamma, const float *beta, void *y16, void *y16lo, float *stat, int rows, int width, int dtype,
+                            hipStream_t stream);
 int launch_splitk_resid_rows(const float *part, int nsl, int stride, const float *bias, void *hi, void *lo, float *stat, int rows, int width, int dtype,
                              hipStream_t stream, const int *rows_dev = nullptr);
 int launch_cast_rowstats(const float *x, void *y16, void *y16lo, float *stat, int rows, int width, int dtype, hipStream_t stream,

@@ -374,11 +374,14 @@ int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_f
     const size_t total = (size_t)n_frames * grid * grid * kpad;
     const dim3 g((unsigned)((total + 255) / 256)), b(256);
     ProfScope prof(VTC_PROF_EMBED, (double)total * ((pixel_dtype == VTC_U8 ? 1 : pixel_dtype == VTC_BF16 ? 2 : 4) + (dtype == VTC_F32 ? 4 : 2)), stream);
-    VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "im2row: output dtype %d", dtype);
+    VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16 || dtype == VTC_F16, "im2row: output dtype %d", dtype);
 #define VTC_IM2ROW_G(PT, OT) hipLaunchKernelGGL((im2row_generic_kernel<PT, OT>), g, b, 0, stream, (const PT *)px, (OT *)out, n_frames, grid, patch, res, kpad, nrm)
-    if (pixel_dtype == VTC_U8) { if (dtype == VTC_BF16) VTC_IM2ROW_G(unsigned char, bf16_t); else VTC_IM2ROW_G(unsigned char, float); }
-    else if (pixel_dtype == VTC_F32) { if (dtype == VTC_BF16) VTC_IM2ROW_G(float, bf16_t); else VTC_IM2ROW_G(float, float); }
-    else { if (dtype == VTC_BF16) VTC_IM2ROW_G(bf16_t, bf16_t); else VTC_IM2ROW_G(bf16_t, float); }
+#define VTC_IM2ROW_GO(PT) do { if (dtype == VTC_BF16) VTC_IM2ROW_G(PT, bf16_t); else if (dtype == VTC_F16) VTC_IM2ROW_G(PT, f16_t); else VTC_IM2ROW_G(PT, float); } while (0)
+    if (pixel_dtype == VTC_U8) VTC_IM2ROW_GO(unsigned char);
+    else if (pixel_dtype == VTC_F32) VTC_IM2ROW_GO(float);
+    else if (pixel_dtype == VTC_F16) VTC_IM2ROW_GO(f16_t);
+    else VTC_IM2ROW_GO(bf16_t);
+#undef VTC_IM2ROW_GO
 #undef VTC_IM2ROW_G
     VTC_LAUNCH_CHECK("im2row_generic");
     return 0;
@@ -394,6 +397,9 @@ int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_f
     if (dtype == VTC_BF16)
       hipLaunchKernelGGL((im2row_u8_kernel<bf16_t>), dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, stream,
                          (const unsigned char *)px, (bf16_t *)out, n_frames, grid, patch, res, nrm);
+    else if (dtype == VTC_F16)
+      hipLaunchKernelGGL((im2row_u8_kernel<f16_t>), dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, stream,
+                         (const unsigned char *)px, (f16_t *)out, n_frames, grid, patch, res, nrm);
     else
       hipLaunchKernelGGL((im2row_u8_kernel<float>), dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, stream,
                          (const unsigned char *)px, (float *)out, n_frames, grid, patch, res, nrm);
@@ -403,6 +409,16 @@ int launch_im2row(const void *px, int pixel_dtype, void *out, int dtype, int n_f
   const size_t total = (size_t)n_frames * grid * grid * (3 * patch * patch / 4);
   const dim3 g((unsigned)((total + 255) / 256)), b(256);
   ProfScope prof(VTC_PROF_EMBED, (double)total * 4 * ((pixel_dtype == VTC_BF16 ? 2 : 4) + (dtype == VTC_BF16 ? 2 : 4)), stream);
+#define VTC_IM2ROW(PT, OT) hipLaunchKernelGGL((im2row_kernel<PT, OT>), g, b, 0, stream, (const PT *)px, (OT *)out, n_frames, grid, patch, res)
+  if (dtype == VTC_F16) {        // IEEE-half operand mode of the vision towers (round 6)
+    if (pixel_dtype == VTC_F32) VTC_IM2ROW(float, f16_t);
+    else if (pixel_dtype == VTC_F16) VTC_IM2ROW(f16_t, f16_t);
+    else VTC_IM2ROW(bf16_t, f16_t);
+  } else if (pixel_dtype == VTC_F16) {
+    if (dtype == VTC_BF16) VTC_IM2ROW(f16_t, bf16_t);
+    else VTC_IM2ROW(f16_t, float);
+  } else
+#undef VTC_IM2ROW
   if (pixel_dtype == VTC_F32 && dtype == VTC_BF16)
     hipLaunchKernelGGL((im2row_kernel<float, bf16_t>), g, b, 0, stream, (const float *)px, (bf16_t *)out, n_frames, grid, patch, res);
   else if (pixel_dtype == VTC_F32)
@@ -441,9 +457,10 @@ int launch_cls_rows(float *x, const float *cls, const float *pos0, int n_items, 
 }
 
 int launch_cls_mean(const float *cls_tmp, void *out, int dtype, int n_items, int F, int T, int W, hipStream_t stream) {
-  VTC_CHECK(dtype == VTC_BF16 || dtype == VTC_F32, "cls_mean: dtype %d (the vision towers run bf16 or fp32)", dtype);
+  VTC_CHECK(dtype == VTC_BF16 || dtype == VTC_F32 || dtype == VTC_F16, "cls_mean: dtype %d", dtype);
   const dim3 g(cdiv(n_items * W, 256)), b(256);
   if (dtype == VTC_BF16) hipLaunchKernelGGL((cls_mean_kernel<bf16_t>), g, b, 0, stream, cls_tmp, (bf16_t *)out, n_items, F, T, W);
+  else if (dtype == VTC_F16) hipLaunchKernelGGL((cls_mean_kernel<f16_t>), g, b, 0, stream, cls_tmp, (f16_t *)out, n_items, F, T, W);
   else hipLaunchKernelGGL((cls_mean_kernel<float>), g, b, 0, stream, cls_tmp, (float *)out, n_items, F, T, W);
   VTC_LAUNCH_CHECK("cls_mean");
   return 0;

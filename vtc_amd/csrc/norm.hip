@@ -112,6 +112,85 @@ __global__ __launch_bounds__(256) void cast_rowstats_kernel(const float *__restr
   if (lane == 0) stat[r] = make_float2(0.0f, rstd);       // the mean of the stored (centred) row
 }
 
+// ln_pre + the entry into the folded scheme in ONE pass over the rows (round 6): z = LayerNorm(x; gamma, beta) -- the arithmetic of
+// ln_row.h -- and then what cast_rowstats_kernel does with z (centred (hi, lo) pair + rstd), without the fp32 z ever reaching HBM:
+// at 1 024 videos the two launches moved 2 x 2.5 GB, this one reads 1.24 GB and writes 1.24 GB.
+template <typename OutT>
+__global__ __launch_bounds__(256) void ln_cast_rowstats_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                               OutT *__restrict__ y, OutT *__restrict__ ylo, float2 *__restrict__ stat, int rows, int width) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float *xr = x + (size_t)r * width;
+  float4 v[LN_MAXV][2];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < width) {
+      v[i][0] = *reinterpret_cast<const float4 *>(xr + c);
+      v[i][1] = *reinterpret_cast<const float4 *>(xr + c + 4);
+      s += ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
+    }
+  }
+  const float mean = wave_sum(s) / width;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    if ((lane + 64 * i) * 8 < width) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float a = v[i][h].x - mean, b = v[i][h].y - mean, cc = v[i][h].z - mean, d = v[i][h].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / width + 1e-5f);
+  // z = LayerNorm(x) in place of v, and its row sum
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < width) {
+      const float4 g0 = *reinterpret_cast<const float4 *>(gamma + c), g1 = *reinterpret_cast<const float4 *>(gamma + c + 4);
+      const float4 b0 = *reinterpret_cast<const float4 *>(beta + c), b1 = *reinterpret_cast<const float4 *>(beta + c + 4);
+      v[i][0] = make_float4((v[i][0].x - mean) * rstd * g0.x + b0.x, (v[i][0].y - mean) * rstd * g0.y + b0.y,
+                            (v[i][0].z - mean) * rstd * g0.z + b0.z, (v[i][0].w - mean) * rstd * g0.w + b0.w);
+      v[i][1] = make_float4((v[i][1].x - mean) * rstd * g1.x + b1.x, (v[i][1].y - mean) * rstd * g1.y + b1.y,
+                            (v[i][1].z - mean) * rstd * g1.z + b1.z, (v[i][1].w - mean) * rstd * g1.w + b1.w);
+      s2 += ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
+    }
+  }
+  const float mean2 = wave_sum(s2) / width;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < width) {
+      const float o[8] = {v[i][0].x - mean2, v[i][0].y - mean2, v[i][0].z - mean2, v[i][0].w - mean2,
+                          v[i][1].x - mean2, v[i][1].y - mean2, v[i][1].z - mean2, v[i][1].w - mean2};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q2 += o[e] * o[e];
+      uint4 pk;
+      pk.x = (unsigned)cvt16<OutT>(o[0]) | ((unsigned)cvt16<OutT>(o[1]) << 16);
+      pk.y = (unsigned)cvt16<OutT>(o[2]) | ((unsigned)cvt16<OutT>(o[3]) << 16);
+      pk.z = (unsigned)cvt16<OutT>(o[4]) | ((unsigned)cvt16<OutT>(o[5]) << 16);
+      pk.w = (unsigned)cvt16<OutT>(o[6]) | ((unsigned)cvt16<OutT>(o[7]) << 16);
+      *reinterpret_cast<uint4 *>(y + (size_t)r * width + c) = pk;
+      const unsigned hw[4] = {pk.x, pk.y, pk.z, pk.w};
+      unsigned lw[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float l0 = o[2 * e] - up16<OutT>((unsigned short)(hw[e] & 0xFFFFu)), l1 = o[2 * e + 1] - up16<OutT>((unsigned short)(hw[e] >> 16));
+        lw[e] = (unsigned)cvt16<OutT>(l0) | ((unsigned)cvt16<OutT>(l1) << 16);
+      }
+      *reinterpret_cast<uint4 *>(ylo + (size_t)r * width + c) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+  }
+  const float rstd2 = 1.0f / sqrtf(wave_sum(q2) / width + 1e-5f);
+  if (lane == 0) stat[r] = make_float2(0.0f, rstd2);       // the mean of the stored (centred) row
+}
+
 // x[src] = hi[src] + lo[src] for the rows src = row_index[i] (or i * row_mul): the fp32 rows the final LayerNorm reads
 template <typename T>
 __global__ __launch_bounds__(256) void split_merge_rows_kernel(const T *__restrict__ hi, const T *__restrict__ lo, float *__restrict__ x,
@@ -325,6 +404,18 @@ int launch_cast_rowstats(const float *x, void *y16, void *y16lo, float *stat, in
   else
     hipLaunchKernelGGL((cast_rowstats_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, (bf16_t *)y16, (bf16_t *)y16lo, (float2 *)stat, rows, width, rows_dev);
   VTC_LAUNCH_CHECK("cast_rowstats");
+  return 0;
+}
+
+int launch_ln_cast_rowstats(const float *x, const float *gamma, const float *beta, void *y16, void *y16lo, float *stat, int rows, int width, int dtype,
+                            hipStream_t stream) {
+  VTC_CHECK(width % 8 == 0 && width <= 512 * LN_MAXV && (dtype == VTC_BF16 || dtype == VTC_F16), "ln_cast_rowstats: width=%d dtype=%d", width, dtype);
+  ProfScope prof(VTC_PROF_NORM, (double)rows * width * 8, stream);
+  if (dtype == VTC_F16)
+    hipLaunchKernelGGL((ln_cast_rowstats_kernel<f16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, gamma, beta, (f16_t *)y16, (f16_t *)y16lo, (float2 *)stat, rows, width);
+  else
+    hipLaunchKernelGGL((ln_cast_rowstats_kernel<bf16_t>), dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, gamma, beta, (bf16_t *)y16, (bf16_t *)y16lo, (float2 *)stat, rows, width);
+  VTC_LAUNCH_CHECK("ln_cast_rowstats");
   return 0;
 }
 

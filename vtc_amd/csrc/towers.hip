@@ -377,7 +377,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
                                   void *ws, size_t ws_bytes, int dtype, void *stream_) {
   hipStream_t s = (hipStream_t)stream_;
   VTC_CHECK(w && pixels && out && ws, "vision_forward: null argument");
-  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16, "vision_forward: bad dtype %d", dtype);
+  VTC_CHECK(dtype == VTC_F32 || dtype == VTC_BF16 || dtype == VTC_F16, "vision_forward: bad dtype %d", dtype);
   VTC_CHECK(n_items > 0 && F > 0, "vision_forward: n_items=%d frames=%d", n_items, F);
   const bool tsf = w->nframes > 0;
   VTC_CHECK(tsf || F == 1, "vision_forward: the image tower takes frames == 1 (got %d)", F);
@@ -392,7 +392,7 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
   VTC_CHECK(ws_bytes >= v.total, "vision_forward: workspace too small (%zu < %zu)", ws_bytes, v.total);
 
   // patch embedding (+pos, +temporal) scattered into the reference's token order, cls rows, ln_pre
-  VTC_CHECK(pixel_dtype == VTC_F32 || pixel_dtype == VTC_BF16 || pixel_dtype == VTC_U8, "vision_forward: bad pixel dtype %d", pixel_dtype);
+  VTC_CHECK(pixel_dtype == VTC_F32 || pixel_dtype == VTC_BF16 || pixel_dtype == VTC_U8 || pixel_dtype == VTC_F16, "vision_forward: bad pixel dtype %d", pixel_dtype);
   {
     GemmEpi e;
     e.mode = EPI_PATCH; e.out_dtype = VTC_F32; e.pos = w->pos; e.temporal = tsf ? w->temporal : nullptr;
@@ -417,10 +417,15 @@ extern "C" int vtc_vision_forward(const vtc_vision_w *w, const void *pixels, int
     RUN(launch_gemm(act, w->conv_w, nullptr, v.x, n_items * F * P, W, patch_k_padded(w->patch), dtype, e, s));
   }
   RUN(launch_cls_rows(v.x, w->class_embedding, w->pos, n_items, T, W, s));
-  RUN(launch_layernorm(v.x, w->ln_pre_g, w->ln_pre_b, v.x, rows, W, VTC_F32, nullptr, 1, false, s));
-
   Fold &fold = v.fold;
   fold.on = fold_usable(w->blocks, w->layers, W, dtype, tsf, w->flags);
+  if (fold.on && w->layers > 0) {
+    // ln_pre and the entry into the (hi, lo) stream in one pass (round 6: the LayerNorm kernel + cast_rowstats moved the rows twice)
+    RUN(launch_ln_cast_rowstats(v.x, w->ln_pre_g, w->ln_pre_b, fold.xb, fold.xl, fold.stat, rows, W, dtype, s));
+    fold.fmt = dtype;
+  } else {
+    RUN(launch_layernorm(v.x, w->ln_pre_g, w->ln_pre_b, v.x, rows, W, VTC_F32, nullptr, 1, false, s));
+  }
   const bool prune = prune_last(w->flags);
   const bool tail_q = prune_last_queries(w->flags) && !(tsf && w->variant == 1);   // ... and its queries (not on the v1 tower's global cls attention)
   for (int l = 0; l < w->layers; ++l) {

@@ -155,7 +155,7 @@ def cli(argv=None):
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--n_pairs", type=int, default=None, help="synthetic datasets only: number of pairs")
-    ap.add_argument("--dtype", type=str, default=None, choices=["bf16", "f32"],
+    ap.add_argument("--dtype", type=str, default=None, choices=["bf16", "f16", "f32"],
                     help="operand arithmetic of the towers (default: VTC_COMPUTE_DTYPE, else bf16; the reference is fp32)")
     args = ap.parse_args(argv)
     mods = {"batch_size": args.bs, "arch;args;branch_to_adapt_val": args.bv, "dataset;args;num_comms": args.nc,

@@ -50,7 +50,10 @@ for _reg in ("register_module_parameter_registration_hook", "register_module_buf
     getattr(torch.nn.modules.module, _reg)(_bump_reg_epoch)
 
 _DTYPE_NAMES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "16": torch.bfloat16,
-                "f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "32": torch.float32}
+                "f32": torch.float32, "fp32": torch.float32, "float32": torch.float32, "32": torch.float32,
+                # round 6: IEEE-half operands in BOTH towers (the bf16 mode already runs the text blocks on half): 11 significant bits
+                # instead of 8 at the same MFMA rate and bytes, range +-65504 (the non-finite watchdog says when a checkpoint leaves it)
+                "f16": torch.float16, "fp16": torch.float16, "half": torch.float16, "float16": torch.float16}
 
 
 def parse_compute_dtype(name):
@@ -60,7 +63,7 @@ def parse_compute_dtype(name):
     try:
         return _DTYPE_NAMES[str(name).strip().lower()]
     except KeyError:
-        raise ValueError(f"vtc_amd: unknown compute dtype {name!r}; known: bf16, f32") from None
+        raise ValueError(f"vtc_amd: unknown compute dtype {name!r}; known: bf16, f16, f32") from None
 
 
 def default_compute_dtype():

@@ -213,7 +213,7 @@ class PackedVision:
         if pixels.dim() == 4:
             pixels = pixels.unsqueeze(1)
         pixels = ops._gpu(pixels, name="pixels")
-        if pixels.dtype not in (torch.float32, torch.bfloat16, torch.uint8):
+        if pixels.dtype not in (torch.float32, torch.bfloat16, torch.uint8, torch.float16):
             pixels = pixels.float()
         n, F = pixels.shape[0], pixels.shape[1]
         if tuple(pixels.shape[2:]) != (3, self.res, self.res):

@@ -633,7 +633,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="pairs per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="operand arithmetic: bf16 (BASELINE's; text blocks on IEEE half), f16 (IEEE half in both towers), f32 (the reference's)")
     ap.add_argument("--no-extra", action="store_true", help="skip config 2, the stress encoder and the extra sweep precisions")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-sweep", action="store_true", help="skip the N x N sweeps")
@@ -689,13 +690,13 @@ def main():
         rccl = dict(backend=dist.get_backend(), ranks=dist.get_world_size(), allreduce_check=float(one.item()))
         assert int(one.item()) == world
 
-    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     B = args.batch
     gen = torch.Generator().manual_seed(123 + rank)           # data seed (tests/test_pretrained_clip.py:46)
     torch.manual_seed(1023)                                    # weight seed (train.py:34)
     stream_ptr = torch.cuda.current_stream().cuda_stream
-    gk = "gemm_bf16" if args.dtype == "bf16" else "gemm_f32"
-    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+    gk = "gemm_bf16" if args.dtype != "f32" else "gemm_f32"
+    peak = PEAK_BF16_TFLOPS if args.dtype != "f32" else 157.3
 
     # ---- config 3: 8-frame TimeSformer video + title + 5 comments (CAM) -- the headline ---------------------
     m3 = HM.PretrainedCLIP_TimeSformer_finaltf(model_type="ViT-B/32", branch_to_adapt="text", branch_to_adapt_val="text",
@@ -709,7 +710,7 @@ def main():
     m3 = m3.eval().to(device)
     m3.compute_dtype = cdt
     log(f"config 3: model built, drawing {B} videos")
-    vid = gpu_randn((B, 8, 3, 224, 224), 123 + rank, device, torch.bfloat16 if cdt == torch.bfloat16 else torch.float32)
+    vid = gpu_randn((B, 8, 3, 224, 224), 123 + rank, device, cdt)
     title = synth_tokens(B, 77, gen).to(device)
     comments = synth_tokens(B * 5, 77, gen, empty_frac=0.1).reshape(B, 5, 77).to(device)
 
@@ -763,11 +764,11 @@ def main():
     attn_launches = sum(v["attn"]["launches"] for v in pv.values())
     attn_flop = TSF_ATTN_GFLOP_PER_LAYER_VIDEO * 1e9 * 12 * B
     attn_frac = attn_flop / (attn_ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12) if attn_ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic("config3" if args.dtype == "bf16" else "config3_f32")
+    traffic, traffic_src = pmc_traffic({"bf16": "config3", "f16": "config3_f16", "f32": "config3_f32"}[args.dtype])
     n_tok = int((torch.cat([title, comments.reshape(-1, 77)]).argmax(-1) + 1).sum().item())
     roofline = dict(bound="mfma", achieved=round(achieved, 1), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
                     traffic=traffic, traffic_source=traffic_src,
-                    kernel=("16-bit-operand MFMA GEMMs of the step (gemm_phased_kernel / gemm_kernel), all epilogues" if args.dtype == "bf16"
+                    kernel=("16-bit-operand MFMA GEMMs of the step (gemm_phased_kernel / gemm_kernel), all epilogues" if args.dtype != "f32"
                             else "fp32 MFMA GEMMs of the step (gemm_kernel<float, ...>: v_mfma_f32_16x16x4_f32), all epilogues"),
                     launches_per_step=g["launches"] // n_prof, avg_launch_us=round(1e3 * g["ms"] / max(1, g["launches"]), 2),
                     flop_per_launch=round(g["work"] / max(1, g["launches"]) / 1e9, 3),
@@ -776,7 +777,8 @@ def main():
         "metric": "video-text pairs encoded/sec (config 3: 8-frame TimeSformer video + title + 5 comments, CAM) + 10k x 10k sim+R@K ms",
         "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 (video tower) + f16 (text tower blocks), fp32 accumulate" if args.dtype == "bf16" and TW.TEXT_HALF_LAYERS > 0 else args.dtype,
+        "dtype": ("bf16 (video tower) + f16 (text tower blocks), fp32 accumulate" if args.dtype == "bf16" and TW.TEXT_HALF_LAYERS > 0 else
+                  "f16 (IEEE-half operands in both towers), fp32 accumulate" if args.dtype == "f16" else args.dtype),
         "data": "synthetic",
         "config": {"workload": "configs/pretrained_clip_timesformer_comments_attention.jsonc PretrainedCLIP_TimeSformer_finaltf forward: "
                                f"{B} pairs/GPU/step = {B} videos (8 x 3 x 224 x 224) + {B} titles + {5 * B} comments (77 tokens) + CAM + sim",

@@ -85,7 +85,8 @@ def nonfinite_cause(device) -> str:
         causes.append("a one-launch CAM gave up at a grid barrier (another process or a collective held the card's CUs); the "
                       "multi-launch CAM is selected from now on")
     causes.append("an IEEE-half overflow in the text tower's half-operand blocks (the tower re-packs itself as bf16 at its next forward "
-                  "and warns), or non-finite weights / inputs")
+                  "and warns); with compute_dtype = torch.float16 an overflow of +-65504 in the vision tower (choose bfloat16: wider range); "
+                  "or non-finite weights / inputs")
     return "; or ".join(causes)
 
 

@@ -169,8 +169,11 @@ class PretrainedCLIPBase(nn.Module):
         pk = self._pack()        # ONE signature walk per forward; the towers below use the packed structs directly
         enc = pk["visual"].forward if self._video_tower else (lambda v: self._encode_vis(v, pk))
         if not self.overlap_towers or len(vis.shape) == 2:
+            # (visual tower first: on ONE stream the towers share a workspace, and the profiler reads the ragged text tower's device-side
+            # row count back after the forward -- it must still stand there)
+            fv = enc(vis)
             ft = pk["text"].forward(title, ids_b=texts_b)
-            return enc(vis), (text_tail(ft, False) if text_tail is not None else ft)
+            return fv, (text_tail(ft, False) if text_tail is not None else ft)
         # The weights were packed (converted / transposed / fused) above, on the CALLER's stream, before the fork: the side stream inherits
         # the dependency through wait_stream, and the packed tensors belong to the caller stream's allocator pool.
         # (Packed lazily inside the fork, the conversions would be enqueued on the side stream only, and the text

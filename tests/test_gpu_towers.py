@@ -869,6 +869,41 @@ def test_video_and_image_towers_in_ieee_half_mode_vs_oracle():
         assert errs[torch.float16] < errs[torch.bfloat16]
 
 
+def test_half_mode_vision_tower_falls_back_to_bf16_when_the_range_is_left():
+    """The IEEE-half mode's range guard (as the text tower's): a residual-stream value beyond +-65504 (ln_pre.bias[7] = 1e5) makes the
+    output non-finite; the FIRST forward after packing notices synchronously, re-packs the tower as bf16 operands, warns and recomputes
+    (finite); an overflow that first occurs in a LATER batch returns NaN rows for that call and switches at the next."""
+    import warnings
+    from vtc_amd import towers
+    a = A.VIT_B32
+    sd = A.synth_visual(a, 341, prefix="v.")
+    sd["v.ln_pre.bias"][7] = 1.0e5
+    x = A.synth_pixels((2, 3, 224, 224), 342)
+    pv = towers.PackedVision(cuda_sd(sd), "v.", torch.float16)
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        out = pv.forward(x.cuda())
+    assert pv.range_fallbacks == 1 and pv.dtype == torch.bfloat16 and any("IEEE-half range" in str(w.message) for w in wl)
+    assert torch.isfinite(out).all()
+    ref = CR.encode_image(x, sd, a, "v.").numpy()
+    print(f"[parity] half-mode vision tower after the bf16 fallback (a 1e5 channel in the stream): max err {np.abs(unit(out.cpu().numpy()) - unit(ref)).max():.3e}")
+    # a later batch: pixels that only then push a value out of range (a tame tower, one pixel plane scaled by 3e4)
+    sd2 = A.synth_visual(a, 343, prefix="v.")
+    pv2 = towers.PackedVision(cuda_sd(sd2), "v.", torch.float16)
+    assert torch.isfinite(pv2.forward(x.cuda())).all() and pv2.range_fallbacks == 0
+    big = x.clone()
+    big[1] *= 3.0e4
+    bad = pv2.forward(big.cuda())
+    torch.cuda.synchronize()
+    if torch.isfinite(bad).all():
+        pytest.skip("ln_pre tamed the scaled pixels: no overflow to test on this tower")
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        again = pv2.forward(big.cuda())
+    assert pv2.range_fallbacks == 1 and pv2.dtype == torch.bfloat16 and torch.isfinite(again).all()
+    assert any("earlier forward" in str(w.message) for w in wl)
+
+
 def test_config3_wrapper_in_ieee_half_mode_vs_oracle(monkeypatch):
     """compute_dtype = torch.float16 through the drop-in wrapper (config 3: TimeSformer + title + comments + CAM), ViT-B/32, B = 3: both
     embedding sets and the cosine similarity against the fp32 oracle, beside the bf16 mode on the same inputs; VTC_COMPUTE_DTYPE=f16 and

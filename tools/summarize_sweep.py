@@ -32,6 +32,6 @@ lines += ["", f"* distance GEMM (`EPI_L2MIN` = 6: three keys + bound per block, 
           "(bound: mfma + valu: K = 512 is 8 K-tiles per 256 x 256 tile, then the block-minima epilogue's VALU work: 13 vector instructions per value with four planes, 6 / 7 in modes 12 / 13 (keys straight from accumulators that start at -(norms)/2))",
           f"* whole sweep: {flop / 1e12:.3f} TFLOP / {tot / 1e6 / sweeps:.3f} ms of kernels = {flop / (tot / 1e9 / sweeps) / 1e12:.0f} TFLOP/s = "
           f"{flop / (tot / 1e9 / sweeps) / 2.5e15:.3f} of the bf16 MFMA peak.  (Rounds 1-4 also printed 2 x 8 N^2 bytes / time / 8 TB/s here -- the "
-          "bytes of a materialised fp32 matrix, which this sweep never writes; the counter-measured bytes are in profiles/r05_sweep_traffic.md.)"]
+          "bytes of a materialised fp32 matrix, which this sweep never writes; the counter-measured bytes are in profiles/rNN_sweep_traffic.md of the same round.)"]
 open(out, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

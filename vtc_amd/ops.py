@@ -370,8 +370,8 @@ def recall_bidir(a: torch.Tensor, b: torch.Tensor, k_vals: Sequence[int], ws: Op
 def split_recall_counters(hits_host: torch.Tensor):
     """(counters, nonfinite) of a HOST copy of the recall-only sweeps' hit counters: the NaN / inf marker (bit 40 and above of the first
     counter of a direction, summed over ranks) taken off."""
-    h = hits_host.to(torch.int64)
-    return h & (L.RECALL_NONFINITE - 1), bool((h >> 40).any())
+    h = hits_host.numpy()                # (numpy: a torch CPU op costs microseconds that the 10k sweep's 0.28 ms would show)
+    return torch.from_numpy(h & (L.RECALL_NONFINITE - 1)), bool((h >> 40).any())
 
 
 def recall_planes(k_vals: Sequence[int], n_total: int) -> int:

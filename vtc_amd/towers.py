@@ -174,8 +174,19 @@ def _pack_blocks(sd: SD, p: str, layers: int, dtype, keep: _Keep, timesformer: b
 
 class PackedVision:
     def __init__(self, sd: SD, prefix: str, dtype, fuse_temporal: bool = True):
+        self._src = (sd, prefix, fuse_temporal)          # references to the caller's tensors: the bf16 re-pack of the half mode's range guard
+        self._flag_dev = self._flag_host = None
+        self._calibrated = False
+        self.range_fallbacks = 0
+        self._build(dtype)
+
+    def _build(self, dtype):
+        sd, prefix, fuse_temporal = self._src
         sd, dev = _host_sd(sd, prefix)
         self.dtype, self.code, self.keep = dtype, ops.dtype_code(dtype), _Keep(dev)
+        if dtype == torch.float16 and self._flag_dev is None:
+            self._flag_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         k = self.keep
         conv = sd["conv1.weight"]
         w = L.VisionW()
@@ -206,9 +217,39 @@ class PackedVision:
         self.w = w
         self.res = w.grid * w.patch
 
+    # ---- range guard of the IEEE-half mode (round 6; as PackedText's) ------------------------------------------------------------
+    # compute_dtype = torch.float16 runs the tower on half operands with a half (hi, lo) residual stream: 11 significant bits, range
+    # +-65504.  A checkpoint whose activations leave that range shows as inf / NaN in the output: the FIRST forward after packing checks
+    # synchronously, re-packs the tower as bf16 and recomputes; later forwards carry the flag to pinned memory asynchronously and the
+    # next call switches (that call's NaN rows have been returned by then -- the wrappers' watchdog raises on them).
+    def _range_switch(self, why: str):
+        import warnings
+        warnings.warn(f"vtc_amd vision tower: {why}: a value left the IEEE-half range (+-65504) in the half-operand mode; re-packing the "
+                      "tower as bf16 operands (wider range, 8 significant bits instead of 11)", RuntimeWarning, stacklevel=3)
+        self.range_fallbacks += 1
+        self._flag_dev.zero_()
+        self._flag_host.zero_()
+        self._build(torch.bfloat16)
+
     @ops.on_device
     def forward(self, pixels: torch.Tensor) -> torch.Tensor:
-        """pixels [N,3,H,W] (image tower) or [N,F,3,H,W] (TimeSformer), fp32 or bf16 -> [N, embed] fp32."""
+        """pixels [N,3,H,W] (image tower) or [N,F,3,H,W] (TimeSformer), fp32 / bf16 / half / uint8 -> [N, embed] fp32."""
+        if self.dtype == torch.float16 and self._flag_host is not None and int(self._flag_host[0]) != 0:
+            self._range_switch("an earlier forward")         # pinned host memory: no synchronisation
+        out = self._forward(pixels)
+        if self.dtype != torch.float16:
+            return out
+        L.check(L.lib().vtc_nonfinite_flag(out.data_ptr(), out.numel(), self._flag_dev.data_ptr(), ops._stream()), "vtc_nonfinite_flag")
+        if not self._calibrated:
+            self._calibrated = True
+            if int(self._flag_dev.item()) != 0:               # first call after packing: synchronous
+                self._range_switch("first forward after packing")
+                return self._forward(pixels)
+            return out
+        self._flag_host.copy_(self._flag_dev, non_blocking=True)
+        return out
+
+    def _forward(self, pixels: torch.Tensor) -> torch.Tensor:
         w = self.w
         if pixels.dim() == 4:
             pixels = pixels.unsqueeze(1)

@@ -21,6 +21,7 @@ torch.set_grad_enabled(False)
 EXTENDED = __import__("os").environ.get("VTC_TEST_EXTENDED") == "1" or "--extended" in __import__("sys").argv
 ARCH = {"TINY": A.TINY, "VIT_B32": A.VIT_B32, "VIT_B16": A.VIT_B16, "VIT_L14": A.VIT_L14}
 DTYPES = [torch.float32, torch.bfloat16]
+DTYPES_H = DTYPES + [torch.float16]      # + the IEEE-half mode of the vision towers (round 6): the tower goldens and the larger model types
 
 
 def tol_for(dtype, embed_dim=512):
@@ -67,7 +68,7 @@ def report_text(name, got, want, dtype, embed_dim):
     assert d.max() < tol, f"{name}: max {d.max()} rms {rms} >= {tol}"
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype", DTYPES_H)
 @pytest.mark.parametrize("fname", golden_files("tower_alt_"))
 def test_timesformer_tower_vs_golden(fname, dtype):
     from vtc_amd import towers
@@ -86,7 +87,7 @@ def test_timesformer_tower_vs_golden(fname, dtype):
             assert np.abs(out - g["out"]).max() < 2e-5 * max(1.0, np.abs(g["out"]).max())
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype", DTYPES_H)
 @pytest.mark.parametrize("fname", golden_files("tower_v1_"))
 def test_timesformer_v1_tower_vs_golden(fname, dtype):
     """model/timesformer_clip.py (older variant: global cls attention, no temporal_fc)."""
@@ -1053,7 +1054,7 @@ def test_every_model_type_forward_vs_oracle(arch_name, model_type):
     img = A.synth_pixels((3, 3, 224, 224), 97)
     refi = CR.encode_image(img, sdi, a, "model.visual.").numpy()
     from vtc_amd import towers
-    for dtype in DTYPES:
+    for dtype in DTYPES_H:
         pv = towers.PackedVision(cuda_sd({k: v for k, v in sdi.items() if k.startswith("model.visual.")}), "model.visual.", dtype)
         out = pv.forward(img.cuda()).cpu().numpy()
         report(f"{model_type} image tower {dtype}", np.abs(unit(out) - unit(refi)).max(), tol_for(dtype, 512))

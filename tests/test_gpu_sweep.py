@@ -689,3 +689,9 @@ def test_nonfinite_rows_are_misses_in_the_rank_path_and_rejected_by_the_metric()
     ok = torch.from_numpy(np.nan_to_num(a, nan=0.0)).cuda()
     with pytest.raises(ValueError, match="in the titles features"):
         m.compute(ok, fb)
+    # (c) the sharded kernels (three simulated ranks on this card): the marker rides in the partial counters of the rank that owns the bad
+    # row -- what the all-reduce carries to every rank -- and the counters under it equal the single-GPU call's
+    single, _ = ops.split_recall_counters(ops.recall_bidir(fa, fb, [1, 5, 10]).cpu())
+    sharded_raw = torch.from_numpy(_play_rank_sharded(a, b, 3, [1, 5, 10]))
+    sharded, marked = ops.split_recall_counters(sharded_raw)
+    assert marked and torch.equal(sharded, single)

@@ -217,3 +217,16 @@ def test_oracle_retrieval_loop_follows_the_reference_comment_rules():
     calls.clear()
     E.retrieval_evaluation_loop(forward, [(fr, cap, "a")], False, first_frame_only=True)
     assert calls[0][0] == (1, 3, 2, 2) and calls[0][2] is None
+
+
+def test_recall_counters_carry_the_nonfinite_marker():
+    """include/vtc_hip.h VTC_RECALL_NONFINITE: bit 40 of a direction's first counter says "a pair with a non-finite target distance was
+    counted as a miss"; summed over ranks it stays above bit 40 and the counters stay below it."""
+    from vtc_amd import _lib as L
+    from vtc_amd import ops
+    assert L.RECALL_NONFINITE == 1 << 40
+    raw = torch.tensor([[7 + 3 * L.RECALL_NONFINITE, 50, 100], [2, 5, 9]], dtype=torch.int64)       # three ranks raised the marker
+    counters, marked = ops.split_recall_counters(raw)
+    assert marked and counters.tolist() == [[7, 50, 100], [2, 5, 9]]
+    counters, marked = ops.split_recall_counters(torch.tensor([[7, 50, 100], [2, 5, 9]], dtype=torch.int64))
+    assert not marked and counters.tolist() == [[7, 50, 100], [2, 5, 9]]
